@@ -1,0 +1,149 @@
+"""Oracle: walk, losses, optimiser and the whole per-batch training step (plain torch autograd on CPU).
+TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import nets, sg2
+
+
+def to_torch(state, dtype=torch.float32):
+    return {k: (torch.from_numpy(np.asarray(v)).to(dtype) if np.asarray(v).dtype.kind == 'f'
+                else torch.from_numpy(np.asarray(v))) for k, v in state.items()}
+
+
+def get_w(PG, z, n_latent):
+    """TransformGraph.get_w (transform_base.py:372-378): [style(z)] * n_latent (same tensor object)."""
+    w = sg2.style_mlp(PG, z)
+    return [w] * n_latent
+
+
+def walk_linear_multi_w(ws, alpha, walk_w, layers=None):
+    """WalkLinearMultiW.forward (transform_base.py:151-165): w_i + alpha @ W[:, i, :] for i in layers (or all)."""
+    out = []
+    for i in range(len(ws)):
+        if layers is None or i in layers:
+            out.append(ws[i] + torch.mm(alpha, walk_w[:, i, :]))
+        else:
+            out.append(ws[i])
+    return out
+
+
+def get_logits(PG, ws, noise=None):
+    """TransformGraph.get_logits, 'w' branch (transform_base.py:348-355): stack -> [B,n_latent,512] -> netG."""
+    latent = torch.stack(ws).transpose(0, 1)
+    return sg2.generator_synthesis(PG, latent, noise)
+
+
+def get_reg_preds(PR, img, attr_idx):
+    """TransformGraph.get_reg_preds (transform_base.py:396-403): integer column select, bit-exact."""
+    preds = nets.resnet50_forward(PR, img)[:, attr_idx]
+    if preds.dim() == 1:
+        preds = preds.unsqueeze(1)
+    return preds
+
+
+def get_alphas(alpha_org, alpha_target):
+    """sg2 TransformGraph.get_alphas (transform_base.py:405-408): epsilon = target - org."""
+    return alpha_target - alpha_org
+
+
+def get_alphas_clamp(alpha_org, alpha_delta):
+    """pggan variant used by train_multi_attr.py:113 (graphs/pggan/transform_base.py:358-364)."""
+    alpha_target = torch.clamp(alpha_org + alpha_delta, min=0, max=1)
+    return alpha_target, alpha_target - alpha_org
+
+
+def bce_loss(pred, y, eps=1e-12):
+    """get_bce_loss (transform_base.py:412-414) on RAW regressor outputs."""
+    return -(y * pred.clamp(min=eps).log() + (1 - y) * (1 - pred).clamp(min=eps).log()).mean()
+
+
+def reg_loss(PR, logit, alpha, attr_idx):
+    """get_reg_loss (transform_base.py:416-424): alpha -> float64, so the loss is float64."""
+    preds = nets.resnet50_forward(PR, logit)[:, attr_idx]
+    return bce_loss(preds, alpha.to(torch.double)).mean()
+
+
+def content_loss(PV, org, shifted):
+    """get_content_loss + averaging in optimizeParametersAll (transform_base.py:426-454,465-470):
+    mean over 4 taps of mse(feat(org).detach(), feat(shifted))."""
+    with torch.no_grad():
+        fo = nets.vgg19_taps(PV, org)
+    fs = nets.vgg19_taps(PV, shifted)
+    losses = [F.mse_loss(a.detach(), b) for a, b in zip(fo, fs)]
+    return sum(losses) / len(losses), losses
+
+
+def gan_loss(PD, logit):
+    """BCEWithLogits(netD(logit), ones) (transform_base.py:460-463)."""
+    d = sg2.discriminator_forward(PD, logit)
+    return F.binary_cross_entropy_with_logits(d, torch.ones_like(d))
+
+
+def total_loss(reg, cont, gan, no_content_loss=False, no_gan_loss=False):
+    """Weighting rule transform_base.py:475-486."""
+    loss = reg if (no_content_loss and no_gan_loss) else 10 * reg
+    if not no_content_loss:
+        loss = loss + 0.05 * cont
+    if not no_gan_loss:
+        loss = loss + 0.05 * gan
+    return loss
+
+
+class Adam:
+    """torch.optim.Adam(lr, betas=(0.5, 0.99), eps=1e-8) restated (transform_base.py:329-331)."""
+
+    def __init__(self, param, lr, betas=(0.5, 0.99), eps=1e-8):
+        self.p, self.lr, self.b1, self.b2, self.eps = param, lr, betas[0], betas[1], eps
+        self.m = torch.zeros_like(param)
+        self.v = torch.zeros_like(param)
+        self.t = 0
+
+    def step(self, grad):
+        self.t += 1
+        self.m = self.b1 * self.m + (1 - self.b1) * grad
+        self.v = self.b2 * self.v + (1 - self.b2) * grad * grad
+        bc1 = 1 - self.b1 ** self.t
+        bc2 = 1 - self.b2 ** self.t
+        denom = self.v.sqrt() / math.sqrt(bc2) + self.eps
+        self.p = self.p - (self.lr / bc1) * self.m / denom
+        return self.p
+
+
+def train_step(nets_state, walk_w, z, alpha_for_graph, attr_idx, layers=None, noise=None, noise2=None,
+               no_content_loss=False, no_gan_loss=False, clamp_variant=False):
+    """One iteration of the hot loop (train.py:48-110 -> transform_base.py:456-490).
+
+    nets_state: dict(G=..., R=..., V=..., D=...) of torch state dicts.  walk_w: [C, n_latent, 512] tensor.
+    alpha_for_graph: [B, C] float tensor (``ag`` of train.py:84-85).  Returns a dict with images, predictions,
+    the individual loss terms, the total loss (float64) and d loss / d walk_w.
+    """
+    PG, PR, PV, PD = nets_state['G'], nets_state['R'], nets_state.get('V'), nets_state.get('D')
+    n_latent = walk_w.shape[1]
+    walk_w = walk_w.detach().clone().requires_grad_(True)
+    ws = get_w(PG, z, n_latent)                                           # train.py:62
+    x0 = get_logits(PG, ws, noise)                                        # train.py:66
+    a0 = get_reg_preds(PR, x0, attr_idx)                                  # train.py:69
+    if clamp_variant:                                                     # train_multi_attr.py:113,133
+        target, eps = get_alphas_clamp(a0, alpha_for_graph)
+    else:                                                                 # train.py:86
+        target, eps = alpha_for_graph, get_alphas(a0, alpha_for_graph)
+    w1 = walk_linear_multi_w(ws, eps, walk_w, layers)                     # train.py:89
+    x1 = get_logits(PG, w1, noise if noise2 is None else noise2)          # train.py:94
+    reg = reg_loss(PR, x1, target, attr_idx)
+    cont = torch.zeros((), dtype=x1.dtype)
+    cont_terms = []
+    gan = torch.zeros((), dtype=x1.dtype)
+    if not no_content_loss:
+        cont, cont_terms = content_loss(PV, x0, x1)
+    if not no_gan_loss:
+        gan = gan_loss(PD, x1)
+    loss = total_loss(reg, cont, gan, no_content_loss, no_gan_loss)
+    grad, = torch.autograd.grad(loss, walk_w)
+    return dict(x0=x0.detach(), x1=x1.detach(), alpha_org=a0.detach(), eps=eps.detach(), target=target.detach(),
+                reg=reg.detach(), cont=cont.detach(), cont_terms=[c.detach() for c in cont_terms],
+                gan=gan.detach(), loss=loss.detach(), grad=grad.detach())
