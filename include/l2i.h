@@ -1,0 +1,138 @@
+/*
+ * l2i.h — C ABI of libl2i_hip.so: the hand-written gfx950 (MI355X / CDNA4) kernels behind the Latent2im
+ * walk-training hot path.
+ *
+ * Drop-in boundary.  The reference's only native code is two pybind/CUDA extensions that are JIT-built at
+ * import (graphs/stylegan_v2_real/op/fused_act.py:10-16, op/upfirdn2d.py:9-15).  The entry points below are
+ * what an FFI for this path binds instead:
+ *
+ *   l2i_fused_bias_act_f32   replaces  fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ *                                      op/fused_bias_act.cpp:11-21, op/fused_bias_act_kernel.cu:18-98
+ *   l2i_upfirdn2d_f32        replaces  upfirdn2d_op.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y,
+ *                                      pad_x0, pad_x1, pad_y0, pad_y1)
+ *                                      op/upfirdn2d.cpp:12-23, op/upfirdn2d_kernel.cu:140-272
+ *   l2i_conv2d_f32           replaces  the F.conv2d(groups=batch) / F.conv_transpose2d(groups=batch) /
+ *                                      weight-materialisation sequence of ModulatedConv2d.forward
+ *                                      (networks.py:231-272), EqualConv2d.forward (networks.py:111-120) and the
+ *                                      torchvision ResNet-50 / VGG-19 conv(+BN eval)+ReLU blocks called at
+ *                                      transform_base.py:396-403,416-454, and their input-gradients
+ *   l2i_torgb_* / l2i_sg2_act_bwd_f32 / l2i_dot_reduce_f32 / l2i_maxpool2d_* / l2i_sqdiff_f32
+ *                            the streaming (HBM-bound) companions of the above on the same path:
+ *                            ToRGB (networks.py:339-358), lrelu backward + style-gradient reductions,
+ *                            MaxPool2d of ResNet/VGG, ContentLoss (transform_base.py:57-63).
+ *
+ * Conventions: every pointer is a DEVICE pointer to contiguous float32 (NCHW for maps); the caller owns all
+ * buffers (nothing is allocated here); `stream` is a hipStream_t passed as void*; kernels are enqueued
+ * asynchronously; return value 0 = enqueued, negative = L2I_E_* (nothing enqueued).  Thread-safe for distinct
+ * streams.  No torch types anywhere in this ABI.
+ */
+#ifndef L2I_H
+#define L2I_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2I_OK 0
+#define L2I_E_ARG (-1)      /* invalid argument combination */
+#define L2I_E_LAUNCH (-2)   /* hipLaunch failed (see l2i_last_error) */
+#define L2I_E_UNSUPPORTED (-3)
+
+#define L2I_ACT_NONE 0
+#define L2I_ACT_LRELU 1     /* y = (v > 0 ? v : v*slope) * gain */
+#define L2I_ACT_RELU 2
+
+/* Generic 2-D correlation as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
+ *   y[b,co,oy*oy_step+oy_off,ox*ox_step+ox_off] = epi( sum_{ci,ky,kx} pro(x)[b,ci,oy*stride-pad_y+ky,ox*stride-pad_x+kx]
+ *                                                       * w[ci][ky*KW+kx][co] )     for oy<OH, ox<OW
+ *   pro(x) = x * in_scale[b,ci] * (in_mask ? (in_mask[same idx] > 0 ? mask_pos : mask_neg) : 1)
+ *   epi(a) = act( a*out_scale[b,co] * (out_mask ? (out_mask[idx] > 0 ? 1 : 0) : 1) + noise[b,oyf,oxf]*noise_w + bias[co]
+ *                 + residual[idx] * (res_mask ? (res_mask[idx] > 0 ? 1 : 0) : 1) ) * out_gain  (+ y[idx] if accumulate)
+ * Out-of-range input coordinates read as zero (that is the padding).  Transposed (stride-2) convolutions are issued
+ * as one call per output phase with (oy_step, ox_step) = 2 and a per-phase packed sub-kernel. */
+typedef struct l2i_conv_params {
+    const float* x;         /* [B, Cin, H, W] */
+    const float* w;         /* packed [Cin][KH*KW][CoutP], CoutP = Cout rounded up to 32, zero padded */
+    float* y;               /* [B, Cout, OHf, OWf] */
+    int32_t B, Cin, H, W, Cout, CoutP;
+    int32_t KH, KW, stride, pad_y, pad_x;
+    int32_t OH, OW, OHf, OWf;
+    int32_t oy_step, ox_step, oy_off, ox_off;
+    const float* in_scale;  /* [B, Cin] or NULL */
+    const float* in_mask;   /* like x, or NULL */
+    float mask_pos, mask_neg;
+    const float* out_scale; /* [B, Cout] or NULL */
+    const float* noise;     /* [B, 1, OHf, OWf] or NULL */
+    float noise_w;
+    const float* bias;      /* [Cout] or NULL */
+    const float* residual;  /* like y, or NULL */
+    const float* res_mask;  /* like y, or NULL */
+    const float* out_mask;  /* like y, or NULL */
+    int32_t act;
+    float act_slope, act_gain, out_gain;
+    int32_t accumulate;
+    int32_t tile_hint;      /* 0 = auto, else 1..N selects a tile configuration (tuning / tests) */
+} l2i_conv_params;
+
+int l2i_conv2d_f32(const l2i_conv_params* p, void* stream);
+
+/* out[i] = act_grad_table(x[i] + b[(i / step_b) % size_b], ref[i]) * scale   — the reference op, all six
+ * act*10+grad cases (fused_bias_act_kernel.cu:36-47).  b / ref may be NULL (= the reference's empty tensors). */
+int l2i_fused_bias_act_f32(float* y, const float* x, const float* b, const float* ref, int64_t n,
+                           int64_t step_b, int64_t size_b, int act, int grad, float alpha, float scale, void* stream);
+
+/* The reference op on [major, in_h, in_w] maps (minor_dim == 1, the only layout the path uses:
+ * op/upfirdn2d.py:98) with an optional fused epilogue (all NULL/0 = the plain reference op):
+ *   y = act( fir(x) + noise[b,oy,ox]*noise_w + bias[c] + addend[idx] ) * act_gain,   major = b*channels + c */
+int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw,
+                      int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                      int channels, const float* noise, float noise_w, const float* bias, const float* addend,
+                      int act, float act_slope, float act_gain, void* stream);
+
+/* ToRGB 1x1 modulated conv without demodulation (networks.py:346-351):
+ *   rgb[b,o,p] = sum_c x[b,c,p] * wmod[b,o,c] + bias[o],  wmod = scale*W[o,c]*s[b,c] prepared by the caller [B,3,C] */
+int l2i_torgb_fwd_f32(float* rgb, const float* x, const float* wmod, const float* bias, int B, int C, int64_t HW,
+                      void* stream);
+
+/* Fused elementwise backward of one StyledConv output (FusedLeakyReLU + NoiseInjection + demod bookkeeping) with the
+ * ToRGB branch folded in:
+ *   g      = gin[idx]*gin_scale[b,c] + sum_o wmod_rgb[b,o,c]*grgb[b,o,p]          (either part optional)
+ *   dz     = g * (y > 0 ? gain : gain*slope)                                        -> dz[idx]
+ *   zpre   = (y > 0 ? y/gain : y/(gain*slope)) - bias[c] - noise[b,p]*noise_w
+ *   red_dz_z[b,c] += sum_p dz*zpre            (-> d demod)        red_x_grgb[b,c,o] += sum_p y*grgb[b,o,p]  (-> d s_rgb)
+ * Reduction buffers must be zeroed by the caller. */
+int l2i_sg2_act_bwd_f32(float* dz, const float* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb,
+                        const float* y, const float* bias, const float* noise, float noise_w, float slope, float gain,
+                        float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream);
+
+/* out[r] (+)= sum_p a[r,p] * (b ? b[r,p] : 1), r < rows (rows = B*C).  `out` must be zeroed by the caller. */
+int l2i_dot_reduce_f32(float* out, const float* a, const float* b, int64_t rows, int64_t cols, void* stream);
+
+/* MaxPool2d(k, s, pad) on [N, H, W] planes; idx holds the window-local argmax (first maximum in row-major order, like
+ * ATen) so that the backward is exact under ties. */
+int l2i_maxpool2d_fwd_f32(float* y, uint8_t* idx, const float* x, int64_t planes, int H, int W, int k, int s, int pad,
+                          int OH, int OW, void* stream);
+int l2i_maxpool2d_bwd_f32(float* gx, const float* gy, const uint8_t* idx, int64_t planes, int H, int W, int k, int s,
+                          int pad, int OH, int OW, void* stream);
+
+/* ContentLoss (transform_base.py:57-63): sum_out[0] += sum (a-b)^2 ; grad[i] = coef*(coef_dev ? coef_dev[0] : 1)*(b[i]-a[i])
+ * (= d/d b of the scaled loss; coef_dev is a device scalar so that the upstream gradient needs no host sync).
+ * sum_out / grad / coef_dev may each be NULL. */
+int l2i_sqdiff_f32(float* sum_out, float* grad, const float* a, const float* b, int64_t n, float coef,
+                   const float* coef_dev, void* stream);
+
+/* y[i] = a[i]*sa[(i/step) % ...] ... small utilities */
+int l2i_axpby_f32(float* y, const float* a, const float* b, float alpha, float beta, int64_t n, void* stream);
+
+/* relu-masked copy: y = g * (ref > 0 ? 1 : 0) */
+int l2i_relu_mask_f32(float* y, const float* g, const float* ref, int64_t n, void* stream);
+
+const char* l2i_last_error(void);
+int l2i_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L2I_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of libl2i_hip.so (the C ABI declared in include/l2i.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no CPU fallback: every
+op in this package raises if the library is missing or a kernel call is made without a GPU tensor.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libl2i_hip.so')
+
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int32
+c_p = ctypes.c_void_p
+c_l = ctypes.c_int64
+
+
+class ConvParams(ctypes.Structure):
+    """Mirror of ``struct l2i_conv_params`` (include/l2i.h) — field order and types must match."""
+    _fields_ = [
+        ('x', c_p), ('w', c_p), ('y', c_p),
+        ('B', c_i), ('Cin', c_i), ('H', c_i), ('W', c_i), ('Cout', c_i), ('CoutP', c_i),
+        ('KH', c_i), ('KW', c_i), ('stride', c_i), ('pad_y', c_i), ('pad_x', c_i),
+        ('OH', c_i), ('OW', c_i), ('OHf', c_i), ('OWf', c_i),
+        ('oy_step', c_i), ('ox_step', c_i), ('oy_off', c_i), ('ox_off', c_i),
+        ('in_scale', c_p), ('in_mask', c_p), ('mask_pos', c_f), ('mask_neg', c_f),
+        ('out_scale', c_p), ('noise', c_p), ('noise_w', c_f), ('bias', c_p),
+        ('residual', c_p), ('res_mask', c_p), ('out_mask', c_p),
+        ('act', c_i), ('act_slope', c_f), ('act_gain', c_f), ('out_gain', c_f),
+        ('accumulate', c_i), ('tile_hint', c_i),
+    ]
+
+
+_SIGNATURES = {
+    'l2i_conv2d_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
+    'l2i_fused_bias_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
+    'l2i_upfirdn2d_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                c_i, c_p, c_f, c_p, c_p, c_i, c_f, c_f, c_p]),
+    'l2i_torgb_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
+    'l2i_sg2_act_bwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_l, c_p]),
+    'l2i_dot_reduce_f32': (c_i, [c_p, c_p, c_p, c_l, c_l, c_p]),
+    'l2i_maxpool2d_fwd_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'l2i_maxpool2d_bwd_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'l2i_sqdiff_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p]),
+    'l2i_axpby_f32': (c_i, [c_p, c_p, c_p, c_f, c_f, c_l, c_p]),
+    'l2i_relu_mask_f32': (c_i, [c_p, c_p, c_p, c_l, c_p]),
+    'l2i_last_error': (ctypes.c_char_p, []),
+    'l2i_abi_version': (c_i, []),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class L2IError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise L2IError('%s is missing: run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950); '
+                           'there is no CPU fallback for the hot path' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)           # AttributeError if the export is absent
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise L2IError('%s failed (%d): %s' % (what, rc, load().l2i_last_error().decode()))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32/uint8 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L2IError('l2i kernels take GPU tensors only (got a %s tensor): no CPU fallback' % t.device)
+    if not t.is_contiguous():
+        raise L2IError('l2i kernels take contiguous tensors')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def fptr(t):
+    if t is not None and t.dtype != torch.float32:
+        raise L2IError('expected float32, got %s' % t.dtype)
+    return ptr(t)

@@ -1,0 +1,16 @@
+"""Module-level constants of the StyleGAN2 graph (reference graphs/stylegan_v2_real/constants.py:1-18), read by the
+drivers as ``constants.BATCH_SIZE`` (train.py:36).  The reference hard-codes 256^2 / batch 4; here ``--resolution`` and
+``--batch_size`` overwrite them before the graph is built (BASELINE configs 3-5 run 1024^2)."""
+BATCH_SIZE = 4
+DIM_Z = 512
+resolution = 256
+useGPU = True
+NUM_CHANNELS = 3
+
+# checkpoint paths (reference placeholders '/path/...'); a missing file selects deterministic synthetic weights
+reg_json = None
+reg_path = '/path/003_dict.model'
+g_path = '/path/550000.pt'
+vgg_path = ''
+
+SYNTH_SEED_G, SYNTH_SEED_D, SYNTH_SEED_R, SYNTH_SEED_V = 100, 200, 300, 400

@@ -1,0 +1,169 @@
+"""Frozen 2-D convolutions on the MI355X matrix cores: weight packing, launch plans (forward and input-gradient)
+and the thin Python call into ``l2i_conv2d_f32``.
+
+Every dense contraction of the walk-training path is a *frozen-weight* convolution (the only trainable tensor
+is the walk, reference transform_base.py:329-331), so weights are packed once at construction into the
+K-major layout the kernel streams (``[Cin][KH*KW][CoutP]``) — for the forward pass and, separately, for the
+input-gradient pass (transposed / flipped / split into stride-2 phases).  No weight-gradient is ever computed.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvParams  # noqa: F401
+
+
+def pack_weight(w):
+    """[Cout, Cin, KH, KW] -> packed [Cin, KH*KW, CoutP] (CoutP = Cout rounded up to 32, zero padded)."""
+    w = torch.as_tensor(w, dtype=torch.float32)
+    cout, cin, kh, kw = w.shape
+    coutp = (cout + 31) // 32 * 32
+    p = torch.zeros(cin, kh * kw, coutp, dtype=torch.float32)
+    p[:, :, :cout] = w.permute(1, 2, 3, 0).reshape(cin, kh * kw, cout)
+    return p.contiguous()
+
+
+class Launch:
+    """One call of the kernel: a stride-1/2 correlation writing every (oy_step, ox_step)-th output pixel."""
+    __slots__ = ('w', 'cin', 'cout', 'kh', 'kw', 'stride', 'pad_y', 'pad_x', 'step', 'off_y', 'off_x')
+
+    def __init__(self, w_oihw, stride, pad_y, pad_x, step=1, off_y=0, off_x=0, device=None):
+        self.cout, self.cin, self.kh, self.kw = w_oihw.shape
+        self.w = pack_weight(w_oihw).to(device) if device is not None else pack_weight(w_oihw)
+        self.stride, self.pad_y, self.pad_x = stride, pad_y, pad_x
+        self.step, self.off_y, self.off_x = step, off_y, off_x
+
+    def to(self, device):
+        self.w = self.w.to(device)
+        return self
+
+
+def correlation_plan(w_oihw, stride, pad):
+    """y[co,o] = sum x[ci, o*stride - pad + k] * w[co,ci,k]."""
+    return [Launch(torch.as_tensor(w_oihw, dtype=torch.float32), stride, pad, pad)]
+
+
+def _phase_axis(K, pad, pi):
+    """Taps of a stride-2 transposed conv (o = 2i + k - pad) that land on outputs of parity ``pi``:
+    returns (tap indices in correlation order, correlation padding) or (None, 0) when the phase is empty."""
+    k0 = (pi + pad) % 2
+    ks = list(range(k0, K, 2))
+    if not ks:
+        return None, 0
+    A = len(ks)
+    d = (pi + pad - k0) // 2
+    taps = [k0 + 2 * (A - 1 - a) for a in range(A)]     # w'[a] = w[k0 + 2(A-1-a)]
+    return taps, (A - 1) - d
+
+
+def transposed_plan(w_oihw, pad):
+    """Stride-2 transposed convolution y[co, 2i+k-pad] += x[ci,i]*w[co,ci,k] as <= 4 stride-1 correlations, one per
+    output parity (same MAC count as the dense form; nothing multiplies an inserted zero)."""
+    w = torch.as_tensor(w_oihw, dtype=torch.float32)
+    K = w.shape[2]
+    assert w.shape[3] == K
+    plan = []
+    for py in (0, 1):
+        ty, pad_y = _phase_axis(K, pad, py)
+        for px in (0, 1):
+            tx, pad_x = _phase_axis(K, pad, px)
+            if ty is None or tx is None:
+                plan.append(None)
+                continue
+            sub = w[:, :, ty, :][:, :, :, tx].contiguous()
+            plan.append(Launch(sub, 1, pad_y, pad_x, step=2, off_y=py, off_x=px))
+    return plan
+
+
+def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0), out_scale=None, noise=None,
+               noise_w=0.0, bias=None, residual=None, res_mask=None, out_mask=None, act=ACT_NONE, slope=0.2, gain=1.0,
+               out_gain=1.0, accumulate=False, tile_hint=0):
+    """Enqueue one kernel call on the current stream.  ``y`` is the full output tensor [B, Cout, OHf, OWf]."""
+    lib = _lib.load()
+    B, cin, H, W = x.shape
+    assert cin == L.cin, (cin, L.cin)
+    assert y.shape[0] == B and y.shape[1] == L.cout, (y.shape, B, L.cout)
+    OHf, OWf = y.shape[2], y.shape[3]
+    if L.step == 1:
+        OH, OW = OHf, OWf
+    else:
+        OH = (OHf - L.off_y + L.step - 1) // L.step
+        OW = (OWf - L.off_x + L.step - 1) // L.step
+    if OH <= 0 or OW <= 0:
+        return
+    p = ConvParams()
+    p.x, p.w, p.y = _lib.fptr(x), _lib.fptr(L.w), _lib.fptr(y)
+    p.B, p.Cin, p.H, p.W, p.Cout, p.CoutP = B, cin, H, W, L.cout, L.w.shape[2]
+    p.KH, p.KW, p.stride, p.pad_y, p.pad_x = L.kh, L.kw, L.stride, L.pad_y, L.pad_x
+    p.OH, p.OW, p.OHf, p.OWf = OH, OW, OHf, OWf
+    p.oy_step = p.ox_step = L.step
+    p.oy_off, p.ox_off = L.off_y, L.off_x
+    p.in_scale, p.in_mask = _lib.fptr(in_scale), _lib.fptr(in_mask)
+    p.mask_pos, p.mask_neg = mask
+    p.out_scale, p.noise, p.noise_w, p.bias = _lib.fptr(out_scale), _lib.fptr(noise), float(noise_w), _lib.fptr(bias)
+    p.residual, p.res_mask, p.out_mask = _lib.fptr(residual), _lib.fptr(res_mask), _lib.fptr(out_mask)
+    p.act, p.act_slope, p.act_gain, p.out_gain = act, slope, gain, out_gain
+    p.accumulate, p.tile_hint = int(accumulate), tile_hint
+    if in_mask is not None:
+        assert in_mask.shape == x.shape
+    if residual is not None:
+        assert residual.shape == y.shape
+    if out_mask is not None:
+        assert out_mask.shape == y.shape
+    _lib.check(lib.l2i_conv2d_f32(p, _lib.stream_ptr()), 'l2i_conv2d_f32')
+
+
+def run_plan(plan, x, y, accumulate=False, **kw):
+    """Run every phase of a plan into ``y``.  Empty phases leave zeros (or the accumulated value) behind."""
+    if any(L is None for L in plan) and not accumulate:
+        y.zero_()
+    for L in plan:
+        if L is not None:
+            run_launch(L, x, y, accumulate=accumulate, **kw)
+    return y
+
+
+class FrozenConv2d:
+    """A convolution (or stride-2 transposed convolution) with constant weights: forward plan + input-gradient plan.
+
+    ``weight`` is [Cout, Cin, K, K] in *correlation* form.  For ``transposed=True`` it means
+    y[co, 2i+k-pad] += x[ci, i] * weight[co, ci, k]  (F.conv_transpose2d(x, weight.transpose(0,1), stride=2))."""
+
+    def __init__(self, weight, stride=1, padding=0, transposed=False, device='cuda'):
+        w = torch.as_tensor(np.asarray(weight) if not torch.is_tensor(weight) else weight, dtype=torch.float32).cpu()
+        self.cout, self.cin, self.k, _ = w.shape
+        self.stride, self.padding, self.transposed = stride, padding, transposed
+        wt = w.transpose(0, 1).contiguous()                       # [Cin, Cout, K, K]: roles swapped for the gradient
+        if transposed:
+            assert stride == 2
+            self.fwd = transposed_plan(w, padding)
+            self.bwd = correlation_plan(wt, 2, padding)           # dx[ci,i] = sum gy[co, 2i+k-pad] w[co,ci,k]
+        else:
+            self.fwd = correlation_plan(w, stride, padding)
+            if stride == 1:
+                self.bwd = correlation_plan(torch.flip(wt, [2, 3]), 1, self.k - 1 - padding)
+            else:
+                assert stride == 2
+                self.bwd = transposed_plan(wt, padding)           # dx[ci, 2o+k-pad] += gy[co,o] w[co,ci,k]
+        for L in self.fwd + self.bwd:
+            if L is not None:
+                L.to(device)
+
+    def out_hw(self, h, w):
+        if self.transposed:
+            return (h - 1) * 2 - 2 * self.padding + self.k, (w - 1) * 2 - 2 * self.padding + self.k
+        return (h + 2 * self.padding - self.k) // self.stride + 1, (w + 2 * self.padding - self.k) // self.stride + 1
+
+    def forward(self, x, out=None, **kw):
+        oh, ow = self.out_hw(x.shape[2], x.shape[3])
+        if out is None:
+            out = torch.empty(x.shape[0], self.cout, oh, ow, device=x.device, dtype=torch.float32)
+        return run_plan(self.fwd, x, out, **kw)
+
+    def dgrad(self, gy, in_hw, out=None, **kw):
+        """Gradient w.r.t. the input of ``forward`` given the gradient ``gy`` w.r.t. its (pre-epilogue) output."""
+        if out is None:
+            out = torch.empty(gy.shape[0], self.cin, in_hw[0], in_hw[1], device=gy.device, dtype=torch.float32)
+        return run_plan(self.bwd, gy, out, **kw)

@@ -1,0 +1,20 @@
+// Shared by the translation units of libl2i_hip.so (not part of the public ABI).
+#ifndef L2I_INTERNAL_H
+#define L2I_INTERNAL_H
+#include <hip/hip_runtime.h>
+
+int l2i_set_error(int code, const char* msg);   // records msg for l2i_last_error(), returns code
+
+#define L2I_CHECK_LAUNCH()                                                      \
+    do {                                                                        \
+        hipError_t e_ = hipGetLastError();                                      \
+        if (e_ != hipSuccess) return l2i_set_error(L2I_E_LAUNCH, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int l2i_grid_for(long long work_items, int per_block, int cap = 256 * 8) {
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+#endif

@@ -1,0 +1,459 @@
+// l2i_stream.hip — the HBM-bound kernels of the walk-training path (gfx950): fused_bias_act, upfirdn2d (+fused
+// StyledConv / ToRGB epilogues), ToRGB, the fused StyledConv backward (leaky-ReLU' + style-gradient reductions),
+// row reductions, max-pool and the content-loss difference.  All are one-pass streaming kernels: 16-byte
+// per-lane accesses where the layout allows, wave64 shuffles + one atomic per wave for the reductions, grids capped
+// at 8 blocks/CU with grid-stride loops.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include "l2i.h"
+#include "l2i_internal.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+int l2i_set_error(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+    return code;
+}
+extern "C" const char* l2i_last_error(void) { return g_err; }
+extern "C" int l2i_abi_version(void) { return 1; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused_bias_act: reference op/fused_bias_act_kernel.cu:18-49 (all act*10+grad cases)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fba_one(float x, float r, int code, float alpha, float scale) {
+    float y;
+    switch (code) {
+        default:
+        case 10: case 11: y = x; break;
+        case 12: case 32: y = 0.f; break;
+        case 30: y = (x > 0.f) ? x : x * alpha; break;
+        case 31: y = (r > 0.f) ? x : x * alpha; break;
+    }
+    return y * scale;
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void fba_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ b,
+                                                  const float* __restrict__ ref, long long n, long long step_b, long long size_b,
+                                                  int code, float alpha, float scale) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    if (VEC4) {
+        const long long n4 = n >> 2;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            float4 v = reinterpret_cast<const float4*>(x)[i];
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ref) r = reinterpret_cast<const float4*>(ref)[i];
+            float bv = 0.f;
+            if (b) bv = b[((i << 2) / step_b) % size_b];      // step_b % 4 == 0: one channel per float4
+            float4 o;
+            o.x = fba_one(v.x + bv, r.x, code, alpha, scale);
+            o.y = fba_one(v.y + bv, r.y, code, alpha, scale);
+            o.z = fba_one(v.z + bv, r.z, code, alpha, scale);
+            o.w = fba_one(v.w + bv, r.w, code, alpha, scale);
+            reinterpret_cast<float4*>(y)[i] = o;
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float v = x[i];
+            if (b) v += b[(i / step_b) % size_b];
+            y[i] = fba_one(v, ref ? ref[i] : 0.f, code, alpha, scale);
+        }
+    }
+}
+
+extern "C" int l2i_fused_bias_act_f32(float* y, const float* x, const float* b, const float* ref, int64_t n, int64_t step_b,
+                                      int64_t size_b, int act, int grad, float alpha, float scale, void* stream) {
+    if (n == 0) return L2I_OK;
+    if (!y || !x || n < 0) return l2i_set_error(L2I_E_ARG, "fused_bias_act: null tensor");
+    if (b && (step_b <= 0 || size_b <= 0)) return l2i_set_error(L2I_E_ARG, "fused_bias_act: bias needs step_b,size_b > 0");
+    const int code = act * 10 + grad;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (n % 4 == 0) && (!b || step_b % 4 == 0) && (((uintptr_t)y | (uintptr_t)x | (uintptr_t)ref) % 16 == 0);
+    if (vec) hipLaunchKernelGGL(fba_kernel<true>, dim3(l2i_grid_for(n / 4, 256)), dim3(256), 0, st, y, x, b, ref, (long long)n, (long long)step_b, (long long)size_b, code, alpha, scale);
+    else hipLaunchKernelGGL(fba_kernel<false>, dim3(l2i_grid_for(n, 256)), dim3(256), 0, st, y, x, b, ref, (long long)n, (long long)step_b, (long long)size_b, code, alpha, scale);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// upfirdn2d: reference op/upfirdn2d_kernel.cu:52-137 on [major, H, W] maps, + optional fused epilogue
+//   out[o] = sum_k u[o*down + k - pad0] * K[kh-1-k],  u[i*up] = x[i]
+// ---------------------------------------------------------------------------------------------------------------
+struct UfdParams {
+    float* y; const float* x; const float* k;
+    long long major; int in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w;
+    int channels; const float* noise; float noise_w; const float* bias; const float* addend; int act; float slope, gain;
+};
+
+// one thread = one output pixel; a block covers a 16x64 output tile of one map so that the <=19x67 input footprint is
+// served from L1/L2 (the FIR taps sit in LDS).
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(const UfdParams p) {
+    __shared__ float sk[64];
+    const int ntap = p.kh * p.kw;
+    for (int t = threadIdx.x; t < ntap; t += 256) {
+        const int ky = t / p.kw, kx = t - ky * p.kw;
+        sk[t] = p.k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];      // flipped: true convolution (.cu:79)
+    }
+    __syncthreads();
+    const int tiles_x = (p.out_w + 63) >> 6, tiles_y = (p.out_h + 15) >> 4;
+    const long long ntiles = p.major * tiles_x * tiles_y;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = (int)(t % tiles_x);
+        const int ty = (int)((t / tiles_x) % tiles_y);
+        const long long mj = t / ((long long)tiles_x * tiles_y);
+        const int ox = tx * 64 + (threadIdx.x & 63);
+        const float* xin = p.x + mj * (long long)p.in_h * p.in_w;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int oy = ty * 16 + (threadIdx.x >> 6) * 4 + rr;
+            if (ox >= p.out_w || oy >= p.out_h) continue;
+            const int my = oy * p.down_y - p.pad_y0, mx = ox * p.down_x - p.pad_x0;
+            float v = 0.f;
+            for (int ky = 0; ky < p.kh; ++ky) {
+                const int uy = my + ky;
+                if (uy < 0) continue;
+                const int iy = uy / p.up_y;
+                if (iy * p.up_y != uy || iy >= p.in_h) continue;
+                for (int kx = 0; kx < p.kw; ++kx) {
+                    const int ux = mx + kx;
+                    if (ux < 0) continue;
+                    const int ix = ux / p.up_x;
+                    if (ix * p.up_x != ux || ix >= p.in_w) continue;
+                    v += xin[(long long)iy * p.in_w + ix] * sk[ky * p.kw + kx];
+                }
+            }
+            const long long oidx = (mj * p.out_h + oy) * p.out_w + ox;
+            if (p.noise) v += p.noise[((mj / p.channels) * p.out_h + oy) * p.out_w + ox] * p.noise_w;
+            if (p.bias) v += p.bias[mj % p.channels];
+            if (p.addend) v += p.addend[oidx];
+            if (p.act == L2I_ACT_LRELU) v = (v > 0.f ? v : v * p.slope) * p.gain;
+            else if (p.act == L2I_ACT_RELU) v = v > 0.f ? v : 0.f;
+            p.y[oidx] = v;
+        }
+    }
+}
+
+extern "C" int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw,
+                                 int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                 int channels, const float* noise, float noise_w, const float* bias, const float* addend,
+                                 int act, float act_slope, float act_gain, void* stream) {
+    if (!y || !x || !k) return l2i_set_error(L2I_E_ARG, "upfirdn2d: null tensor");
+    if (major <= 0 || in_h <= 0 || in_w <= 0) return l2i_set_error(L2I_E_ARG, "upfirdn2d: empty input");
+    if (kh <= 0 || kw <= 0 || kh * kw > 64) return l2i_set_error(L2I_E_ARG, "upfirdn2d: FIR must have 1..64 taps");
+    if (up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0) return l2i_set_error(L2I_E_ARG, "upfirdn2d: up/down must be positive");
+    UfdParams p;
+    p.y = y; p.x = x; p.k = k; p.major = major; p.in_h = in_h; p.in_w = in_w; p.kh = kh; p.kw = kw;
+    p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.pad_x0 = pad_x0; p.pad_y0 = pad_y0;
+    p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;       // op/upfirdn2d.py:102-103
+    p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+    if (p.out_h <= 0 || p.out_w <= 0) return l2i_set_error(L2I_E_ARG, "upfirdn2d: empty output");
+    p.channels = channels > 0 ? channels : 1;
+    p.noise = noise; p.noise_w = noise_w; p.bias = bias; p.addend = addend; p.act = act; p.slope = act_slope; p.gain = act_gain;
+    const long long ntiles = major * ((p.out_w + 63) / 64) * ((p.out_h + 15) / 16);
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3(l2i_grid_for(ntiles, 1, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ToRGB forward: rgb[b,o,p] = sum_c x[b,c,p]*wmod[b,o,c] + bias[o]         (networks.py:346-351)
+// one thread = 4 consecutive pixels; the 3xC modulated weights of the sample sit in LDS; x is read exactly once.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void torgb_fwd_kernel(float* __restrict__ rgb, const float* __restrict__ x, const float* __restrict__ wmod,
+                                                        const float* __restrict__ bias, int C, long long HW, int blocks_per_b) {
+    extern __shared__ float sw[];       // [3][C]
+    const int b = blockIdx.x / blocks_per_b;
+    const int blk = blockIdx.x - b * blocks_per_b;
+    for (int i = threadIdx.x; i < 3 * C; i += 256) sw[i] = wmod[(long long)b * 3 * C + i];
+    __syncthreads();
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
+    const long long hw4 = HW >> 2;
+    const float* xb = x + (long long)b * C * HW;
+    float* ob = rgb + (long long)b * 3 * HW;
+    for (long long i = (long long)blk * 256 + threadIdx.x; i < hw4; i += (long long)blocks_per_b * 256) {
+        float4 a0 = make_float4(b0, b0, b0, b0), a1 = make_float4(b1, b1, b1, b1), a2 = make_float4(b2, b2, b2, b2);
+        for (int c = 0; c < C; ++c) {
+            const float4 v = reinterpret_cast<const float4*>(xb + (long long)c * HW)[i];
+            const float w0 = sw[c], w1 = sw[C + c], w2 = sw[2 * C + c];
+            a0.x += v.x * w0; a0.y += v.y * w0; a0.z += v.z * w0; a0.w += v.w * w0;
+            a1.x += v.x * w1; a1.y += v.y * w1; a1.z += v.z * w1; a1.w += v.w * w1;
+            a2.x += v.x * w2; a2.y += v.y * w2; a2.z += v.z * w2; a2.w += v.w * w2;
+        }
+        reinterpret_cast<float4*>(ob)[i] = a0;
+        reinterpret_cast<float4*>(ob + HW)[i] = a1;
+        reinterpret_cast<float4*>(ob + 2 * HW)[i] = a2;
+    }
+}
+
+extern "C" int l2i_torgb_fwd_f32(float* rgb, const float* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream) {
+    if (!rgb || !x || !wmod) return l2i_set_error(L2I_E_ARG, "torgb_fwd: null tensor");
+    if (B <= 0 || C <= 0 || HW <= 0 || (HW % 4) != 0) return l2i_set_error(L2I_E_ARG, "torgb_fwd: HW must be a positive multiple of 4");
+    int bpb = (int)((HW / 4 + 255) / 256);
+    const int cap = (256 * 8 + B - 1) / B;
+    if (bpb > cap) bpb = cap;
+    if (bpb < 1) bpb = 1;
+    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(B * bpb), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream, rgb, x, wmod, bias, C, (long long)HW, bpb);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused StyledConv backward elementwise pass (see l2i.h).  grid = (B*C rows) x (chunks of the HW axis).
+// ---------------------------------------------------------------------------------------------------------------
+struct ActBwdParams {
+    float* dz; const float* gin; const float* gin_scale; const float* grgb; const float* wmod_rgb; const float* y;
+    const float* bias; const float* noise; float noise_w, slope, gain; float* red_dz_z; float* red_x_grgb;
+    int B, C; long long HW; int chunks;
+};
+
+__global__ __launch_bounds__(256) void sg2_act_bwd_kernel(const ActBwdParams p) {
+    const int row = blockIdx.x / p.chunks;             // b*C + c
+    const int chunk = blockIdx.x - row * p.chunks;
+    const int b = row / p.C, c = row - b * p.C;
+    const long long hw4 = p.HW >> 2;
+    const float gs = p.gin_scale ? p.gin_scale[row] : 1.f;
+    const float bia = p.bias ? p.bias[c] : 0.f;
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+    if (p.grgb) {
+        const float* wm = p.wmod_rgb + (long long)b * 3 * p.C;
+        w0 = wm[c]; w1 = wm[p.C + c]; w2 = wm[2 * p.C + c];
+    }
+    const float gpos = p.gain, gneg = p.gain * p.slope;
+    const float ipos = 1.f / gpos, ineg = 1.f / gneg;
+    const float4* y4 = reinterpret_cast<const float4*>(p.y + (long long)row * p.HW);
+    const float4* g4 = p.gin ? reinterpret_cast<const float4*>(p.gin + (long long)row * p.HW) : nullptr;
+    const float4* n4 = p.noise ? reinterpret_cast<const float4*>(p.noise + (long long)b * p.HW) : nullptr;
+    const float4* r0 = p.grgb ? reinterpret_cast<const float4*>(p.grgb + (long long)b * 3 * p.HW) : nullptr;
+    const float4* r1 = r0 ? r0 + hw4 : nullptr;
+    const float4* r2 = r0 ? r1 + hw4 : nullptr;
+    float4* d4 = reinterpret_cast<float4*>(p.dz + (long long)row * p.HW);
+    float s_dz = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (long long i = (long long)chunk * 256 + threadIdx.x; i < hw4; i += (long long)p.chunks * 256) {
+        const float4 yv = y4[i];
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g4) { const float4 t = g4[i]; g.x = t.x * gs; g.y = t.y * gs; g.z = t.z * gs; g.w = t.w * gs; }
+        if (r0) {
+            const float4 a = r0[i], bq = r1[i], cq = r2[i];
+            g.x += a.x * w0 + bq.x * w1 + cq.x * w2; g.y += a.y * w0 + bq.y * w1 + cq.y * w2;
+            g.z += a.z * w0 + bq.z * w1 + cq.z * w2; g.w += a.w * w0 + bq.w * w1 + cq.w * w2;
+            s0 += yv.x * a.x + yv.y * a.y + yv.z * a.z + yv.w * a.w;
+            s1 += yv.x * bq.x + yv.y * bq.y + yv.z * bq.z + yv.w * bq.w;
+            s2 += yv.x * cq.x + yv.y * cq.y + yv.z * cq.z + yv.w * cq.w;
+        }
+        float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n4) { nz = n4[i]; nz.x *= p.noise_w; nz.y *= p.noise_w; nz.z *= p.noise_w; nz.w *= p.noise_w; }
+        float4 d;
+        d.x = g.x * (yv.x > 0.f ? gpos : gneg); d.y = g.y * (yv.y > 0.f ? gpos : gneg);
+        d.z = g.z * (yv.z > 0.f ? gpos : gneg); d.w = g.w * (yv.w > 0.f ? gpos : gneg);
+        s_dz += d.x * (yv.x * (yv.x > 0.f ? ipos : ineg) - bia - nz.x) + d.y * (yv.y * (yv.y > 0.f ? ipos : ineg) - bia - nz.y) +
+                d.z * (yv.z * (yv.z > 0.f ? ipos : ineg) - bia - nz.z) + d.w * (yv.w * (yv.w > 0.f ? ipos : ineg) - bia - nz.w);
+        d4[i] = d;
+    }
+    __shared__ float red[4][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    s_dz = wave_sum(s_dz);
+    if (r0) { s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); }
+    if (lane == 0) { red[wv][0] = s_dz; red[wv][1] = s0; red[wv][2] = s1; red[wv][3] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (p.red_dz_z) atomicAdd(p.red_dz_z + row, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+        if (r0 && p.red_x_grgb) {
+            atomicAdd(p.red_x_grgb + (long long)row * 3 + 0, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+            atomicAdd(p.red_x_grgb + (long long)row * 3 + 1, red[0][2] + red[1][2] + red[2][2] + red[3][2]);
+            atomicAdd(p.red_x_grgb + (long long)row * 3 + 2, red[0][3] + red[1][3] + red[2][3] + red[3][3]);
+        }
+    }
+}
+
+extern "C" int l2i_sg2_act_bwd_f32(float* dz, const float* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb,
+                                   const float* y, const float* bias, const float* noise, float noise_w, float slope, float gain,
+                                   float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream) {
+    if (!dz || !y) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd: null tensor");
+    if (!gin && !grgb) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd: need gin and/or grgb");
+    if (grgb && !wmod_rgb) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd: grgb needs wmod_rgb");
+    if (B <= 0 || C <= 0 || HW <= 0 || (HW % 4) != 0) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd: HW must be a positive multiple of 4");
+    if (gain == 0.f || slope == 0.f) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd: gain and slope must be non-zero");
+    ActBwdParams p;
+    p.dz = dz; p.gin = gin; p.gin_scale = gin_scale; p.grgb = grgb; p.wmod_rgb = wmod_rgb; p.y = y; p.bias = bias; p.noise = noise;
+    p.noise_w = noise_w; p.slope = slope; p.gain = gain; p.red_dz_z = red_dz_z; p.red_x_grgb = red_x_grgb; p.B = B; p.C = C; p.HW = HW;
+    const long long rows = (long long)B * C;
+    long long chunks = (HW / 4 + 1023) / 1024;          // >= 4 float4 per thread
+    const long long cap = (256 * 16 + rows - 1) / rows;
+    if (chunks > cap) chunks = cap;
+    if (chunks < 1) chunks = 1;
+    p.chunks = (int)chunks;
+    hipLaunchKernelGGL(sg2_act_bwd_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, (hipStream_t)stream, p);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// row dot / sum reduction
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dot_reduce_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ bq,
+                                                         long long cols, int chunks) {
+    const long long row = blockIdx.x / chunks;
+    const int chunk = blockIdx.x - (int)(row * chunks);
+    const float* ar = a + row * cols;
+    const float* br = bq ? bq + row * cols : nullptr;
+    float s = 0.f;
+    if ((cols & 3) == 0 && ((uintptr_t)ar % 16 == 0) && (!br || (uintptr_t)br % 16 == 0)) {
+        const long long c4 = cols >> 2;
+        for (long long i = (long long)chunk * 256 + threadIdx.x; i < c4; i += (long long)chunks * 256) {
+            const float4 v = reinterpret_cast<const float4*>(ar)[i];
+            if (br) { const float4 w = reinterpret_cast<const float4*>(br)[i]; s += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w; }
+            else s += v.x + v.y + v.z + v.w;
+        }
+    } else {
+        for (long long i = (long long)chunk * 256 + threadIdx.x; i < cols; i += (long long)chunks * 256)
+            s += br ? ar[i] * br[i] : ar[i];
+    }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + row, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int l2i_dot_reduce_f32(float* out, const float* a, const float* b, int64_t rows, int64_t cols, void* stream) {
+    if (!out || !a) return l2i_set_error(L2I_E_ARG, "dot_reduce: null tensor");
+    if (rows <= 0 || cols <= 0) return l2i_set_error(L2I_E_ARG, "dot_reduce: empty input");
+    long long chunks = (cols / 4 + 1023) / 1024;
+    const long long cap = (256 * 16 + rows - 1) / rows;
+    if (chunks > cap) chunks = cap;
+    if (chunks < 1) chunks = 1;
+    if (rows * chunks > 0x7fffffffLL) return l2i_set_error(L2I_E_ARG, "dot_reduce: too many rows");
+    hipLaunchKernelGGL(dot_reduce_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, (hipStream_t)stream, out, a, b, (long long)cols, (int)chunks);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MaxPool2d forward / backward on [planes, H, W]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ y, uint8_t* __restrict__ idx, const float* __restrict__ x,
+                                                          long long planes, int H, int W, int k, int s, int pad, int OH, int OW) {
+    const long long total = planes * OH * OW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % OW);
+        const int oy = (int)((i / OW) % OH);
+        const long long pl = i / ((long long)OW * OH);
+        const float* xp = x + pl * H * W;
+        float best = -INFINITY;
+        int bi = 0;
+        bool found = false;
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * s - pad + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * s - pad + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float v = xp[(long long)iy * W + ix];
+                if (!found || v > best || (v != v)) { best = v; bi = ky * k + kx; found = true; }   // first max; NaN propagates like ATen
+            }
+        }
+        y[i] = best;
+        idx[i] = (uint8_t)bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(float* __restrict__ gx, const float* __restrict__ gy, const uint8_t* __restrict__ idx,
+                                                          long long planes, int H, int W, int k, int s, int pad, int OH, int OW) {
+    const long long total = planes * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ix = (int)(i % W);
+        const int iy = (int)((i / W) % H);
+        const long long pl = i / ((long long)W * H);
+        float g = 0.f;
+        // windows that contain (iy, ix): oy in [ceil((iy+pad-k+1)/s), floor((iy+pad)/s)]
+        int oy_lo = iy + pad - k + 1; oy_lo = oy_lo <= 0 ? 0 : (oy_lo + s - 1) / s;
+        int oy_hi = (iy + pad) / s; if (oy_hi > OH - 1) oy_hi = OH - 1;
+        int ox_lo = ix + pad - k + 1; ox_lo = ox_lo <= 0 ? 0 : (ox_lo + s - 1) / s;
+        int ox_hi = (ix + pad) / s; if (ox_hi > OW - 1) ox_hi = OW - 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const long long o = (pl * OH + oy) * OW + ox;
+                const int ky = iy - (oy * s - pad), kx = ix - (ox * s - pad);
+                if ((int)idx[o] == ky * k + kx) g += gy[o];
+            }
+        gx[i] = g;
+    }
+}
+
+extern "C" int l2i_maxpool2d_fwd_f32(float* y, uint8_t* idx, const float* x, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, void* stream) {
+    if (!y || !idx || !x) return l2i_set_error(L2I_E_ARG, "maxpool_fwd: null tensor");
+    if (planes <= 0 || H <= 0 || W <= 0 || k <= 0 || k > 15 || s <= 0 || OH <= 0 || OW <= 0) return l2i_set_error(L2I_E_ARG, "maxpool_fwd: bad geometry");
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(l2i_grid_for(planes * OH * OW, 256)), dim3(256), 0, (hipStream_t)stream, y, idx, x, (long long)planes, H, W, k, s, pad, OH, OW);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+extern "C" int l2i_maxpool2d_bwd_f32(float* gx, const float* gy, const uint8_t* idx, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, void* stream) {
+    if (!gx || !gy || !idx) return l2i_set_error(L2I_E_ARG, "maxpool_bwd: null tensor");
+    if (planes <= 0 || H <= 0 || W <= 0 || k <= 0 || k > 15 || s <= 0 || OH <= 0 || OW <= 0) return l2i_set_error(L2I_E_ARG, "maxpool_bwd: bad geometry");
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(l2i_grid_for(planes * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gx, gy, idx, (long long)planes, H, W, k, s, pad, OH, OW);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ContentLoss pieces and small utilities
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqdiff_kernel(float* __restrict__ sum_out, float* __restrict__ grad, const float* __restrict__ a,
+                                                     const float* __restrict__ b, long long n, float coef,
+                                                     const float* __restrict__ coef_dev) {
+    float s = 0.f;
+    if (coef_dev) coef *= coef_dev[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = b[i] - a[i];
+        s += d * d;
+        if (grad) grad[i] = coef * d;
+    }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && sum_out) atomicAdd(sum_out, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int l2i_sqdiff_f32(float* sum_out, float* grad, const float* a, const float* b, int64_t n, float coef,
+                              const float* coef_dev, void* stream) {
+    if (!a || !b || n <= 0) return l2i_set_error(L2I_E_ARG, "sqdiff: null/empty tensor");
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(l2i_grid_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, sum_out, grad, a, b, (long long)n, coef, coef_dev);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, const float* __restrict__ a, const float* __restrict__ b,
+                                                    float alpha, float beta, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+extern "C" int l2i_axpby_f32(float* y, const float* a, const float* b, float alpha, float beta, int64_t n, void* stream) {
+    if (!y || !a || n <= 0) return l2i_set_error(L2I_E_ARG, "axpby: null/empty tensor");
+    hipLaunchKernelGGL(axpby_kernel, dim3(l2i_grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, y, a, b, alpha, beta, (long long)n);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ y, const float* __restrict__ g, const float* __restrict__ ref, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = ref[i] > 0.f ? g[i] : 0.f;
+}
+
+extern "C" int l2i_relu_mask_f32(float* y, const float* g, const float* ref, int64_t n, void* stream) {
+    if (!y || !g || !ref || n <= 0) return l2i_set_error(L2I_E_ARG, "relu_mask: null/empty tensor");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(l2i_grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, y, g, ref, (long long)n);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}

@@ -1,0 +1,133 @@
+"""StyleGAN2 discriminator (frozen, random-init in the reference: transform_base.py:540-548 never loads it) on the l2i
+HIP kernels.  Reference: networks.py:517-645 (ConvLayer, ResBlock, Discriminator).
+
+Body (from_rgb conv + residual blocks) = one autograd function with hand-scheduled input-gradient; the 4x4 tail
+(minibatch-stddev, final conv, two linears) runs on small torch ops + one FrozenConv2d call.
+EqualConv2d's 1/sqrt(fan_in) is folded into the packed weights; FusedLeakyReLU bias+activation, the residual add and
+the 1/sqrt(2) live in the conv epilogue; leaky-ReLU' is a prologue mask of the gradient convs.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import conv as C
+from . import kernels as K
+
+SQRT2 = math.sqrt(2.0)
+LRELU_MASK = (SQRT2, 0.2 * SQRT2)          # d/dx [lrelu(x, 0.2) * sqrt2] keyed on the sign of the saved output
+
+
+def _eq_conv(P, name, stride, padding, device):
+    w = torch.as_tensor(np.asarray(P[name]), dtype=torch.float32)
+    w = w * (1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3]))
+    return C.FrozenConv2d(w, stride=stride, padding=padding, device=device)
+
+
+def _vec(P, name, device):
+    return torch.as_tensor(np.asarray(P[name]), dtype=torch.float32).contiguous().to(device)
+
+
+class Discriminator:
+    def __init__(self, state, size, device='cuda'):
+        P = state
+        self.size, self.device = size, device
+        log_size = int(math.log2(size))
+        self.conv0 = _eq_conv(P, 'convs.0.0.weight', 1, 0, device)
+        self.bias0 = _vec(P, 'convs.0.1.bias', device)
+        self.blocks = []
+        for n in range(1, log_size - 1):
+            p = 'convs.%d' % n
+            self.blocks.append(dict(
+                c1=_eq_conv(P, p + '.conv1.0.weight', 1, 1, device), b1=_vec(P, p + '.conv1.1.bias', device),
+                c2=_eq_conv(P, p + '.conv2.1.weight', 2, 0, device), b2=_vec(P, p + '.conv2.2.bias', device),
+                sk=_eq_conv(P, p + '.skip.1.weight', 2, 0, device),
+                k=_vec(P, p + '.conv2.0.kernel', device)))
+        for blk in self.blocks:
+            blk['kf'] = torch.flip(blk['k'], [0, 1]).contiguous()
+        self.final_conv = _eq_conv(P, 'final_conv.0.weight', 1, 1, device)
+        self.final_bias = _vec(P, 'final_conv.1.bias', device)
+        w = _vec(P, 'final_linear.0.weight', device)
+        self.lin0_wt = (w * (1.0 / math.sqrt(w.shape[1]))).t().contiguous()
+        self.lin0_b = _vec(P, 'final_linear.0.bias', device)
+        w = _vec(P, 'final_linear.1.weight', device)
+        self.lin1_wt = (w * (1.0 / math.sqrt(w.shape[1]))).t().contiguous()
+        self.lin1_b = _vec(P, 'final_linear.1.bias', device)
+
+    def __call__(self, img):
+        """[B,3,size,size] -> [B,1] logits (networks.py:627-645)."""
+        from .op import fused_leaky_relu
+        out = _DBodyFn.apply(img, self)                                        # [B,512,4,4]
+        batch, channel, height, width = out.shape
+        group = min(batch, 4)
+        if batch % group != 0:
+            raise ValueError('minibatch-stddev needs a batch divisible by %d (networks.py:631-634)' % group)
+        sd = out.view(group, -1, 1, channel, height, width)
+        sd = torch.sqrt(sd.var(0, unbiased=False) + 1e-8)
+        sd = sd.mean([2, 3, 4], keepdim=True).squeeze(2)
+        sd = sd.repeat(group, 1, height, width)
+        out = torch.cat([out, sd], 1)
+        out = _ConvLReLUFn.apply(out, self.final_conv, self.final_bias)
+        out = out.reshape(batch, -1)
+        out = fused_leaky_relu(torch.mm(out, self.lin0_wt), self.lin0_b)
+        return torch.addmm(self.lin1_b, out, self.lin1_wt)
+
+
+class _ConvLReLUFn(torch.autograd.Function):
+    """conv + FusedLeakyReLU with frozen weights (ConvLayer with activate=True, networks.py:545-558)."""
+
+    @staticmethod
+    def forward(ctx, x, conv, bias):
+        y = conv.forward(x.detach().contiguous(), bias=bias, act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
+        ctx.conv, ctx.y, ctx.in_hw = conv, y, (x.shape[2], x.shape[3])
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = ctx.conv.dgrad(g.contiguous(), ctx.in_hw, in_mask=ctx.y, mask=LRELU_MASK)
+        return gx, None, None
+
+
+class _DBodyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, net):
+        keep = img.requires_grad
+        x = img.detach().contiguous()
+        y0 = net.conv0.forward(x, bias=net.bias0, act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
+        saved = [y0]
+        cur = y0
+        for blk in net.blocks:
+            y1 = blk['c1'].forward(cur, bias=blk['b1'], act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
+            t = K.upfirdn2d(y1, blk['k'], pad=(2, 2, 2, 2))                    # Blur before the stride-2 3x3
+            y2 = blk['c2'].forward(t, bias=blk['b2'], act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
+            del t
+            ts = K.upfirdn2d(cur, blk['k'], pad=(1, 1, 1, 1))                  # Blur before the stride-2 1x1 skip
+            out = blk['sk'].forward(ts, residual=y2, out_gain=1.0 / SQRT2)     # (conv2 + skip) / sqrt2
+            del ts
+            if keep:
+                saved.append((y1, y2, (cur.shape[2], cur.shape[3])))
+            cur = out
+        ctx.net, ctx.saved, ctx.in_hw = net, saved if keep else None, (x.shape[2], x.shape[3])
+        return cur
+
+    @staticmethod
+    def backward(ctx, g):
+        net, saved = ctx.net, ctx.saved
+        if saved is None:
+            raise RuntimeError('discriminator was run without a differentiable input')
+        g = g.contiguous()
+        for blk, (y1, y2, in_hw) in zip(reversed(net.blocks), reversed(saved[1:])):
+            h = in_hw[0]
+            # conv2 path: lrelu' * 1/sqrt2 folded into the prologue mask
+            g_t = blk['c2'].dgrad(g, (h + 1, h + 1), in_mask=y2, mask=(1.0, 0.2))
+            g_y1 = K.upfirdn2d(g_t, blk['kf'], pad=(1, 1, 1, 1))
+            del g_t
+            g_a = blk['c1'].dgrad(g_y1, in_hw, in_mask=y1, mask=LRELU_MASK)
+            del g_y1
+            # skip path
+            g_ts = blk['sk'].dgrad(g, (h - 1, h - 1), out_gain=1.0 / SQRT2)
+            g = K.upfirdn2d(g_ts, blk['kf'], pad=(2, 2, 2, 2), addend=g_a)
+            del g_ts, g_a
+        g_img = net.conv0.dgrad(g, ctx.in_hw, in_mask=saved[0], mask=LRELU_MASK)
+        ctx.saved = None
+        return g_img, None

@@ -1,0 +1,83 @@
+"""Data parallelism for the walk-training step: one process per GPU, ``torch.distributed`` (backend ``nccl`` = RCCL over
+xGMI on ROCm; ``gloo`` for the CPU tests).  The path shards by sample: every rank holds a full replica of the frozen
+networks (0.33 GB fp32) and a slice of each batch; the only exchange per step is ONE all-reduce of the walk gradient
+([n_attr, n_latent, 512] fp32 = 28..184 KB -> latency-bound, a single small-message collective, nothing to bucket or
+overlap: it is the last op before Adam).  The reference has no distributed code at all (SURVEY §2 last rows)."""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def is_initialized():
+    return td.is_available() and td.is_initialized()
+
+
+def rank():
+    return td.get_rank() if is_initialized() else 0
+
+
+def world_size():
+    return td.get_world_size() if is_initialized() else 1
+
+
+def init_from_env(backend=None):
+    """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rk = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', str(rk)))
+    if world > 1 and not is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        td.init_process_group(backend=backend, rank=rk, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
+    return rk, world, local
+
+
+def shard(n, rk=None, world=None):
+    """Contiguous slice of ``range(n)`` owned by this rank (equal shards: mean of shard means == global mean)."""
+    rk = rank() if rk is None else rk
+    world = world_size() if world is None else world
+    if n % world != 0:
+        raise ValueError('global batch %d is not divisible by world size %d' % (n, world))
+    per = n // world
+    return slice(rk * per, (rk + 1) * per)
+
+
+def average_gradients(params):
+    """All-reduce (mean) the gradients of the trainable parameters — for this path: the walk tensor only."""
+    if world_size() == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    if len(grads) == 1:
+        flat = grads[0]
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        flat.div_(world_size())
+    else:
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        flat.div_(world_size())
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+
+def barrier():
+    if is_initialized():
+        td.barrier()
+
+
+def max_over_ranks(value, device=None):
+    if world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else ('cuda' if td.get_backend() == 'nccl' else 'cpu'))
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,422 @@
+"""Host-side mirror of the reference Graph API for the StyleGAN2 walk-training path.
+
+Same class / method names, argument meaning and error behaviour as the reference so that ``train.py`` reads the same:
+
+    graphs/__init__.py:3-22                      find_model_using_name
+    graphs/transform_graph_scene.py:5-125        get_transform_graphs -> [SceneGraph, faceGraph]
+    graphs/stylegan_v2_real/transform_base.py    TransformGraph (:246-549), PixelTransform (:901-903),
+                                                 WalkLinearMultiW (:140-165), ContentLoss/Normalization (:44-63)
+    utils/transforms.py:634-735                  FaceTransform / SceneTransform alpha samplers
+
+Underneath, every network is the frozen HIP implementation of this package (generator.py, regressor.py, perceptual.py,
+discriminator.py); nothing here runs on the CPU and nothing imports the oracle.  Differences from the reference,
+all output-equivalent: frozen networks carry no autograd state (the reference keeps requires_grad=True everywhere and
+back-propagates weight gradients it never uses); the first generator/regressor pass therefore builds
+no graph (A.4); the VGG prefix is evaluated once per image instead of once per tap.
+"""
+import math
+import os
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import constants, dist, synth
+from .discriminator import Discriminator
+from .generator import Generator
+from .perceptual import VGG19Prefix
+from .regressor import ResNet50
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# walk modules
+# ----------------------------------------------------------------------------------------------------------------
+class WalkLinearMultiW(nn.Module):
+    """Input-independent linear walk in W+ (transform_base.py:140-165): w_i + alpha @ W[:, i, :].
+    ``self.w`` [n_attr, 2*(step+1), dim_z] ~ N(0, 0.02) from the global numpy RNG, exactly like the reference."""
+
+    def __init__(self, dim_z, step, Nsliders, attrList):
+        super().__init__()
+        self.dim_z = dim_z
+        self.step = step
+        self.w = nn.Parameter(torch.Tensor(np.random.normal(0.0, 0.02, [len(attrList), (self.step + 1) * 2, self.dim_z])))
+
+    def forward(self, input, alpha, layers=None, name=None, index_=None):
+        al = alpha.to(self.w.device)
+        dirs = torch.matmul(al, self.w.permute(1, 0, 2))                 # [n_latent, B, dim_z] in one batched GEMM
+        w_transformed = []
+        for i in range(len(input)):
+            if layers is None or i in layers:
+                w_transformed.append(input[i] + dirs[i])
+            else:
+                w_transformed.append(input[i])
+        return w_transformed
+
+
+# pickles written by save_multi_models must resolve in the reference's vis_w.py (transform_base.py:499-509)
+WalkLinearMultiW.__module__ = 'graphs.stylegan_v2_real.transform_base'
+
+
+class ContentLoss(nn.Module):
+    """transform_base.py:57-63."""
+
+    def forward(self, org, shifted):
+        self.loss = torch.nn.functional.mse_loss(org.detach(), shifted)
+        return self.loss
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# network holders
+# ----------------------------------------------------------------------------------------------------------------
+class StyleGAN:
+    """Attribute contract of stylegan2.StyleGAN (stylegan2.py:19-31): ``netG`` / ``netD``.  The reference also builds
+    ``g_running`` and two Adam optimisers that the walk path never touches (updateGAN raises, train.py:40-41)."""
+
+    def __init__(self, netG, netD):
+        self.netG, self.netD = netG, netD
+
+
+def _to_numpy_state(sd):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
+
+
+def load_networks(resolution, device, need_vgg=True, need_d=True):
+    """Frozen nets from the checkpoint paths of ``constants`` (reference transform_base.py:522-549) or — when a path
+    does not exist — deterministic synthetic weights of the same architecture (latent2im_amd.synth)."""
+    src = {}
+    if constants.g_path and os.path.isfile(constants.g_path):
+        g_state = _to_numpy_state(torch.load(constants.g_path, map_location='cpu')['g_ema'])
+        src['G'] = constants.g_path
+    else:
+        g_state = synth.generator_state(resolution, seed=constants.SYNTH_SEED_G)
+        src['G'] = 'synthetic(seed=%d)' % constants.SYNTH_SEED_G
+    if constants.reg_path and os.path.isfile(constants.reg_path):
+        r_state = _to_numpy_state(torch.load(constants.reg_path, map_location='cpu')['model'])
+        src['R'] = constants.reg_path
+    else:
+        r_state = synth.resnet50_state(seed=constants.SYNTH_SEED_R)
+        src['R'] = 'synthetic(seed=%d)' % constants.SYNTH_SEED_R
+    netG = Generator(g_state, resolution, device=device)
+    reg = ResNet50(r_state, device=device)
+    vgg = netD = None
+    if need_vgg:
+        if constants.vgg_path and os.path.isfile(constants.vgg_path):
+            v_state = _to_numpy_state(torch.load(constants.vgg_path, map_location='cpu'))
+            v_state = {k.replace('features.', ''): v for k, v in v_state.items()}
+            src['V'] = constants.vgg_path
+        else:
+            v_state = synth.vgg19_prefix_state(seed=constants.SYNTH_SEED_V)
+            src['V'] = 'synthetic(seed=%d)' % constants.SYNTH_SEED_V
+        vgg = VGG19Prefix(v_state, device=device)
+    if need_d:
+        # the reference's netD is ALWAYS freshly initialised (never loaded): seeded here for reproducibility
+        netD = Discriminator(synth.discriminator_state(resolution, seed=constants.SYNTH_SEED_D), resolution, device=device)
+        src['D'] = 'random-init(seed=%d)' % constants.SYNTH_SEED_D
+    return netG, netD, reg, vgg, src
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# TransformGraph
+# ----------------------------------------------------------------------------------------------------------------
+class TransformGraph:
+    def __init__(self, lr, walk_type, nsliders, loss_type, eps, N_f, trainEmbed, attrList, attrTable, layers, stylegan_opts,
+                 nets=None):
+        assert (loss_type in ['l2', 'lpips']), 'unimplemented loss'
+        if not torch.cuda.is_available():
+            raise RuntimeError('latent2im_amd runs on an MI355X (ROCm) device only: no GPU is visible and there is no CPU path')
+        self.lr = lr
+        self.useGPU = constants.useGPU
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.img_size = constants.resolution
+        if nets is None:
+            nets = load_networks(self.img_size, self.device)
+        netG, netD, self.regressor, self.vgg19, self.weight_sources = nets
+        self.module = StyleGAN(netG, netD)
+        self.reg_optmizer = None
+
+        self.attrTable = attrTable
+        self.attrList = attrList
+        self.attrIdx = self.get_attr_idx()
+
+        self.dim_z = constants.DIM_Z
+        self.Nsliders = nsliders
+        self.num_channels = constants.NUM_CHANNELS
+        self.BATCH_SIZE = constants.BATCH_SIZE
+        self.LAMBDA = 0.05
+        self.BCE_loss = nn.BCELoss()
+        self.BCE_loss_logits = nn.BCEWithLogitsLoss()
+        self.MSE_loss = nn.MSELoss()
+        self.ContentLoss = ContentLoss()
+        self.trainEmbed = trainEmbed
+
+        # the reference hard-codes step = 6 (256^2, transform_base.py:285); generalised: n_latent = 2*(step+1)
+        self.step = int(math.log2(self.img_size)) - 2
+        self.alpha = 1
+        self.stylegan_opts = stylegan_opts
+        self.layers = layers
+        self.is_mlp = False
+
+        if walk_type == 'linear':
+            if self.trainEmbed:
+                raise NotImplementedError('WalkEmbed is unused in the paper (transform_base.py:298-303) and out of scope')
+            if stylegan_opts.latent == 'z':
+                raise NotImplementedError('Not implemented setting of linear transformation for z')
+            elif stylegan_opts.latent == 'w':
+                self.walk = WalkLinearMultiW(self.dim_z, self.step, nsliders, self.attrList).to(self.device)
+            else:
+                raise NotImplementedError('Not implemented latent walk type:' '{}'.format(stylegan_opts.latent))
+        elif 'NN' in walk_type:
+            raise NotImplementedError('WalkNonLinearW (transform_base.py:207-243) is out of scope of this build')
+        else:
+            raise NotImplementedError('unknown walk_type %r' % (walk_type,))
+
+        self.optimizers = torch.optim.Adam(self.walk.parameters(), lr=self.lr, betas=(0.5, 0.99))
+        self.y = None
+        self.z = None
+        self.truncation = None
+        self.walk_type = walk_type
+        self.last_terms = None
+
+    # -- reference helpers ---------------------------------------------------------------------------------------
+    def get_attr_idx(self):
+        return [self.attrTable[i] for i in self.attrList]
+
+    def get_logits(self, inputs_dict, reshape=True):
+        if self.stylegan_opts.latent == 'z':
+            raise NameError("latent: the reference's Generator.forward fails for input_is_latent=False (networks.py:471-494)")
+        w = inputs_dict['w']
+        if isinstance(w, (list, tuple)):
+            w = torch.stack(list(w)).transpose(0, 1)
+        else:
+            w = w.transpose(0, 1)
+        outputs_orig, _ = self.module.netG(w.contiguous(), input_is_latent=True)
+        return outputs_orig
+
+    def get_w(self, z, is_single=False):
+        w = self.module.netG.style(z)
+        if is_single:
+            return [w]
+        return [w] * (self.step + 1) * 2
+
+    def get_w_new_tensor(self, multi_ws, alpha, layers=None, name=None, trainEmbed=False, index_=None):
+        if layers is not None:
+            layers = [int(l) for l in layers]                 # the reference passes strings through
+        return self.walk(multi_ws, alpha=alpha, layers=layers)
+
+    def get_reg_preds(self, logit):
+        preds = self.regressor(logit)[:, self.attrIdx]        # integer column select: bit-exact
+        if len(preds.size()) == 1:
+            preds = preds.unsqueeze(1)
+        return preds
+
+    def get_alphas(self, alpha_org, alpha_target):
+        """train.py flow (transform_base.py:405-408): epsilon = target - org."""
+        return alpha_target - alpha_org
+
+    def get_alphas_clamped(self, alpha_org, alpha_delta):
+        """train_multi_attr.py:113 flow (graphs/pggan/transform_base.py:358-364): (clamped target, new delta)."""
+        alpha_target = torch.clamp(alpha_org + alpha_delta, min=0, max=1)
+        return alpha_target, alpha_target - alpha_org
+
+    def get_bce_loss(self, pred, y, eps=1e-12):
+        return -(y * pred.clamp(min=eps).log() + (1 - y) * (1 - pred).clamp(min=eps).log()).mean()
+
+    def get_reg_loss(self, feed_dict):
+        logit = feed_dict['logit']
+        alpha_gt = feed_dict['alpha'].to(torch.double)
+        preds = self.regressor(logit)[:, self.attrIdx]
+        return self.get_bce_loss(preds, alpha_gt).mean()
+
+    def get_content_loss(self, org_img, shifted_img):
+        """List of four scalars (transform_base.py:426-454)."""
+        losses = self.vgg19.content_losses(org_img, shifted_img)
+        return [losses[i] for i in range(4)]
+
+    # -- loss / optimiser ----------------------------------------------------------------------------------------
+    def get_w_loss(self, feed_dict, no_content_loss=False, no_gan_loss=False):
+        """Total walk loss of optimizeParametersAll (transform_base.py:459-486) without the optimiser step."""
+        logit = feed_dict['logit']
+        gan_loss = content_losses = None
+        if not no_gan_loss:
+            D_fake_result = self.module.netD(logit)
+            gan_loss = self.BCE_loss_logits(D_fake_result, torch.ones_like(D_fake_result))
+        if not no_content_loss:
+            content_loss_list = self.get_content_loss(feed_dict['org'], feed_dict['logit'])
+            content_losses = sum(content_loss_list) / len(content_loss_list)
+        reg_loss = self.get_reg_loss(feed_dict)
+        loss = reg_loss if (no_content_loss and no_gan_loss) else 10 * reg_loss
+        if not no_content_loss:
+            loss = loss + 0.05 * content_losses
+        if not no_gan_loss:
+            loss = loss + 0.05 * gan_loss
+        self.last_terms = dict(reg=reg_loss.detach(), cont=None if content_losses is None else content_losses.detach(),
+                               gan=None if gan_loss is None else gan_loss.detach())
+        return loss
+
+    def optimizeParametersAll(self, feed_dict, trainEmbed, updateGAN, no_content_loss=False, no_gan_loss=False):
+        self.optimizers.zero_grad()
+        loss = self.get_w_loss(feed_dict, no_content_loss, no_gan_loss)
+        loss.backward()
+        dist.average_gradients(self.walk.parameters())        # data parallel: one RCCL all-reduce of <= 184 KB
+        self.optimizers.step()
+        return loss
+
+    optimize_parameters = optimizeParametersAll              # BASELINE.json spelling
+
+    # -- checkpoints ---------------------------------------------------------------------------------------------
+    def save_multi_models(self, save_path_w, save_path_gan, trainEmbed=False, updateGAN=False, single_transform_name=None):
+        print('Save W and GAN in %s and %s' % (save_path_w, save_path_gan))
+        if updateGAN:
+            raise NotImplementedError('jointly training the GAN is not implemented in the reference either (train.py:40-41)')
+        if dist.rank() == 0:
+            torch.save(self.walk, save_path_w + '_walk_module.ckpt')
+
+    def load_multi_models(self, save_path_w, save_path_gan, trainEmbed=False, updateGAN=False, single_transform_name=None):
+        print('Load w in %s' % save_path_w)
+        self.walk = torch.load(save_path_w, map_location=self.device, weights_only=False)
+
+    def load_multi_models_from_single(self, save_path_ws, save_path_gan, trainEmbed=False, updateGAN=False,
+                                      single_transform_name=None, index=None):
+        for i in range(len(save_path_ws)):
+            walk_ckpt = torch.load(save_path_ws[i], map_location=self.device, weights_only=False)
+            with torch.no_grad():
+                self.walk.w[index[i]] = walk_ckpt.w[0]
+
+    # -- inference ("next" row f-1: vis_w.py) --------------------------------------------------------------------
+    def clip_ims(self, ims):
+        return np.uint8(np.clip(((ims + 1) / 2.0) * 255, 0, 255))
+
+    def apply_alpha(self, graph_inputs, alpha_to_graph, layers=None, name=None, trainEmbed=False, index_=None, given_w=None):
+        """transform_base.py:554-603 (w branch): returns (edited image, alpha_org, original image)."""
+        with torch.no_grad():
+            zs_batch = graph_inputs['z']
+            if not torch.is_tensor(zs_batch):
+                zs_batch = torch.Tensor(zs_batch).to(self.device)
+            latent_w = given_w if given_w is not None else self.get_w(zs_batch)
+            out_zs = self.get_logits({'w': latent_w})
+            alpha_org = self.get_reg_preds(out_zs)
+            alpha_delta = self.get_alphas(alpha_org, torch.Tensor(np.asarray(alpha_to_graph)).to(self.device))
+            if index_ is not None:
+                if len(self.attrIdx) == len(self.attrTable):
+                    alpha_delta[:, index_] = torch.Tensor(np.asarray(alpha_to_graph)).to(self.device) - alpha_org[:, index_]
+                else:
+                    i = self.attrIdx.index(index_)
+                    alpha_delta[:, i] = torch.Tensor(np.asarray(alpha_to_graph)[:, 0]).to(self.device) - alpha_org[:, i]
+            latent_w_new = self.get_w_new_tensor(latent_w, alpha_delta, layers=layers, name=name, trainEmbed=trainEmbed,
+                                                 index_=index_)
+            best_im_out = self.get_logits({'w': latent_w_new})
+        return best_im_out, alpha_org, out_zs
+
+    def vis_image_batch(self, graph_inputs, filename, batch_start, wgt=False, wmask=False, num_panels=7):
+        raise NotImplementedError('Subclass should implement vis_image_batch')
+
+
+class PixelTransform(TransformGraph):
+    def __init__(self, *args, **kwargs):
+        TransformGraph.__init__(self, *args, **kwargs)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# alpha samplers (utils/transforms.py:634-735 and the overrides in stylegan_v2_real/transform_op.py:65-77)
+# ----------------------------------------------------------------------------------------------------------------
+class FaceTransform:
+    def __init__(self, atrr_name='Black_Hair'):
+        self.atrr_name = atrr_name
+        self.alpha_original = 1
+        self.num_panel = 6
+        self.embed_alpha_max = 1
+        self.embedding_alpha = np.linspace(0.0, 1.0, self.num_panel)
+        self.alpha_max = 1
+
+    def get_train_alpha(self, zs_batch, N_attr=40, trainEmbed=False):
+        """One target alpha ~ U(0,1)^N_attr per step, shared by the whole batch (global numpy RNG)."""
+        batch_size = zs_batch.shape[0]
+        if trainEmbed:
+            index_ = np.random.choice(self.num_panel)
+            alpha_val = self.embedding_alpha[index_]
+            return np.ones((batch_size, self.Nsliders)) * (alpha_val / self.embed_alpha_max), alpha_val, index_
+        alpha_val = np.random.uniform(0, 1, N_attr)
+        return np.ones((batch_size, self.Nsliders)) * alpha_val, alpha_val, None
+
+    def scale_test_alpha_for_graph(self, alpha, zs_batch, **kwargs):
+        return alpha * np.ones((zs_batch.shape[0], self.Nsliders))
+
+    def test_alphas(self):
+        return np.linspace(0, 1, 9)
+
+    def vis_alphas(self, num_panels):
+        return np.linspace(0, 1, num_panels)
+
+
+class SceneTransform:
+    def __init__(self):
+        self.alpha_max = 1
+        self.num_panel = 6
+        self.embed_alpha_max = 1
+        self.embedding_alpha = np.linspace(0.0, 1.0, self.num_panel)
+
+    def get_train_alpha(self, zs_batch, N_attr=40, trainEmbed=False):
+        """One delta ~ U(-1,1)^N_attr per step, shared by the whole batch."""
+        batch_size = zs_batch.shape[0]
+        if trainEmbed:
+            index_ = np.random.choice(self.num_panel)
+            alpha_val = self.embedding_alpha[index_]
+            return np.ones((batch_size, self.Nsliders)) * alpha_val, alpha_val, index_
+        alpha_val = np.random.uniform(-1, 1, N_attr)
+        return np.ones((batch_size, N_attr)) * alpha_val, alpha_val, None
+
+    def scale_test_alpha_for_graph(self, alpha, zs_batch, **kwargs):
+        return alpha * np.ones((zs_batch.shape[0], self.Nsliders))
+
+    def test_alphas(self):
+        return np.linspace(0, 1, 10)
+
+    def vis_alphas(self, num_panels):
+        return np.linspace(0, 1, num_panels)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# plugin lookup
+# ----------------------------------------------------------------------------------------------------------------
+def _make_graph(name, op_cls):
+    def __init__(self, lr=0.001, walk_type='NNz', loss='l2', eps=1.41, N_f=4, **kwargs):
+        nsliders = 1
+        self.walk_type = walk_type
+        self.num_channels = constants.NUM_CHANNELS
+        self.Nsliders = nsliders
+        self.img_size = constants.resolution
+        PixelTransform.__init__(self, lr, walk_type, nsliders, loss, eps, N_f, **kwargs)
+        op_cls.__init__(self)
+
+    def vis_image_batch(self, graph_inputs, filename, batch_start, wgt=False, wmask=False, num_panels=7, max_alpha=None,
+                        min_alpha=None, N_attr=40):
+        zs_batch = graph_inputs['z']
+        if max_alpha is not None and min_alpha is not None:
+            alphas = np.linspace(min_alpha, max_alpha, num_panels)
+        else:
+            alphas = np.linspace(0, 1, num_panels)
+        return [self.scale_test_alpha_for_graph(a, zs_batch) for a in alphas], list(alphas)
+
+    return type(name, (PixelTransform, op_cls), {'__init__': __init__, 'vis_image_batch': vis_image_batch})
+
+
+SceneGraph = _make_graph('SceneGraph', SceneTransform)
+faceGraph = _make_graph('faceGraph', FaceTransform)
+
+
+def get_transform_graphs(model):
+    if model != 'stylegan_v2_real':
+        raise ImportError("No module named 'graphs.%s' in this build (only the StyleGAN2 path is MI355X-native)" % model)
+    return [SceneGraph, faceGraph]
+
+
+def find_model_using_name(model, transform):
+    """graphs/__init__.py:3-22: class whose lower-cased name equals transform.replace('_','') + 'graph'."""
+    target = transform.replace('_', '') + 'graph'
+    for g in get_transform_graphs(model):
+        if g.__name__.lower() == target.lower():
+            print('Find NAME: ', target.lower())
+            return g
+    print("In graphs.transform_graph_scene, there should be a Class with class name that matches %s in lowercase." % target)
+    raise SystemExit(0)

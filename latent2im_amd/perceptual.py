@@ -1,0 +1,83 @@
+"""VGG-19 ``features`` prefix content loss on the l2i HIP kernels.
+
+Reference: transform_base.py:426-454 (get_content_loss), :44-63 (Normalization, ContentLoss), :465-470 (mean of the four
+taps).  The reference rebuilds and re-runs the growing VGG prefix once per tap (conv_1 four times, conv_2 three times,
+…); the taps are the same tensors each time, so here the prefix is evaluated once per image.  The four taps are the
+PRE-ReLU conv outputs; the ReLU (and the ReLU after the max-pool, which commutes with it) is applied as an input mask in
+the prologue of the next conv, and as an output mask in the epilogue of the gradient convs.
+Normalisation (x - mean)/std: the per-channel 1/std is folded into the first conv's weights, x - mean is one
+``fused_bias_act`` call (zero padding of the normalised image is preserved exactly).
+"""
+import numpy as np
+import torch
+
+from . import conv as C
+from . import kernels as K
+
+VGG_MEAN = (0.485, 0.456, 0.406)
+VGG_STD = (0.229, 0.224, 0.225)
+
+
+class VGG19Prefix:
+    def __init__(self, state, device='cuda'):
+        P = state
+        self.device = device
+        w0 = torch.as_tensor(np.asarray(P['0.weight']), dtype=torch.float32)
+        w0 = w0 / torch.tensor(VGG_STD, dtype=torch.float32).reshape(1, 3, 1, 1)
+        ws = [w0] + [torch.as_tensor(np.asarray(P['%d.weight' % i]), dtype=torch.float32) for i in (2, 5, 7)]
+        self.convs = [C.FrozenConv2d(w, 1, 1, device=device) for w in ws]
+        self.biases = [torch.as_tensor(np.asarray(P['%d.bias' % i]), dtype=torch.float32).contiguous().to(device)
+                       for i in (0, 2, 5, 7)]
+        self.neg_mean = (-torch.tensor(VGG_MEAN, dtype=torch.float32)).to(device)
+
+    def taps(self, img):
+        """[B,3,H,W] -> (c1, c2, p, c3, c4, pool_idx): pre-ReLU conv outputs conv_1..conv_4, p = maxpool(c2)."""
+        xc = K.fused_bias_act(img.contiguous(), self.neg_mean, None, 1, 0, 0.0, 1.0)        # x - mean
+        c1 = self.convs[0].forward(xc, bias=self.biases[0])
+        c2 = self.convs[1].forward(c1, in_mask=c1, mask=(1.0, 0.0), bias=self.biases[1])
+        p, idx = K.maxpool2d_fwd(c2, 2, 2, 0)                     # relu(maxpool(.)) == maxpool(relu(.))
+        c3 = self.convs[2].forward(p, in_mask=p, mask=(1.0, 0.0), bias=self.biases[2])
+        c4 = self.convs[3].forward(c3, in_mask=c3, mask=(1.0, 0.0), bias=self.biases[3])
+        return c1, c2, p, c3, c4, idx
+
+    def content_losses(self, org, shifted):
+        """Four mse(feat_k(org).detach(), feat_k(shifted)) scalars as one [4] tensor, differentiable w.r.t. shifted."""
+        with torch.no_grad():
+            o1, o2, _, o3, o4, _ = self.taps(org.detach())
+        return _ContentFn.apply(shifted, self, (o1, o2, o3, o4))
+
+
+class _ContentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, net, org_taps):
+        c1, c2, p, c3, c4, idx = net.taps(img.detach())
+        mine = (c1, c2, c3, c4)
+        sums = [K.sqdiff(a, b)[0] for a, b in zip(org_taps, mine)]
+        losses = torch.cat([s / float(b.numel()) for s, b in zip(sums, mine)])
+        if img.requires_grad:
+            ctx.net, ctx.org, ctx.acts, ctx.in_hw = net, org_taps, (c1, c2, p, c3, c4, idx), (img.shape[2], img.shape[3])
+        return losses
+
+    @staticmethod
+    def backward(ctx, g_losses):
+        net, (o1, o2, o3, o4) = ctx.net, ctx.org
+        c1, c2, p, c3, c4, idx = ctx.acts
+        gl = [g_losses[k:k + 1].contiguous() for k in range(4)]   # device scalars: no host sync in the backward
+        # direct term of every tap: d/d c_k [ mean (c_k - o_k)^2 ] = 2 (c_k - o_k) / N_k
+        d4 = K.sqdiff(o4, c4, coef=2.0 / c4.numel(), coef_dev=gl[3], want_grad=True, want_sum=False)[1]
+        d3 = K.sqdiff(o3, c3, coef=2.0 / c3.numel(), coef_dev=gl[2], want_grad=True, want_sum=False)[1]
+        g3 = net.convs[3].dgrad(d4, (c3.shape[2], c3.shape[3]), out_mask=c3, residual=d3)
+        del d4, d3
+        gp = net.convs[2].dgrad(g3, (p.shape[2], p.shape[3]), out_mask=p)
+        del g3
+        g2 = K.maxpool2d_bwd(gp, idx, (c2.shape[2], c2.shape[3]), 2, 2, 0)
+        del gp
+        d2 = K.sqdiff(o2, c2, coef=2.0 / c2.numel(), coef_dev=gl[1], want_grad=True, want_sum=False)[1]
+        K.axpby(g2, d2, 1.0, 1.0, out=g2)
+        del d2
+        d1 = K.sqdiff(o1, c1, coef=2.0 / c1.numel(), coef_dev=gl[0], want_grad=True, want_sum=False)[1]
+        g1 = net.convs[1].dgrad(g2, (c1.shape[2], c1.shape[3]), out_mask=c1, residual=d1)
+        del g2, d1
+        g_img = net.convs[0].dgrad(g1, ctx.in_hw)
+        ctx.acts = ctx.org = None
+        return g_img, None, None

@@ -1,0 +1,108 @@
+"""Frozen ResNet-50 attribute regressor (torchvision v0.5.0 layout, fc -> 40) on the l2i HIP kernels.
+
+Reference call sites: transform_base.py:522-528 (construction / checkpoint ``ckpt['model']``), :396-403 and :416-424
+(``regressor(img)[:, attrIdx]`` on the raw [-1,1] generator output, eval mode :267).  Eval-mode BatchNorm is an affine
+map, so it is folded into the preceding conv at construction; ReLU and the residual add live in the conv epilogue;
+the backward is input-gradient only, with every ReLU mask applied in the *prologue* of the next gradient conv
+(no standalone elementwise passes).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import conv as C
+from . import kernels as K
+from .specs import RESNET50_LAYERS
+
+
+def _fold_bn(P, conv_name, bn_name, eps=1e-5):
+    w = torch.as_tensor(np.asarray(P[conv_name + '.weight']), dtype=torch.float64)
+    g = torch.as_tensor(np.asarray(P[bn_name + '.weight']), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(P[bn_name + '.bias']), dtype=torch.float64)
+    m = torch.as_tensor(np.asarray(P[bn_name + '.running_mean']), dtype=torch.float64)
+    v = torch.as_tensor(np.asarray(P[bn_name + '.running_var']), dtype=torch.float64)
+    k = g / torch.sqrt(v + eps)
+    return (w * k.reshape(-1, 1, 1, 1)).float(), (b - m * k).float()
+
+
+class _CB:
+    """conv + folded BN (+ReLU in the epilogue)."""
+
+    def __init__(self, P, conv_name, bn_name, stride, padding, device):
+        w, b = _fold_bn(P, conv_name, bn_name)
+        self.conv = C.FrozenConv2d(w, stride=stride, padding=padding, device=device)
+        self.bias = b.contiguous().to(device)
+
+
+class ResNet50:
+    def __init__(self, state, device='cuda'):
+        P = state
+        self.device = device
+        self.stem = _CB(P, 'conv1', 'bn1', 2, 3, device)
+        self.blocks = []
+        for li, (planes, blocks, stride) in enumerate(RESNET50_LAYERS):
+            for b in range(blocks):
+                p = 'layer%d.%d' % (li + 1, b)
+                s = stride if b == 0 else 1
+                blk = dict(c1=_CB(P, p + '.conv1', p + '.bn1', 1, 0, device),
+                           c2=_CB(P, p + '.conv2', p + '.bn2', s, 1, device),       # v1.5: stride on the 3x3
+                           c3=_CB(P, p + '.conv3', p + '.bn3', 1, 0, device),
+                           down=_CB(P, p + '.downsample.0', p + '.downsample.1', s, 0, device) if b == 0 else None)
+                self.blocks.append(blk)
+        self.fc_w = torch.as_tensor(np.asarray(P['fc.weight']), dtype=torch.float32).contiguous().to(device)
+        self.fc_b = torch.as_tensor(np.asarray(P['fc.bias']), dtype=torch.float32).contiguous().to(device)
+
+    def __call__(self, img):
+        """[B,3,H,W] -> [B, num_classes]; differentiable w.r.t. img."""
+        feat = _ResNetFeatFn.apply(img, self)                  # [B, 2048] pooled features
+        return torch.addmm(self.fc_b, feat, self.fc_w.t())
+
+
+class _ResNetFeatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, net):
+        keep = img.requires_grad
+        x = img.detach().contiguous()
+        a0 = net.stem.conv.forward(x, bias=net.stem.bias, act=C.ACT_RELU)
+        p0, idx0 = K.maxpool2d_fwd(a0, 3, 2, 1)
+        saved = dict(in_hw=(x.shape[2], x.shape[3]), a0=a0 if keep else None, idx0=idx0 if keep else None, blocks=[])
+        cur = p0
+        for blk in net.blocks:
+            y1 = blk['c1'].conv.forward(cur, bias=blk['c1'].bias, act=C.ACT_RELU)
+            y2 = blk['c2'].conv.forward(y1, bias=blk['c2'].bias, act=C.ACT_RELU)
+            if blk['down'] is not None:
+                idt = blk['down'].conv.forward(cur, bias=blk['down'].bias)
+            else:
+                idt = cur
+            out = blk['c3'].conv.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU)
+            if keep:
+                saved['blocks'].append((y1, y2, out, (cur.shape[2], cur.shape[3])))
+            cur = out
+        b, c, h, w = cur.shape
+        feat = K.dot_reduce(cur) * (1.0 / (h * w))             # adaptive avg-pool (1,1)
+        ctx.net, ctx.saved, ctx.last_shape = net, saved if keep else None, (b, c, h, w)
+        return feat
+
+    @staticmethod
+    def backward(ctx, g_feat):
+        net, saved = ctx.net, ctx.saved
+        if saved is None:
+            raise RuntimeError('regressor was run without a differentiable input')
+        b, c, h, w = ctx.last_shape
+        g = (g_feat * (1.0 / (h * w))).reshape(b, c, 1, 1).expand(b, c, h, w).contiguous()
+        for blk, (y1, y2, out, in_hw) in zip(reversed(net.blocks), reversed(saved['blocks'])):
+            # out = relu(c3(y2) + idt): the relu mask rides on every consumer of g
+            g_y2 = blk['c3'].conv.dgrad(g, (y2.shape[2], y2.shape[3]), in_mask=out, mask=(1.0, 0.0))
+            g_y1 = blk['c2'].conv.dgrad(g_y2, (y1.shape[2], y1.shape[3]), in_mask=y2, mask=(1.0, 0.0))
+            if blk['down'] is None:
+                g_in = blk['c1'].conv.dgrad(g_y1, in_hw, in_mask=y1, mask=(1.0, 0.0), residual=g, res_mask=out)
+            else:
+                g_in = blk['c1'].conv.dgrad(g_y1, in_hw, in_mask=y1, mask=(1.0, 0.0))
+                blk['down'].conv.dgrad(g, in_hw, out=g_in, in_mask=out, mask=(1.0, 0.0), accumulate=True)
+            g = g_in
+        a0 = saved['a0']
+        g_a0 = K.maxpool2d_bwd(g, saved['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1)
+        g_img = net.stem.conv.dgrad(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0))
+        ctx.saved = None
+        return g_img, None

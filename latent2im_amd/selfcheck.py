@@ -1,0 +1,73 @@
+"""smoke(): one tiny walk-training step (64^2 generator, batch 4, full loss) on cuda:0, checked against the CPU oracle.
+Called by __graft_entry__.smoke(); the oracle import lives HERE only because smoke() is one of the three places allowed
+to use the checker (it is never on the product path)."""
+import types
+
+import numpy as np
+import torch
+
+
+def build_graph(resolution, attr_names, batch_size, lr=1e-3, walk_seed=7, device=None):
+    """A faceGraph on synthetic weights without touching the CLI (used by smoke(), bench.py and the tests)."""
+    from . import constants, graph, synth
+    constants.resolution = resolution
+    constants.BATCH_SIZE = batch_size
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'dataset', 'attributes_celeba.txt')) as f:
+        names = [l.strip() for l in f if l.strip()]
+    table = {n: i for i, n in enumerate(names)}
+    state = np.random.get_state()
+    g = graph.faceGraph(lr=lr, walk_type='linear', loss='l2', trainEmbed=False, attrList=list(attr_names), attrTable=table,
+                        layers=None, stylegan_opts=types.SimpleNamespace(latent='w'))
+    np.random.set_state(state)
+    with torch.no_grad():
+        g.walk.w.copy_(torch.from_numpy(synth.walk_init(len(attr_names), g.module.netG.n_latent, seed=walk_seed)))
+    return g
+
+
+def run_step(g, zs, alpha, no_content_loss=False, no_gan_loss=False, clamp=False, layers=None, optimize=True):
+    """train.py:56-110 with an explicit alpha instead of the global-RNG draw.  Returns dict of device tensors."""
+    dev = g.device
+    z = torch.Tensor(zs).to(dev)
+    w = g.get_w(z)
+    x0 = g.get_logits({'w': w})
+    a0 = g.get_reg_preds(x0)
+    ag = torch.tensor(alpha).float().to(dev)
+    if clamp:
+        target, eps = g.get_alphas_clamped(a0, ag)
+    else:
+        target, eps = ag, g.get_alphas(a0, ag)
+    w1 = g.get_w_new_tensor(w, eps, layers=layers)
+    x1 = g.get_logits({'w': w1})
+    feed = {'w': w1, 'org': x0, 'logit': x1, 'alpha': target}
+    if optimize:
+        loss = g.optimizeParametersAll(feed, False, False, no_content_loss=no_content_loss, no_gan_loss=no_gan_loss)
+    else:
+        g.optimizers.zero_grad()
+        loss = g.get_w_loss(feed, no_content_loss, no_gan_loss)
+        loss.backward()
+    return dict(x0=x0, x1=x1, a0=a0, eps=eps, loss=loss.detach(), grad=g.walk.w.grad.detach().clone(), terms=g.last_terms)
+
+
+def smoke():
+    from . import synth
+    from oracle import step as ostep                     # checker only
+    assert torch.cuda.is_available(), 'smoke() needs the MI355X'
+    torch.cuda.set_device(0)
+    g = build_graph(64, ['Smiling'], 4)
+    zs = synth.z_sample(4, seed=0)
+    alpha = np.ones((4, 1)) * 0.19
+    r = run_step(g, zs, alpha)
+    torch.cuda.synchronize()
+    dt = torch.float64
+    nets = dict(G=ostep.to_torch(synth.generator_state(64, seed=100), dt), D=ostep.to_torch(synth.discriminator_state(64, seed=200), dt),
+                R=ostep.to_torch(synth.resnet50_state(seed=300), dt), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400), dt))
+    o = ostep.train_step(nets, torch.from_numpy(synth.walk_init(1, 10, seed=7)).to(dt), torch.from_numpy(zs), torch.from_numpy(alpha), [31])
+    img_err = float((r['x1'].double().cpu() - o['x1']).abs().max())
+    loss_err = abs(float(r['loss']) - float(o['loss']))
+    gerr = float((r['grad'].double().cpu() - o['grad']).abs().max() / o['grad'].abs().max())
+    print('smoke: loss %.6f (oracle %.6f)  max|dimg| %.2e  walk-grad rel-to-max err %.2e' % (float(r['loss']), float(o['loss']), img_err, gerr))
+    assert img_err < 1e-3 * float(o['x1'].abs().max()) + 1e-4, img_err
+    assert loss_err < 1e-3 * abs(float(o['loss'])) + 1e-4, loss_err
+    assert gerr < 1e-2, gerr

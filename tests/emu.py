@@ -1,0 +1,54 @@
+"""CPU emulation of the *semantics* of l2i_conv2d_f32 (include/l2i.h) with torch ops — test infrastructure that
+lets the host-side launch plans (weight packing, stride-2 phase decomposition, gradient plans) be checked in the
+GPU-less container.  Never imported by the product."""
+import torch
+import torch.nn.functional as F
+
+
+def emulate_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0), out_scale=None, noise=None,
+                   noise_w=0.0, bias=None, residual=None, res_mask=None, out_mask=None, act=0, slope=0.2, gain=1.0, out_gain=1.0,
+                   accumulate=False, tile_hint=0):
+    B, cin, H, W = x.shape
+    OHf, OWf = y.shape[2], y.shape[3]
+    OH = (OHf - L.off_y + L.step - 1) // L.step
+    OW = (OWf - L.off_x + L.step - 1) // L.step
+    if OH <= 0 or OW <= 0:
+        return
+    w = L.w[:, :, :L.cout].reshape(L.cin, L.kh, L.kw, L.cout).permute(3, 0, 1, 2)     # unpack
+    xi = x
+    if in_scale is not None:
+        xi = xi * in_scale.reshape(B, cin, 1, 1)
+    if in_mask is not None:
+        xi = xi * torch.where(in_mask > 0, torch.tensor(mask[0]), torch.tensor(mask[1]))
+    # input window needed: rows o*stride - pad + k for o < OH
+    need_h = (OH - 1) * L.stride + L.kh
+    need_w = (OW - 1) * L.stride + L.kw
+    pt, pl = max(L.pad_y, 0), max(L.pad_x, 0)
+    xi = xi[:, :, max(-L.pad_y, 0):, max(-L.pad_x, 0):]
+    pb = max(need_h - pt - xi.shape[2], 0)
+    pr = max(need_w - pl - xi.shape[3], 0)
+    xi = F.pad(xi, [pl, pr, pt, pb])[:, :, :need_h, :need_w]
+    a = F.conv2d(xi, w, stride=L.stride)
+    assert a.shape[2] == OH and a.shape[3] == OW, (a.shape, OH, OW)
+    if out_scale is not None:
+        a = a * out_scale.reshape(B, L.cout, 1, 1)
+    sl = (slice(None), slice(None), slice(L.off_y, None, L.step), slice(L.off_x, None, L.step))
+    if out_mask is not None:
+        a = torch.where(out_mask[sl] > 0, a, torch.zeros_like(a))
+    if noise is not None:
+        a = a + noise[sl] * noise_w
+    if bias is not None:
+        a = a + bias.reshape(1, -1, 1, 1)
+    if residual is not None:
+        r = residual[sl]
+        if res_mask is not None:
+            r = torch.where(res_mask[sl] > 0, r, torch.zeros_like(r))
+        a = a + r
+    if act == 1:
+        a = torch.where(a > 0, a, a * slope) * gain
+    elif act == 2:
+        a = torch.relu(a)
+    a = a * out_gain
+    if accumulate:
+        a = a + y[sl]
+    y[sl] = a

@@ -1,0 +1,62 @@
+"""Host-side launch plans of latent2im_amd.conv (packing, stride-2 phases, input-gradient plans) checked on CPU through
+the semantic emulator of the kernel (tests/emu.py) against torch's own conv / conv_transpose / autograd."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from latent2im_amd import conv
+from tests import emu
+
+
+@pytest.fixture(autouse=True)
+def _emulated(monkeypatch):
+    monkeypatch.setattr(conv, 'run_launch', emu.emulate_launch)
+
+
+CASES = [  # (cin, cout, k, stride, pad, transposed, h, w)
+    (5, 7, 3, 1, 1, False, 9, 9), (5, 7, 1, 1, 0, False, 6, 8), (4, 6, 3, 2, 1, False, 12, 12), (4, 6, 3, 2, 1, False, 11, 13),
+    (4, 6, 1, 2, 0, False, 8, 8), (3, 8, 7, 2, 3, False, 20, 20), (4, 6, 3, 2, 0, False, 9, 9), (4, 6, 1, 2, 0, False, 7, 7),
+    (6, 4, 3, 2, 0, True, 5, 5), (6, 4, 3, 2, 0, True, 4, 6), (33, 40, 3, 1, 1, False, 5, 5),
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,tr,h,w', CASES)
+def test_forward_and_dgrad_plans(cin, cout, k, stride, pad, tr, h, w):
+    rs = np.random.RandomState(cin * 100 + cout + k)
+    wt = torch.from_numpy(rs.randn(cout, cin, k, k)).float()
+    x = torch.from_numpy(rs.randn(2, cin, h, w)).float().requires_grad_(True)
+    fc = conv.FrozenConv2d(wt, stride, pad, transposed=tr, device='cpu')
+    if tr:
+        ref = F.conv_transpose2d(x, wt.transpose(0, 1), stride=2, padding=pad)
+    else:
+        ref = F.conv2d(x, wt, stride=stride, padding=pad)
+    y = fc.forward(x.detach())
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y.numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    gy = torch.from_numpy(rs.randn(*ref.shape)).float()
+    gref, = torch.autograd.grad(ref, x, gy)
+    gx = fc.dgrad(gy, (h, w))
+    np.testing.assert_allclose(gx.numpy(), gref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_pack_weight_layout():
+    w = torch.arange(2 * 3 * 2 * 2, dtype=torch.float32).reshape(2, 3, 2, 2)
+    p = conv.pack_weight(w)
+    assert p.shape == (3, 4, 32)
+    assert p[1, 2, 1] == w[1, 1, 1, 0] and p[:, :, 2:].abs().sum() == 0
+
+
+def test_epilogue_and_prologue_semantics():
+    rs = np.random.RandomState(3)
+    wt = torch.from_numpy(rs.randn(6, 4, 3, 3)).float()
+    x = torch.from_numpy(rs.randn(2, 4, 8, 8)).float()
+    s = torch.from_numpy(rs.rand(2, 4)).float() + 0.5
+    d = torch.from_numpy(rs.rand(2, 6)).float() + 0.5
+    nz = torch.from_numpy(rs.randn(2, 1, 8, 8)).float()
+    b = torch.from_numpy(rs.randn(6)).float()
+    fc = conv.FrozenConv2d(wt, 1, 1, device='cpu')
+    y = fc.forward(x, in_scale=s, out_scale=d, noise=nz, noise_w=0.3, bias=b, act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    ref = F.conv2d(x * s[:, :, None, None], wt, padding=1) * d[:, :, None, None] + 0.3 * nz + b[None, :, None, None]
+    ref = F.leaky_relu(ref, 0.2) * 2 ** 0.5
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)

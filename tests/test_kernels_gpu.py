@@ -1,0 +1,148 @@
+"""GPU parity of every C-ABI kernel (include/l2i.h) against the CPU oracle / torch CPU ops on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from latent2im_amd import conv, kernels, synth
+from oracle import sg2
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).float()
+
+
+def close(a, b, rtol=1e-4, atol=1e-4):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol)
+
+
+CONV_CASES = [  # cin, cout, k, stride, pad, transposed, h, w, batch
+    (8, 32, 3, 1, 1, False, 16, 16, 2), (6, 40, 3, 1, 1, False, 37, 45, 1), (64, 64, 3, 1, 1, False, 64, 64, 1),
+    (32, 128, 1, 1, 0, False, 32, 32, 2), (3, 64, 7, 2, 3, False, 64, 64, 1), (16, 24, 3, 2, 1, False, 33, 31, 2),
+    (16, 24, 1, 2, 0, False, 16, 16, 1), (12, 20, 3, 2, 0, True, 8, 8, 2), (32, 32, 3, 2, 0, True, 33, 33, 1),
+    (512, 512, 3, 1, 1, False, 4, 4, 2), (130, 70, 3, 1, 1, False, 8, 8, 1), (5, 3, 3, 1, 1, False, 40, 40, 1),
+    (64, 3, 7, 2, 3, False, 16, 16, 1),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('hint', [0, 1, 2, 3, 4, 5, 6, 7])
+def test_conv_forward_dgrad_vs_torch(case, hint):
+    cin, cout, k, stride, pad, tr, h, w, b = case
+    if hint and [4, 2, 1, 2, 1, 1, 4][hint - 1] * 32 > (cout + 31) // 32 * 32 + 96:
+        pytest.skip('tile much larger than the layer')
+    rs = np.random.RandomState(cin + 7 * cout + k + hint)
+    wt = T(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    x = T(rs.randn(b, cin, h, w)).requires_grad_(True)
+    ref = F.conv_transpose2d(x, wt.transpose(0, 1), stride=2, padding=pad) if tr else F.conv2d(x, wt, stride=stride, padding=pad)
+    fc = conv.FrozenConv2d(wt, stride, pad, transposed=tr, device=DEV)
+    y = fc.forward(x.detach().to(DEV), tile_hint=hint)
+    torch.cuda.synchronize()
+    close(y, ref, 1e-4, 2e-5)
+    gy = T(rs.randn(*ref.shape))
+    gref, = torch.autograd.grad(ref, x, gy)
+    gx = fc.dgrad(gy.to(DEV), (h, w), tile_hint=hint)
+    close(gx, gref, 1e-4, 2e-5)
+
+
+def test_conv_prologue_epilogue_fusions():
+    rs = np.random.RandomState(5)
+    wt = T(rs.randn(48, 40, 3, 3) / 19.0)
+    x, s, d = T(rs.randn(2, 40, 20, 20)), T(rs.rand(2, 40) + 0.5), T(rs.rand(2, 48) + 0.5)
+    nz, bias = T(rs.randn(2, 1, 20, 20)), T(rs.randn(48))
+    msk, res, rmask = T(rs.randn(2, 40, 20, 20)), T(rs.randn(2, 48, 20, 20)), T(rs.randn(2, 48, 20, 20))
+    fc = conv.FrozenConv2d(wt, 1, 1, device=DEV)
+    g = lambda t: t.to(DEV)
+    y = fc.forward(g(x), in_scale=g(s), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    ref = F.leaky_relu(F.conv2d(x * s[:, :, None, None], wt, padding=1) * d[:, :, None, None] + 0.3 * nz + bias[None, :, None, None], 0.2) * 2 ** 0.5
+    close(y, ref, 1e-4, 2e-5)
+    y = fc.forward(g(x), in_mask=g(msk), mask=(2 ** 0.5, 0.2 * 2 ** 0.5), bias=g(bias), residual=g(res), res_mask=g(rmask), act=conv.ACT_RELU, out_gain=0.5)
+    xm = x * torch.where(msk > 0, torch.tensor(2 ** 0.5), torch.tensor(0.2 * 2 ** 0.5))
+    ref = torch.relu(F.conv2d(xm, wt, padding=1) + bias[None, :, None, None] + res * (rmask > 0)) * 0.5
+    close(y, ref, 1e-4, 2e-5)
+    y0 = g(res).clone()
+    fc.forward(g(x), out=y0, accumulate=True)
+    close(y0, res + F.conv2d(x, wt, padding=1), 1e-4, 2e-5)
+
+
+def test_fused_bias_act_golden(golden):
+    gd = golden('fused_bias_act')
+    x, b, ref = (T(gd[k]).to(DEV) for k in ('x', 'b', 'ref'))
+    for act in (1, 3):
+        for grad in (0, 1, 2):
+            y = kernels.fused_bias_act(x, b if grad == 0 else None, ref if grad == 1 else None, act, grad, 0.2, 2 ** 0.5)
+            close(y, T(gd['y_%d%d' % (act, grad)]), 1e-6, 1e-7)
+    close(kernels.fused_bias_act(T(gd['x2']).to(DEV), T(gd['b2']).to(DEV), None, 3, 0, 0.2, 2 ** 0.5), T(gd['y2_30']), 1e-6, 1e-7)
+    # odd sizes take the scalar path; big maps the float4 path
+    rs = np.random.RandomState(0)
+    for shape in ((3, 5, 7, 9), (2, 32, 64, 64), (1, 3, 1, 1)):
+        xx, bb = T(rs.randn(*shape)), T(rs.randn(shape[1]))
+        close(kernels.fused_bias_act(xx.to(DEV), bb.to(DEV), None, 3, 0, 0.2, 2 ** 0.5), sg2.fused_leaky_relu(xx, bb), 1e-6, 1e-7)
+
+
+def test_upfirdn2d_golden(golden):
+    gd = golden('upfirdn2d')
+    for i, (n, c, h, w, up, down, p0, p1, gain) in enumerate(gd['cases']):
+        up, down, p0, p1 = int(up), int(down), int(p0), int(p1)
+        x = T(np.random.RandomState(20 + i).randn(int(n), int(c), int(h), int(w)).astype(np.float32))
+        k = T(synth.fir_kernel(gain=gain))
+        y = kernels.upfirdn2d(x.to(DEV), k.to(DEV), (up, up), (down, down), (p0, p1, p0, p1))
+        close(y, T(gd['y_%d' % i]), 1e-5, 1e-6)
+        # backward = same op, flipped kernel, up<->down, g_pad (op/upfirdn2d.py:105-115)
+        gy = T(gd['gy_%d' % i])
+        g0 = 4 - p0 - 1
+        g1y = int(h) * up - gy.shape[2] * down + p0 - up + 1
+        g1x = int(w) * up - gy.shape[3] * down + p0 - up + 1
+        gx = kernels.upfirdn2d(gy.to(DEV), torch.flip(k, [0, 1]).to(DEV), (down, down), (up, up), (g0, g1x, g0, g1y))
+        close(gx, T(gd['gx_%d' % i]), 1e-5, 1e-6)
+
+
+def test_upfirdn2d_fused_epilogue():
+    rs = np.random.RandomState(1)
+    x, nz, b, add = T(rs.randn(2, 5, 17, 17)), T(rs.randn(2, 1, 16, 16)), T(rs.randn(5)), T(rs.randn(2, 5, 16, 16))
+    k = T(synth.fir_kernel(gain=4.0))
+    y = kernels.upfirdn2d(x.to(DEV), k.to(DEV), pad=(1, 1, 1, 1), noise=nz.to(DEV), noise_w=0.4, bias=b.to(DEV), addend=add.to(DEV),
+                          act=kernels.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    ref = F.leaky_relu(sg2.upfirdn2d(x, k, pad=(1, 1)) + 0.4 * nz + b[None, :, None, None] + add, 0.2) * 2 ** 0.5
+    close(y, ref, 1e-5, 1e-6)
+
+
+def test_torgb_and_act_bwd_and_reductions():
+    rs = np.random.RandomState(2)
+    B, C, H = 2, 24, 12
+    x, wm, bias = T(rs.randn(B, C, H, H)), T(rs.randn(B, 3, C)), T(rs.randn(3))
+    rgb = kernels.torgb_fwd(x.to(DEV), wm.to(DEV), bias.to(DEV))
+    close(rgb, torch.einsum('bchw,boc->bohw', x, wm) + bias[None, :, None, None], 1e-4, 1e-5)
+    # fused backward pass
+    y, gin, gs, grgb = T(rs.randn(B, C, H, H)), T(rs.randn(B, C, H, H)), T(rs.rand(B, C) + 0.5), T(rs.randn(B, 3, H, H))
+    cb, nz = T(rs.randn(C)), T(rs.randn(B, 1, H, H))
+    dz, red, red_rgb = kernels.sg2_act_bwd(y.to(DEV), gin.to(DEV), gs.to(DEV), grgb.to(DEV), wm.to(DEV), cb.to(DEV), nz.to(DEV), 0.3)
+    g = gin * gs[:, :, None, None] + torch.einsum('bohw,boc->bchw', grgb, wm)
+    dz_ref = g * torch.where(y > 0, torch.tensor(2 ** 0.5), torch.tensor(0.2 * 2 ** 0.5))
+    zpre = torch.where(y > 0, y / 2 ** 0.5, y / (0.2 * 2 ** 0.5)) - cb[None, :, None, None] - 0.3 * nz
+    close(dz, dz_ref, 1e-5, 1e-5)
+    close(red, (dz_ref * zpre).sum((2, 3)), 1e-4, 1e-3)
+    close(red_rgb, torch.einsum('bchw,bohw->bco', y, grgb), 1e-4, 1e-3)
+    close(kernels.dot_reduce(x.to(DEV), y.to(DEV)), (x * y).sum((2, 3)), 1e-4, 1e-3)
+    close(kernels.dot_reduce(x.to(DEV)), x.sum((2, 3)), 1e-4, 1e-3)
+    s, gr = kernels.sqdiff(x.to(DEV), y.to(DEV), coef=0.25, want_grad=True)
+    close(s, ((y - x) ** 2).sum().reshape(1), 1e-4, 1e-3)
+    close(gr, 0.25 * (y - x), 1e-6, 1e-6)
+    close(kernels.relu_mask(x.to(DEV), y.to(DEV)), x * (y > 0), 0, 0)
+    close(kernels.axpby(x.to(DEV), y.to(DEV), 0.5, -2.0), 0.5 * x - 2 * y, 1e-6, 1e-6)
+
+
+@pytest.mark.parametrize('k,s,pad,h', [(3, 2, 1, 16), (2, 2, 0, 16), (3, 2, 1, 15)])
+def test_maxpool(k, s, pad, h):
+    rs = np.random.RandomState(k + h)
+    x = torch.relu(T(rs.randn(2, 5, h, h))).requires_grad_(True)      # zeros create ties, as after a ReLU
+    ref = F.max_pool2d(x, k, s, pad)
+    y, idx = kernels.maxpool2d_fwd(x.detach().to(DEV), k, s, pad)
+    close(y, ref, 0, 0)
+    gy = T(rs.randn(*ref.shape))
+    gref, = torch.autograd.grad(ref, x, gy)
+    gx = kernels.maxpool2d_bwd(gy.to(DEV), idx, (h, h), k, s, pad)
+    close(gx, gref, 1e-6, 1e-6)

@@ -1,0 +1,64 @@
+"""Micro-benchmark of l2i_conv2d_f32 on the layer shapes of the 1024^2 walk-training step (GPU box only).
+Prints TFLOP/s (2*MAC of the dense contraction) per shape and tile configuration."""
+import sys
+import os
+import json
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from latent2im_amd import conv
+
+SHAPES = [  # name, cin, cout, k, stride, pad, transposed, res, batch
+    ('g64_512', 512, 512, 3, 1, 1, False, 64, 8),
+    ('g128_256', 256, 256, 3, 1, 1, False, 128, 8),
+    ('g256_128', 128, 128, 3, 1, 1, False, 256, 8),
+    ('g512_64', 64, 64, 3, 1, 1, False, 512, 8),
+    ('g1024_32', 32, 32, 3, 1, 1, False, 1024, 8),
+    ('g_up512', 128, 64, 3, 2, 0, True, 256, 8),
+    ('g16_512', 512, 512, 3, 1, 1, False, 16, 8),
+    ('g4_512', 512, 512, 3, 1, 1, False, 4, 8),
+    ('r_1x1_256', 256, 64, 1, 1, 0, False, 256, 8),
+    ('r_1x1_2048', 1024, 2048, 1, 1, 0, False, 32, 8),
+    ('r_stem', 3, 64, 7, 2, 3, False, 1024, 8),
+    ('v_64', 64, 64, 3, 1, 1, False, 1024, 4),
+]
+
+
+def main():
+    hints = [int(h) for h in sys.argv[1].split(',')] if len(sys.argv) > 1 else [0, 1, 2, 3]
+    rows = []
+    for name, cin, cout, k, stride, pad, tr, res, b in SHAPES:
+        w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+        fc = conv.FrozenConv2d(w, stride, pad, transposed=tr, device='cuda')
+        x = torch.randn(b, cin, res, res, device='cuda')
+        oh, ow = fc.out_hw(res, res)
+        y = torch.empty(b, cout, oh, ow, device='cuda')
+        macs = b * cout * cin * k * k * (res * res if tr else oh * ow)
+        for hint in hints:
+            if hint and [4, 2, 1, 2, 1, 1, 4][hint - 1] * 32 > (cout + 31) // 32 * 32:
+                continue
+            try:
+                for _ in range(2):
+                    fc.forward(x, out=y, tile_hint=hint)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n = 5
+                e0.record()
+                for _ in range(n):
+                    fc.forward(x, out=y, tile_hint=hint)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / n
+                tf = 2 * macs / ms / 1e9
+                rows.append(dict(shape=name, hint=hint, ms=round(ms, 4), tflops=round(tf, 2)))
+                print('%-12s hint=%d  %8.3f ms  %7.2f TFLOP/s' % (name, hint, ms, tf), flush=True)
+            except Exception as e:
+                print(name, hint, 'ERR', e, flush=True)
+    print(json.dumps(rows))
+
+
+if __name__ == '__main__':
+    main()
