@@ -1,0 +1,143 @@
+"""Benchmark of the walk-training hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+One "step" = one full iteration of the reference's training loop (train.py:48-110) over one batch of synthetic z:
+sample z -> style MLP -> StyleGAN2 synthesis (original) -> ResNet-50 regressor -> linear W+ walk -> synthesis (edited)
+-> discriminator + VGG-19 content + regressor BCE losses -> backward into the walk -> [all-reduce] -> Adam.
+Workload = BASELINE.json configs[2]: StyleGAN2 FFHQ-shaped 1024^2 generator, ResNet-50 regressor, 1 attribute
+(Smiling), batch 8 per GPU, full loss (the reference's default flags), fp32 on the matrix cores.  Weak scaling: the
+per-GPU batch is fixed; ranks draw identical z / alpha and take their slice; the only collective is one all-reduce of
+the walk gradient per step.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(resolution, attrs, budget_s, full_loss=True):
+    """The CPU oracle (plain torch on the host cores) on a bounded sample of the same workload: whole training steps at
+    the benchmark resolution with batch 1 (per-image work is identical; D's stddev group is min(B,4))."""
+    from latent2im_amd import synth
+    from oracle import step as ostep
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    nets = dict(G=ostep.to_torch(synth.generator_state(resolution, seed=100)), D=ostep.to_torch(synth.discriminator_state(resolution, seed=200)),
+                R=ostep.to_torch(synth.resnet50_state(seed=300)), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400)))
+    n_latent = 2 * int(np.log2(resolution)) - 2
+    walk = torch.from_numpy(synth.walk_init(len(attrs), n_latent, seed=7))
+    idx = list(range(len(attrs)))
+    done, t_total = 0, 0.0
+    while True:
+        z = torch.from_numpy(synth.z_sample(1, seed=done)).float()
+        t0 = time.time()
+        ostep.train_step(nets, walk, z, torch.full((1, len(attrs)), 0.3), [31 + i for i in idx],
+                         no_content_loss=not full_loss, no_gan_loss=not full_loss)
+        t_total += time.time() - t0
+        done += 1
+        if t_total >= budget_s or done >= 4:
+            break
+    return dict(value=done / t_total, unit='images/s', cores=threads, kind='port',
+                sample='%d full training step(s) of batch 1 at %d^2 (same losses), %.1f s of CPU work, torch %s CPU ops'
+                       % (done, resolution, t_total, torch.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--resolution', type=int, default=1024)
+    ap.add_argument('--batch', type=int, default=8, help='per-GPU batch')
+    ap.add_argument('--attrs', type=str, default='Smiling')
+    ap.add_argument('--reg_only', action='store_true', help='--no_content_loss --no_gan_loss')
+    ap.add_argument('--cpu_baseline_s', type=float, default=12.0, help='CPU-oracle time budget (0 = skip)')
+    ap.add_argument('--no_kernel_events', action='store_true', help='do not bracket conv launches with events')
+    a = ap.parse_args()
+
+    from latent2im_amd import conv, dist, selfcheck, synth
+    rk, world, local = dist.init_from_env()
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus))
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X'
+    dev = torch.device('cuda', torch.cuda.current_device())
+    attrs = a.attrs.split(',')
+    np.random.seed(1234)
+    g = selfcheck.build_graph(a.resolution, attrs, a.batch * world, lr=1e-4)
+    if world > 1:
+        torch.distributed.broadcast(g.walk.w.data, src=0)
+    flags = dict(no_content_loss=a.reg_only, no_gan_loss=a.reg_only)
+    global_b = a.batch * world
+    zs_all = synth.z_sample(global_b * (a.steps + a.warmup), seed=0)
+    sl = dist.shard(global_b)
+
+    def one_step(i):
+        zs = zs_all[i * global_b:(i + 1) * global_b][sl]
+        alpha = np.ones((a.batch, len(attrs))) * np.random.uniform(0, 1, len(attrs))      # FaceTransform.get_train_alpha
+        return selfcheck.run_step(g, zs, alpha, **flags)
+
+    for i in range(a.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    if not a.no_kernel_events:
+        conv.PROFILE = []
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        r = one_step(a.warmup + i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = dist.max_over_ranks(elapsed, dev)
+    prof, conv.PROFILE = conv.PROFILE, None
+
+    if rk != 0:
+        return
+    ms_per_step = elapsed / a.steps * 1e3
+    value = global_b * a.steps / elapsed
+    roof = None
+    if prof:
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+        tot_flop = sum(f for _, _, f in prof)
+        ach = tot_flop / (tot_ms * 1e-3) / 1e12
+        roof = dict(bound='mfma', kernel='conv_mfma_kernel (l2i_conv2d_f32)', achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                    unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    launches_per_step=len(prof) // a.steps, avg_launch_ms=round(tot_ms / len(prof), 4),
+                    kernel_ms_per_step=round(tot_ms / a.steps, 2),
+                    algorithmic_tflop_per_step=round(tot_flop / a.steps / 1e12, 3),
+                    note='achieved = sum over conv launches of 2*MAC of the dense correlation / sum of their HIP-event durations '
+                         'in the timed region; algorithmic TFLOP per image = algorithmic_tflop_per_step / batch')
+    out = dict(metric='edited images/sec', value=round(value, 3), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
+               ms_per_step=round(ms_per_step, 2), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
+               data='synthetic',
+               config=dict(workload='StyleGAN2 FFHQ-shaped %d^2 generator (random-init), ResNet-50 regressor, %d attr, %s, '
+                                    'batch %d per GPU, linear W+ walk' % (a.resolution, len(attrs),
+                                                                          'reg-only loss' if a.reg_only else 'full loss (reg+content+GAN)', a.batch),
+                           resolution=a.resolution, global_batch=global_b, per_gpu_batch=a.batch, attrs=attrs,
+                           losses='reg' if a.reg_only else 'reg+content+gan', parallelism='dp%d' % world,
+                           loss=float(r['loss'])),
+               roofline=roof)
+    if world == 1 and a.cpu_baseline_s > 0:
+        out['cpu_baseline'] = cpu_baseline(a.resolution, attrs, a.cpu_baseline_s, full_loss=not a.reg_only)
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

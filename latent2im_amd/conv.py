@@ -15,6 +15,9 @@ from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvParams  # noqa: F401
 
 
+PROFILE = None      # bench.py sets this to a list: every launch then appends (start_event, end_event, algorithmic_flops)
+
+
 def pack_weight(w):
     """[Cout, Cin, KH, KW] -> packed [Cin, KH*KW, CoutP] (CoutP = Cout rounded up to 32, zero padded)."""
     w = torch.as_tensor(w, dtype=torch.float32)
@@ -112,6 +115,13 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         assert residual.shape == y.shape
     if out_mask is not None:
         assert out_mask.shape == y.shape
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.l2i_conv2d_f32(p, _lib.stream_ptr()), 'l2i_conv2d_f32')
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * B * L.cout * cin * L.kh * L.kw * OH * OW))
+        return
     _lib.check(lib.l2i_conv2d_f32(p, _lib.stream_ptr()), 'l2i_conv2d_f32')
 
 

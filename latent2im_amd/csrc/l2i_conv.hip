@@ -12,31 +12,50 @@
 // pixels of one channel = a 128-byte coalesced NCHW row segment.  The two lane halves of the K=2 MFMA take
 // channels c and c+CK/2 of the staged chunk, so all LDS fragment addresses are "lane base + wave-uniform offset".
 //
-// Block = 256 threads = 4 waves, all along N: block tile = (WM*32 channels) x (4*WN*32 pixels); the pixel tile is
-// TH rows x TW columns with TW = min(32, pow2(OW)).  Per K chunk: input tile [CK][IH][IWp] + weights [CK][KH*KW][BM]
-// staged in LDS (<= 48 KiB so 2-3 blocks share a CU and hide each other's staging).
+// Block = 256 threads = 4 waves, all along N: block tile = (WM*32 channels) x (4*WN*32 pixels).  The pixel tile is
+// TB samples x TH rows x TW columns (all powers of two, TB*TH*TW = 128*WN): large maps use TB = 1, TW = 32; maps
+// smaller than the tile (4x4 .. 16x16 layers, and their odd-sized phase maps) pack several samples into one tile.
+//
+// Pipeline per K chunk (CK input channels): the NEXT chunk's global loads are issued into registers before the
+// MFMA loop of the current chunk (independent loads, nothing waits on them), and written to LDS after it — HBM/L2
+// latency hides under ~10^4 cycles of matrix work; 2 blocks per CU cover the two barriers per chunk.  Prologue
+// fusions (style/demod scale, activation-gradient mask) are applied on the register->LDS write.  1x1 stride-1
+// layers (half of ResNet-50) stage 16-byte vectors.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "l2i.h"
 #include "l2i_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvLaunch {
-    int tw_log2;      // log2(TW)
-    int tiles_x, tiles_y, mblocks;
-    int CK;           // channels per LDS chunk (even)
-    int IH, IW, IWp;  // staged input tile
-    int plane;        // IH*IWp
+    int tw_log2, th_log2, tb_log2;     // pixel tile = 2^tb samples x 2^th rows x 2^tw columns
+    int tiles_x, tiles_y, bgroups, mblocks;
+    int CK;                            // channels per LDS chunk (even)
+    int IH, IW, IWp;                   // staged input rows / columns / padded pitch per sample
+    int planeS, plane;                 // floats per (channel, sample) and per channel (>= TB*planeS, multiple of 4)
+    int rows_c;                        // TB*IH: staged rows per channel
+    unsigned magic_iw, magic_rc, magic_ih;   // ceil(2^32/d) for d = IW, rows_c, IH
+    int in_elems;                      // CK*rows_c*IW   (VEC: in float4 units)
+    int w_vec;                         // CK*KK*BM/4
 };
 
-template <int WM, int WN>
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic) { return __umulhi(n, magic); }
+
+template <int BM> struct WSlots { static constexpr int value = (BM == 128) ? 10 : (BM == 64 ? 8 : 4); };
+
+// NIN: input slots per thread per chunk (floats, or float4 when VEC); NWV: weight float4 slots per thread per chunk
+template <int WM, int WN, bool VEC, bool MASK>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const l2i_conv_params p, const ConvLaunch L) {
     constexpr int BM = WM * 32;
+    constexpr int NIN = VEC ? 4 : 12;
+    constexpr int NWV = WSlots<BM>::value;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* lds_in = smem;                               // [CK][IH][IWp]
-    float* lds_w = smem + L.CK * L.plane;               // [CK][KK][BM]   (offset kept 16-B aligned by the host)
+    float* lds_in = smem;                               // [CK][TB][IH][IWp]
+    float* lds_w = smem + L.CK * L.plane;               // [CK][KK][BM]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -44,29 +63,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const l2i_conv_params p,
     const int half = lane >> 5;
     const int j = lane & 31;
     const int KK = p.KH * p.KW;
-    const int TW = 1 << L.tw_log2;
-    const int RPT = 32 >> L.tw_log2;                    // rows per 32-pixel N tile
-    const int TH = 4 * WN * RPT;
+    const int TW = 1 << L.tw_log2, TH = 1 << L.th_log2;
 
-    // ---- block -> (batch, tile, channel block) ----
+    // ---- block -> (sample group, tile, channel block) ----
     int bid = blockIdx.x;
     const int mblk = bid % L.mblocks; bid /= L.mblocks;
     const int tx = bid % L.tiles_x; bid /= L.tiles_x;
     const int ty = bid % L.tiles_y; bid /= L.tiles_y;
-    const int b = bid;
+    const int b0 = bid << L.tb_log2;
     const int m0 = mblk * BM;
-    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int oy0 = ty << L.th_log2, ox0 = tx << L.tw_log2;
     const int iy0 = oy0 * p.stride - p.pad_y, ix0 = ox0 * p.stride - p.pad_x;
 
-    // ---- per-lane fragment bases ----
+    // ---- per-lane fragment bases: pixel index within the tile = q*32 + j -> (tb, row, col) ----
     const int CKh = L.CK >> 1;
     int pixoff[WN];
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
-        const int q = wave * WN + n;
-        const int r = q * RPT + (j >> L.tw_log2);
-        const int c = j & (TW - 1);
-        pixoff[n] = (r * p.stride) * L.IWp + c * p.stride + half * CKh * L.plane;
+        const int pi = (wave * WN + n) * 32 + j;
+        const int c = pi & (TW - 1);
+        const int r = (pi >> L.tw_log2) & (TH - 1);
+        const int tb = pi >> (L.tw_log2 + L.th_log2);
+        pixoff[n] = tb * L.planeS + (r * p.stride) * L.IWp + c * p.stride + half * CKh * L.plane;
     }
     const int wlane = half * CKh * KK * BM + j;
 
@@ -78,55 +96,121 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const l2i_conv_params p,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const size_t x_b = (size_t)b * p.Cin * p.H * p.W;
-    const int scol = tid & 63, srow = tid >> 6;
+    // ---- staging state: every global access of the K loop is a buffer load "descriptor + per-slot VGPR offset +
+    //      per-chunk SGPR offset": no address arithmetic and no bounds branches inside the loop (out-of-range = 0) ----
+    const size_t plane_x = (size_t)p.H * p.W;
+    const int nb = (p.B - b0) < (1 << L.tb_log2) ? (p.B - b0) : (1 << L.tb_log2);
+    const unsigned in_bytes = (unsigned)((size_t)nb * p.Cin * plane_x * sizeof(float));   // host guarantees < 4 GiB
+    const size_t grp_off = (size_t)b0 * p.Cin * plane_x;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + grp_off), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)((MASK ? p.in_mask : p.x) + grp_off), 0, in_bytes, 0x00020000);
+    const unsigned w_bytes = (unsigned)((size_t)p.Cin * KK * p.CoutP * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
+    const unsigned sc_bytes = (unsigned)((size_t)nb * p.Cin * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((p.in_scale ? p.in_scale : p.x) + (size_t)b0 * p.Cin), 0, p.in_scale ? sc_bytes : 0u, 0x00020000);
 
-    for (int c0 = 0; c0 < p.Cin; c0 += L.CK) {
-        __syncthreads();        // previous chunk's fragments fully consumed
-        // ---- stage input tile (prologue fused: style/demod scale, activation-gradient mask) ----
-        {
-            int c = 0, iy = srow;
-            while (iy >= L.IH) { iy -= L.IH; ++c; }
-            while (c < L.CK) {
-                const int ci = c0 + c;
-                const int gy = iy0 + iy;
-                const bool rowok = (ci < p.Cin) && (gy >= 0) && (gy < p.H);
-                float sc = 1.f;
-                if (rowok && p.in_scale) sc = p.in_scale[(size_t)b * p.Cin + ci];
-                const size_t rbase = x_b + ((size_t)ci * p.H + gy) * p.W;
-                float* dst = lds_in + c * L.plane + iy * L.IWp;
-                for (int ix = scol; ix < L.IW; ix += 64) {
-                    const int gx = ix0 + ix;
-                    float v = 0.f;
-                    if (rowok && gx >= 0 && gx < p.W) {
-                        v = p.x[rbase + gx] * sc;
-                        if (p.in_mask) v *= (p.in_mask[rbase + gx] > 0.f) ? p.mask_pos : p.mask_neg;
+    typedef typename std::conditional<VEC, u32x4, unsigned>::type in_t;
+    in_t rin[NIN];
+    in_t rmk[MASK ? NIN : 1];
+    u32x4 rw[NWV];
+    unsigned rsc = 0;
+    unsigned voff[NIN];          // byte offset of the slot inside the sample group (channel 0 of the chunk), or out of range
+    int loff[NIN];               // float offset of the slot inside lds_in, or -1
+    const int iw_units = VEC ? (L.IW >> 2) : L.IW;
+#pragma unroll
+    for (int u = 0; u < NIN; ++u) {
+        const unsigned e = tid + u * 256;
+        voff[u] = in_bytes;
+        loff[u] = -1;
+        if ((int)e < L.in_elems) {
+            unsigned row, ixu;
+            if constexpr (VEC) { row = e >> (L.tw_log2 - 2); ixu = e & (iw_units - 1); }
+            else { row = fast_div(e, L.magic_iw); ixu = e - row * L.IW; }
+            const unsigned c = fast_div(row, L.magic_rc);
+            const unsigned r2 = row - c * L.rows_c;
+            const unsigned tb = fast_div(r2, L.magic_ih);
+            const int iy = (int)(r2 - tb * L.IH);
+            const int gy = iy0 + iy;
+            const int gx = ix0 + (int)(VEC ? ixu * 4 : ixu);
+            loff[u] = (int)(c * L.plane + tb * L.planeS + iy * L.IWp + (VEC ? ixu * 4 : ixu));
+            if ((int)tb < nb && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                voff[u] = (unsigned)((((size_t)tb * p.Cin + c) * plane_x + (size_t)gy * p.W + gx) * sizeof(float));
+        }
+    }
+    constexpr int V = BM / 4;
+    const int wrow0 = tid / V, wc4 = tid - wrow0 * V;
+    const unsigned wvoff = (m0 + wc4 * 4 < p.CoutP) ? (unsigned)(((size_t)wrow0 * p.CoutP + m0 + wc4 * 4) * sizeof(float)) : w_bytes;
+    const unsigned wstep = (unsigned)((256 / V) * p.CoutP * sizeof(float));                // slot u = rows wrow0 + u*256/V
+    const int TBCK = L.CK << L.tb_log2;
+    const unsigned scoff = (tid < TBCK) ? (unsigned)((((tid / L.CK) * p.Cin) + (tid % L.CK)) * sizeof(float)) : sc_bytes;
+    float* lds_sc = lds_w + L.CK * KK * BM;              // [TB][CK] input scales of the chunk (ones when absent)
+
+    // issue the global loads of chunk c0 into registers (no waits, no VALU)
+    auto issue = [&](int c0) {
+        const unsigned so = (unsigned)((size_t)c0 * plane_x * sizeof(float));
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) {
+            if constexpr (VEC) {
+                rin[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff[u], so, 0);
+                if constexpr (MASK) rmk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, voff[u], so, 0);
+            } else {
+                rin[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff[u], so, 0);
+                if constexpr (MASK) rmk[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, voff[u], so, 0);
+            }
+        }
+        const unsigned sw = (unsigned)((size_t)c0 * KK * p.CoutP * sizeof(float));
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) rw[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff, sw + u * wstep, 0);
+        rsc = __builtin_amdgcn_raw_buffer_load_b32(rs_s, scoff, (unsigned)(c0 * sizeof(float)), 0);
+    };
+
+    // write the prefetched registers to LDS (activation-gradient mask applied here; the style/demod scale goes to
+    // a small LDS table that the MFMA loop multiplies into the B fragments)
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) {
+            if (loff[u] >= 0) {
+                if constexpr (VEC) {
+                    float4 v = make_float4(__uint_as_float(rin[u].x), __uint_as_float(rin[u].y), __uint_as_float(rin[u].z), __uint_as_float(rin[u].w));
+                    if constexpr (MASK) {
+                        v.x *= (__uint_as_float(rmk[u].x) > 0.f) ? p.mask_pos : p.mask_neg;
+                        v.y *= (__uint_as_float(rmk[u].y) > 0.f) ? p.mask_pos : p.mask_neg;
+                        v.z *= (__uint_as_float(rmk[u].z) > 0.f) ? p.mask_pos : p.mask_neg;
+                        v.w *= (__uint_as_float(rmk[u].w) > 0.f) ? p.mask_pos : p.mask_neg;
                     }
-                    dst[ix] = v;
+                    *reinterpret_cast<float4*>(lds_in + loff[u]) = v;
+                } else {
+                    float v = __uint_as_float(rin[u]);
+                    if constexpr (MASK) v *= (__uint_as_float(rmk[u]) > 0.f) ? p.mask_pos : p.mask_neg;
+                    lds_in[loff[u]] = v;
                 }
-                iy += 4;
-                while (iy >= L.IH) { iy -= L.IH; ++c; }
             }
         }
-        // ---- stage weights: rows (c*KK+tap) of BM contiguous channels, float4 coalesced ----
-        {
-            const int rows = L.CK * KK;
-            const int rows_valid = (p.Cin - c0) * KK;       // rows beyond Cin are zero
-            constexpr int V = BM / 4;
-            const float* wsrc = p.w + (size_t)c0 * KK * p.CoutP + m0;
-            for (int idx = tid; idx < rows * V; idx += 256) {
-                const int row = idx / V, c4 = idx - row * V;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < rows_valid && m0 + c4 * 4 < p.CoutP)
-                    v = *reinterpret_cast<const float4*>(wsrc + (size_t)row * p.CoutP + c4 * 4);
-                *reinterpret_cast<float4*>(lds_w + row * BM + c4 * 4) = v;
-            }
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) {
+            const int idx = tid + u * 256;
+            if (idx < L.w_vec) reinterpret_cast<u32x4*>(lds_w)[idx] = rw[u];
         }
+        if (tid < TBCK) lds_sc[tid] = p.in_scale ? __uint_as_float(rsc) : 1.f;
+    };
+
+    int sbase[WN];               // per N tile: index of this lane's (sample, first channel) in the scale table
+#pragma unroll
+    for (int n = 0; n < WN; ++n) sbase[n] = ((((wave * WN + n) * 32 + j) >> (L.tw_log2 + L.th_log2)) * L.CK) + half * CKh;
+
+    issue(0);
+    for (int c0 = 0; c0 < p.Cin; c0 += L.CK) {
+        commit();
         __syncthreads();
+        if (c0 + L.CK < p.Cin) issue(c0 + L.CK);        // in flight during the MFMA loop below
         // ---- MFMA over the chunk: lanes 0-31 take channel cc, lanes 32-63 channel cc + CK/2 ----
         for (int cc = 0; cc < CKh; ++cc) {
             const float* wr = lds_w + wlane + cc * KK * BM;
             const float* ir = lds_in + cc * L.plane;
+            float sv[WN];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) sv[n] = lds_sc[sbase[n] + cc];
             for (int ky = 0; ky < p.KH; ++ky) {
                 for (int kx = 0; kx < p.KW; ++kx) {
                     float a[WM], bb[WN];
@@ -134,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const l2i_conv_params p,
 #pragma unroll
                     for (int m = 0; m < WM; ++m) a[m] = wr[m * 32];
 #pragma unroll
-                    for (int n = 0; n < WN; ++n) bb[n] = ir[pixoff[n] + toff];
+                    for (int n = 0; n < WN; ++n) bb[n] = ir[pixoff[n] + toff] * sv[n];
 #pragma unroll
                     for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -144,29 +228,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const l2i_conv_params p,
                 }
             }
         }
+        __syncthreads();        // every wave is done reading this chunk's fragments
     }
 
-    // ---- epilogue: demod / noise / bias / residual / activation, 128-B row segments per register ----
+    // ---- epilogue: demod / mask / noise / bias / residual / activation; 128-B row segments per register ----
     const size_t plane_o = (size_t)p.OHf * p.OWf;
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
-        const int q = wave * WN + n;
-        const int oy = oy0 + q * RPT + (j >> L.tw_log2);
-        const int ox = ox0 + (j & (TW - 1));
-        const bool pok = (oy < p.OH) && (ox < p.OW);
+        const int pi = (wave * WN + n) * 32 + j;
+        const int ox = ox0 + (pi & (TW - 1));
+        const int oy = oy0 + ((pi >> L.tw_log2) & (TH - 1));
+        const int bb = b0 + (pi >> (L.tw_log2 + L.th_log2));
+        const bool pok = (oy < p.OH) && (ox < p.OW) && (bb < p.B);
         const int oyf = oy * p.oy_step + p.oy_off, oxf = ox * p.ox_step + p.ox_off;
         const size_t poff = (size_t)oyf * p.OWf + oxf;
         float nz = 0.f;
-        if (pok && p.noise) nz = p.noise[(size_t)b * plane_o + poff] * p.noise_w;
+        if (pok && p.noise) nz = p.noise[(size_t)bb * plane_o + poff] * p.noise_w;
+        const int co_lane = m0 + 4 * half;
+        const size_t lane_base = ((size_t)bb * p.Cout + co_lane) * plane_o + poff;
+        const float* osc = p.out_scale ? p.out_scale + (size_t)bb * p.Cout : nullptr;
 #pragma unroll
         for (int m = 0; m < WM; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = m0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int cofs = m * 32 + (r & 3) + 8 * (r >> 2);          // compile-time constant
+                const int co = co_lane + cofs;
                 if (pok && co < p.Cout) {
                     float v = acc[m][n][r];
-                    if (p.out_scale) v *= p.out_scale[(size_t)b * p.Cout + co];
-                    const size_t oidx = ((size_t)b * p.Cout + co) * plane_o + poff;
+                    if (osc) v *= osc[co];
+                    const size_t oidx = lane_base + (size_t)cofs * plane_o;
                     if (p.out_mask) v = (p.out_mask[oidx] > 0.f) ? v : 0.f;
                     v += nz;
                     if (p.bias) v += p.bias[co];
@@ -188,21 +278,73 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const l2i_conv_params p,
 
 // ------------------------------------------------------------------------------------------------------------
 static int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static unsigned magic_for(unsigned d) { return (unsigned)((0x100000000ULL + d - 1) / d); }    // exact while n*d < 2^32
 
 struct TileCfg { int wm, wn; };
 static const TileCfg kTiles[] = {{4, 2}, {2, 2}, {1, 4}, {2, 1}, {1, 1}, {1, 2}, {4, 1}};
 static const int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int WM, int WN>
-static hipError_t launch_cfg(const l2i_conv_params& p, const ConvLaunch& L, int grid, size_t lds, hipStream_t st) {
-    static bool attr_done = false;          // allow > 64 KiB dynamic LDS if ever requested
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN>), dim3(grid), dim3(256), lds, st, p, L);
+template <int WM, int WN, bool VEC, bool MASK>
+static hipError_t launch_one(const l2i_conv_params& p, const ConvLaunch& L, int grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, VEC, MASK>), dim3(grid), dim3(256), lds, st, p, L);
     return hipGetLastError();
+}
+
+template <int WM, int WN>
+static hipError_t launch_cfg(const l2i_conv_params& p, const ConvLaunch& L, int grid, size_t lds, bool vec, hipStream_t st) {
+    const bool mask = p.in_mask != nullptr;
+    if (vec) return mask ? launch_one<WM, WN, true, true>(p, L, grid, lds, st) : launch_one<WM, WN, true, false>(p, L, grid, lds, st);
+    return mask ? launch_one<WM, WN, false, true>(p, L, grid, lds, st) : launch_one<WM, WN, false, false>(p, L, grid, lds, st);
+}
+
+// geometry of one tile configuration for this problem; returns false if it cannot be staged
+static bool plan_tile(const l2i_conv_params& p, int wm, int wn, ConvLaunch& L, bool& vec, size_t& lds, long& grid) {
+    const int BM = wm * 32, BN = 128 * wn;
+    const int nwv = (BM == 128) ? 10 : (BM == 64 ? 8 : 4);
+    L.tw_log2 = ilog2_ceil(p.OW < 32 ? p.OW : 32);
+    const int TW = 1 << L.tw_log2;
+    int th = BN / TW;
+    const int oh_p2 = 1 << ilog2_ceil(p.OH);
+    if (th > oh_p2) th = oh_p2;
+    L.th_log2 = ilog2_ceil(th);
+    const int TH = 1 << L.th_log2;
+    L.tb_log2 = ilog2_ceil(BN / (TH * TW));
+    const int TB = 1 << L.tb_log2;
+    if ((size_t)TB * p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull) return false;     // 32-bit buffer offsets per sample group
+    L.tiles_x = (p.OW + TW - 1) / TW;
+    L.tiles_y = (p.OH + TH - 1) / TH;
+    L.bgroups = (p.B + TB - 1) / TB;
+    L.mblocks = (p.CoutP + BM - 1) / BM;
+    L.IH = (TH - 1) * p.stride + p.KH;
+    L.IW = (TW - 1) * p.stride + p.KW;
+    vec = (p.KW == 1 && p.KH == 1 && p.stride == 1 && p.pad_x == 0 && p.pad_y == 0 && (p.W % 4) == 0 && TW >= 4 &&
+           (((uintptr_t)p.x) % 16) == 0 && (!p.in_mask || (((uintptr_t)p.in_mask) % 16) == 0));
+    L.IWp = vec ? L.IW : (L.IW | 1);
+    L.planeS = L.IH * L.IWp;
+    L.plane = (TB * L.planeS + 3) & ~3;
+    L.rows_c = TB * L.IH;
+    const int KK = p.KH * p.KW;
+    // channels per chunk: bounded by LDS (48 KiB -> 2-3 blocks per CU), by the register prefetch slots and by Cin
+    const size_t per_c = (size_t)(L.plane + KK * BM) * sizeof(float);
+    int ck = (int)((48 * 1024) / per_c);
+    const int in_per_c = vec ? (L.rows_c * (L.IW / 4)) : (L.rows_c * L.IW);
+    const int ck_in = ((vec ? 4 : 12) * 256) / in_per_c;
+    const int ck_w = (nwv * 256) / (KK * BM / 4);
+    if (ck > ck_in) ck = ck_in;
+    if (ck > ck_w) ck = ck_w;
+    ck &= ~1;
+    if (ck < 2) return false;
+    const int cin_even = (p.Cin + 1) & ~1;
+    if (ck > cin_even) ck = cin_even;
+    L.CK = ck;
+    L.in_elems = ck * in_per_c;
+    L.w_vec = ck * KK * BM / 4;
+    L.magic_iw = magic_for((unsigned)L.IW);
+    L.magic_rc = magic_for((unsigned)L.rows_c);
+    L.magic_ih = magic_for((unsigned)L.IH);
+    lds = per_c * ck + (size_t)(ck << L.tb_log2) * sizeof(float);
+    grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks;
+    return lds <= 64 * 1024 && grid > 0 && grid <= 0x7fffffffL;
 }
 
 extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
@@ -217,61 +359,51 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
     if (p.oy_step <= 0 || p.ox_step <= 0 || (p.OH - 1) * p.oy_step + p.oy_off >= p.OHf || (p.OW - 1) * p.ox_step + p.ox_off >= p.OWf ||
         p.oy_off < 0 || p.ox_off < 0)
         return l2i_set_error(L2I_E_ARG, "conv2d: output window exceeds the output tensor");
+    if ((((uintptr_t)p.w) % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv2d: packed weights must be 16-byte aligned");
+    if ((size_t)p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull || (size_t)p.Cin * p.KH * p.KW * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull)
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d: one sample / the weight pack must stay below 4 GiB (32-bit buffer offsets)");
 
-    // ---- tile selection: largest channel tile that divides the work into enough blocks for 256 CUs ----
+    // ---- tile selection: minimise a simple time model  waves(grid / resident blocks) x cycles per block  ----
+    //      cycles per block = MFMA issue (64 cycles each) + per-chunk barrier/commit cost + epilogue stores (hidden by co-resident blocks);
+    //      resident blocks per CU from the register footprint of each instantiation and its LDS request.
+    ConvLaunch L, Lbest;
+    bool vec = false, vbest = false;
+    size_t lds = 0, lbest = 0;
+    long grid = 0, gbest = -1;
     int sel = -1;
     if (p.tile_hint > 0) {
         if (p.tile_hint > kNumTiles) return l2i_set_error(L2I_E_ARG, "conv2d: tile_hint out of range");
         sel = p.tile_hint - 1;
+        if (!plan_tile(p, kTiles[sel].wm, kTiles[sel].wn, Lbest, vbest, lbest, gbest))
+            return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d: requested tile cannot be staged for this problem");
     } else {
-        const int twl = ilog2_ceil(p.OW < 32 ? p.OW : 32);
-        const int TW = 1 << twl, RPT = 32 >> twl;
-        long best_blocks = -1;
-        for (int i = 0; i < 5; ++i) {       // preference order of kTiles[0..4]
-            const int BM = kTiles[i].wm * 32, TH = 4 * kTiles[i].wn * RPT;
-            if (BM > p.CoutP) continue;
-            const long blocks = (long)p.B * ((p.OH + TH - 1) / TH) * ((p.OW + TW - 1) / TW) * (p.CoutP / BM + (p.CoutP % BM ? 1 : 0));
-            if (blocks >= 512) { sel = i; break; }
-            if (blocks > best_blocks) { best_blocks = blocks; sel = i; }
+        static const int kOcc[5] = {1, 3, 3, 3, 4};           // waves per SIMD = blocks per CU allowed by VGPR+AGPR
+        double best_cost = 0.0;
+        for (int i = 0; i < 5; ++i) {
+            if (kTiles[i].wm * 32 > p.CoutP) continue;
+            if (!plan_tile(p, kTiles[i].wm, kTiles[i].wn, L, vec, lds, grid)) continue;
+            int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
+            if (per_cu > kOcc[i]) per_cu = kOcc[i];
+            if (per_cu < 1) per_cu = 1;
+            const long rounds = (grid + 255) / 256;                   // blocks each CU works through (all share its 4 matrix pipes)
+            const int nchunks = (p.Cin + L.CK - 1) / L.CK;
+            const double mfma = 64.0 * kTiles[i].wm * kTiles[i].wn * (double)nchunks * (L.CK / 2) * p.KH * p.KW;
+            const double ovh = 1500.0 * nchunks + 400.0 * kTiles[i].wm * kTiles[i].wn;     // barriers + commit, epilogue
+            const double cost = (double)rounds * (mfma + ovh / per_cu);                     // co-resident blocks hide each other's overhead
+            if (sel < 0 || cost < best_cost) { sel = i; best_cost = cost; Lbest = L; vbest = vec; lbest = lds; gbest = grid; }
         }
-        if (sel < 0) sel = 4;
+        if (sel < 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d: no tile configuration fits this problem");
     }
-    const int WM = kTiles[sel].wm, WN = kTiles[sel].wn, BM = WM * 32;
-
-    ConvLaunch L;
-    L.tw_log2 = ilog2_ceil(p.OW < 32 ? p.OW : 32);
-    const int TW = 1 << L.tw_log2, RPT = 32 >> L.tw_log2, TH = 4 * WN * RPT;
-    L.tiles_x = (p.OW + TW - 1) / TW;
-    L.tiles_y = (p.OH + TH - 1) / TH;
-    L.mblocks = (p.CoutP + BM - 1) / BM;
-    L.IH = (TH - 1) * p.stride + p.KH;
-    L.IW = (TW - 1) * p.stride + p.KW;
-    L.IWp = L.IW | 1;
-    L.plane = L.IH * L.IWp;
-    L.plane = (L.plane + 3) & ~3;           // keeps the weight region 16-B aligned for any even CK
-    const int KK = p.KH * p.KW;
-    const size_t per_c = (size_t)(L.plane + KK * BM) * sizeof(float);
-    int ck = (int)((48 * 1024) / per_c) & ~1;
-    if (ck < 2) ck = 2;
-    int cin_even = (p.Cin + 1) & ~1;
-    if (ck > cin_even) ck = cin_even;
-    if (ck > 64) ck = 64;
-    L.CK = ck;
-    const size_t lds = per_c * ck;
-    if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d: tile does not fit in LDS");
-    const long grid = (long)p.B * L.tiles_y * L.tiles_x * L.mblocks;
-    if (grid <= 0 || grid > 0x7fffffffL) return l2i_set_error(L2I_E_ARG, "conv2d: grid too large");
-
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
     switch (sel) {
-        case 0: e = launch_cfg<4, 2>(p, L, (int)grid, lds, st); break;
-        case 1: e = launch_cfg<2, 2>(p, L, (int)grid, lds, st); break;
-        case 2: e = launch_cfg<1, 4>(p, L, (int)grid, lds, st); break;
-        case 3: e = launch_cfg<2, 1>(p, L, (int)grid, lds, st); break;
-        case 4: e = launch_cfg<1, 1>(p, L, (int)grid, lds, st); break;
-        case 5: e = launch_cfg<1, 2>(p, L, (int)grid, lds, st); break;
-        default: e = launch_cfg<4, 1>(p, L, (int)grid, lds, st); break;
+        case 0: e = launch_cfg<4, 2>(p, Lbest, (int)gbest, lbest, vbest, st); break;
+        case 1: e = launch_cfg<2, 2>(p, Lbest, (int)gbest, lbest, vbest, st); break;
+        case 2: e = launch_cfg<1, 4>(p, Lbest, (int)gbest, lbest, vbest, st); break;
+        case 3: e = launch_cfg<2, 1>(p, Lbest, (int)gbest, lbest, vbest, st); break;
+        case 4: e = launch_cfg<1, 1>(p, Lbest, (int)gbest, lbest, vbest, st); break;
+        case 5: e = launch_cfg<1, 2>(p, Lbest, (int)gbest, lbest, vbest, st); break;
+        default: e = launch_cfg<4, 1>(p, Lbest, (int)gbest, lbest, vbest, st); break;
     }
     if (e != hipSuccess) return l2i_set_error(L2I_E_LAUNCH, hipGetErrorString(e));
     return L2I_OK;

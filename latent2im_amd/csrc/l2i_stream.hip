@@ -142,6 +142,81 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UfdParams p) {
     }
 }
 
+// Fast path for the hot case up = down = 1 with a 4x4 FIR (every Blur of the generator and discriminator, forward and
+// backward): one block = 32x64 outputs of one map; the 35x67 input footprint is staged once in LDS (coalesced rows),
+// each thread produces a 2x4 patch from a 5x7 register window (35 LDS dwords per 8 outputs), 16-byte stores.
+__global__ __launch_bounds__(256) void upfirdn2d_k4_kernel(const UfdParams p) {
+    constexpr int TH = 32, TW = 64, IH = TH + 3, IW = TW + 3, PITCH = 68;
+    __shared__ __attribute__((aligned(16))) float tile[IH * PITCH];
+    float kf[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) kf[t] = p.k[15 - t];                 // flipped taps (true convolution), wave-uniform
+    const int tiles_x = (p.out_w + TW - 1) / TW, tiles_y = (p.out_h + TH - 1) / TH;
+    const long long ntiles = p.major * tiles_x * tiles_y;
+    const int tx4 = (threadIdx.x & 15) * 4, ty2 = (threadIdx.x >> 4) * 2;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = (int)(t % tiles_x);
+        const int ty = (int)((t / tiles_x) % tiles_y);
+        const long long mj = t / ((long long)tiles_x * tiles_y);
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
+        const float* xin = p.x + mj * (long long)p.in_h * p.in_w;
+        __syncthreads();
+        for (int e = threadIdx.x; e < IH * IW; e += 256) {
+            const int r = e / IW, c = e - r * IW;
+            const int gy = iy0 + r, gx = ix0 + c;
+            float v = 0.f;
+            if (gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w) v = xin[(long long)gy * p.in_w + gx];
+            tile[r * PITCH + c] = v;
+        }
+        __syncthreads();
+        float win[5][7];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const float4 a = *reinterpret_cast<const float4*>(&tile[(ty2 + r) * PITCH + tx4]);
+            const float4 b = *reinterpret_cast<const float4*>(&tile[(ty2 + r) * PITCH + tx4 + 4]);
+            win[r][0] = a.x; win[r][1] = a.y; win[r][2] = a.z; win[r][3] = a.w; win[r][4] = b.x; win[r][5] = b.y; win[r][6] = b.z;
+        }
+        const int c = (int)(mj % p.channels);
+        const long long bsel = mj / p.channels;
+        const float bia = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int oy = oy0 + ty2 + r;
+            if (oy >= p.out_h) continue;
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) v += win[r + ky][q + kx] * kf[ky * 4 + kx];
+                o[q] = v + bia;
+            }
+            const int ox = ox0 + tx4;
+            const long long obase = (mj * p.out_h + oy) * p.out_w + ox;
+            const long long nbase = (bsel * p.out_h + oy) * p.out_w + ox;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (ox + q < p.out_w) {
+                    if (p.noise) o[q] += p.noise[nbase + q] * p.noise_w;
+                    if (p.addend) o[q] += p.addend[obase + q];
+                    if (p.act == L2I_ACT_LRELU) o[q] = (o[q] > 0.f ? o[q] : o[q] * p.slope) * p.gain;
+                    else if (p.act == L2I_ACT_RELU) o[q] = o[q] > 0.f ? o[q] : 0.f;
+                }
+            }
+            if (ox + 3 < p.out_w && ((obase & 3) == 0) && (((uintptr_t)p.y & 15) == 0)) {
+                *reinterpret_cast<float4*>(p.y + obase) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ox + q < p.out_w) p.y[obase + q] = o[q];
+            }
+        }
+    }
+}
+
 extern "C" int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw,
                                  int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                                  int channels, const float* noise, float noise_w, const float* bias, const float* addend,
@@ -158,6 +233,12 @@ extern "C" int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64
     if (p.out_h <= 0 || p.out_w <= 0) return l2i_set_error(L2I_E_ARG, "upfirdn2d: empty output");
     p.channels = channels > 0 ? channels : 1;
     p.noise = noise; p.noise_w = noise_w; p.bias = bias; p.addend = addend; p.act = act; p.slope = act_slope; p.gain = act_gain;
+    if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4) {
+        const long long nt = major * ((p.out_w + 63) / 64) * ((p.out_h + 31) / 32);
+        hipLaunchKernelGGL(upfirdn2d_k4_kernel, dim3(l2i_grid_for(nt, 1, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p);
+        L2I_CHECK_LAUNCH();
+        return L2I_OK;
+    }
     const long long ntiles = major * ((p.out_w + 63) / 64) * ((p.out_h + 15) / 16);
     hipLaunchKernelGGL(upfirdn2d_kernel, dim3(l2i_grid_for(ntiles, 1, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p);
     L2I_CHECK_LAUNCH();
