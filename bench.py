@@ -112,8 +112,8 @@ def main():
     value = global_b * a.steps / elapsed
     roof = None
     if prof:
-        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
-        tot_flop = sum(f for _, _, f in prof)
+        tot_ms = sum(q[0].elapsed_time(q[1]) for q in prof)
+        tot_flop = sum(q[2] for q in prof)
         ach = tot_flop / (tot_ms * 1e-3) / 1e12
         roof = dict(bound='mfma', kernel='conv_mfma_kernel (l2i_conv2d_f32)', achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
                     unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,

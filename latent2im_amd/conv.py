@@ -120,7 +120,8 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         e0.record()
         _lib.check(lib.l2i_conv2d_f32(p, _lib.stream_ptr()), 'l2i_conv2d_f32')
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * B * L.cout * cin * L.kh * L.kw * OH * OW))
+        PROFILE.append((e0, e1, 2.0 * B * L.cout * cin * L.kh * L.kw * OH * OW,
+                        (B, cin, L.cout, L.kh, L.kw, L.stride, H, W, OH, OW, L.step, in_mask is not None, in_scale is not None)))
         return
     _lib.check(lib.l2i_conv2d_f32(p, _lib.stream_ptr()), 'l2i_conv2d_f32')
 

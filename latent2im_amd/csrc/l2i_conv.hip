@@ -41,6 +41,7 @@ struct ConvLaunch {
     unsigned magic_iw, magic_rc, magic_ih;   // ceil(2^32/d) for d = IW, rows_c, IH
     int in_elems;                      // CK*rows_c*IW   (VEC: in float4 units)
     int w_vec;                         // CK*KK*BM/4
+    int vec_epi;                       // 1: LDS-transposed epilogue with 16-byte global accesses
 };
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic) { return __umulhi(n, magic); }
@@ -49,7 +50,7 @@ template <int BM> struct WSlots { static constexpr int value = (BM == 128) ? 10 
 
 // NIN: input slots per thread per chunk (floats, or float4 when VEC); NWV: weight float4 slots per thread per chunk
 template <int WM, int WN, bool VEC, bool MASK>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const l2i_conv_params p, const ConvLaunch L) {
+__global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : 1) void conv_mfma_kernel(const l2i_conv_params p, const ConvLaunch L) {
     constexpr int BM = WM * 32;
     constexpr int NIN = VEC ? 4 : 12;
     constexpr int NWV = WSlots<BM>::value;
@@ -231,8 +232,83 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const l2i_conv_params p,
         __syncthreads();        // every wave is done reading this chunk's fragments
     }
 
-    // ---- epilogue: demod / mask / noise / bias / residual / activation; 128-B row segments per register ----
+    // ---- epilogue A (wide): accumulators -> per-wave LDS transpose -> 16-byte loads/stores.  In the MFMA layout a
+    //      lane owns ONE pixel of 16 channels, so direct stores are 4 B per lane and the store path (not HBM) bounds
+    //      low-K layers; after the transpose a lane owns 4 consecutive pixels of one channel: 4x fewer, 4x wider
+    //      global instructions for y, residual, masks and noise alike.
     const size_t plane_o = (size_t)p.OHf * p.OWf;
+    if (L.vec_epi) {
+        float* reg = smem + wave * (32 * 64);           // [32 channels][64 pixels] of this wave; the K loop is done
+        const int ch_l = lane >> 4;                     // channel row within a group of 4
+        const int px = (lane & 15) * 4;                 // first of this lane's 4 pixels inside the 64-pixel strip
+#pragma unroll
+        for (int n0 = 0; n0 < WN; n0 += 2) {
+            const int nn = px >> 5;
+            const int pi = (wave * WN + n0 + nn) * 32 + (px & 31);
+            const int ox = ox0 + (pi & (TW - 1));
+            const int oy = oy0 + ((pi >> L.tw_log2) & (TH - 1));
+            const int bb = b0 + (pi >> (L.tw_log2 + L.th_log2));
+            const bool pok = (n0 + nn < WN) && (oy < p.OH) && (ox < p.OW) && (bb < p.B);
+            const size_t poff = (size_t)(oy + p.oy_off) * p.OWf + ox + p.ox_off;
+            float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pok && p.noise) {
+                nz = *reinterpret_cast<const float4*>(p.noise + (size_t)bb * plane_o + poff);
+                nz.x *= p.noise_w; nz.y *= p.noise_w; nz.z *= p.noise_w; nz.w *= p.noise_w;
+            }
+            const float* osc = (pok && p.out_scale) ? p.out_scale + (size_t)bb * p.Cout : nullptr;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (n0 + q < WN) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            reg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + q * 32 + j] = acc[m][(n0 + q) < WN ? (n0 + q) : 0][r];
+                    }
+                }
+#pragma unroll 2
+                for (int i = 0; i < 8; ++i) {
+                    const int ch = i * 4 + ch_l;
+                    const int co = m0 + m * 32 + ch;
+                    const float4 t = *reinterpret_cast<const float4*>(&reg[ch * 64 + px]);
+                    if (pok && co < p.Cout) {
+                        float4 v = t;
+                        if (osc) { const float sc = osc[co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+                        const size_t oidx = ((size_t)bb * p.Cout + co) * plane_o + poff;
+                        if (p.out_mask) {
+                            const float4 mk = *reinterpret_cast<const float4*>(p.out_mask + oidx);
+                            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                        }
+                        v.x += nz.x; v.y += nz.y; v.z += nz.z; v.w += nz.w;
+                        if (p.bias) { const float bv = p.bias[co]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
+                        if (p.residual) {
+                            float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
+                            if (p.res_mask) {
+                                const float4 mk = *reinterpret_cast<const float4*>(p.res_mask + oidx);
+                                rv.x = mk.x > 0.f ? rv.x : 0.f; rv.y = mk.y > 0.f ? rv.y : 0.f; rv.z = mk.z > 0.f ? rv.z : 0.f; rv.w = mk.w > 0.f ? rv.w : 0.f;
+                            }
+                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        }
+                        if (p.act == L2I_ACT_LRELU) {
+                            v.x = (v.x > 0.f ? v.x : v.x * p.act_slope) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.act_slope) * p.act_gain;
+                            v.z = (v.z > 0.f ? v.z : v.z * p.act_slope) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.act_slope) * p.act_gain;
+                        } else if (p.act == L2I_ACT_RELU) {
+                            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                        }
+                        v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain;
+                        if (p.accumulate) {
+                            const float4 o = *reinterpret_cast<const float4*>(p.y + oidx);
+                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                        }
+                        *reinterpret_cast<float4*>(p.y + oidx) = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- epilogue B (scalar): strided phase outputs, odd widths, unaligned tensors ----
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
         const int pi = (wave * WN + n) * 32 + j;
@@ -343,6 +419,10 @@ static bool plan_tile(const l2i_conv_params& p, int wm, int wn, ConvLaunch& L, b
     L.magic_rc = magic_for((unsigned)L.rows_c);
     L.magic_ih = magic_for((unsigned)L.IH);
     lds = per_c * ck + (size_t)(ck << L.tb_log2) * sizeof(float);
+    auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
+    L.vec_epi = (p.ox_step == 1 && p.oy_step == 1 && (p.OWf % 4) == 0 && (p.OW % 4) == 0 && (p.ox_off % 4) == 0 && L.tw_log2 >= 2 &&
+                 al16(p.y) && al16(p.residual) && al16(p.res_mask) && al16(p.out_mask) && al16(p.noise)) ? 1 : 0;
+    if (L.vec_epi && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);      // 8 KiB transpose strip per wave
     grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks;
     return lds <= 64 * 1024 && grid > 0 && grid <= 0x7fffffffL;
 }
