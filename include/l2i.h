@@ -78,6 +78,16 @@ typedef struct l2i_conv_params {
 
 int l2i_conv2d_f32(const l2i_conv_params* p, void* stream);
 
+/* Stride-2 TRANSPOSED convolution, all four output parities in one launch:
+ *   y[b,co,2*iy+ky-pad,2*ix+kx-pad] += x[b,ci,iy,ix] * w[co,ci,ky,kx]          (F.conv_transpose2d(stride=2) of the up
+ *   layers, networks.py:246-255, and the input-gradient of every stride-2 conv of the path).
+ * Same struct as l2i_conv2d_f32 with KH = KW = K, pad_y = pad_x = pad, y = [B,Cout,OHf,OWf] of the natural size
+ * (H-1)*2-2*pad+K (or one more); `w` is the FUSED pack [Cin][K*K][CoutP] whose tap order is the kernel's walk order
+ * (latent2im_amd/conv.py:fused_transposed_taps).  Fused: in_scale, in_mask, out_scale, out_gain; everything else must
+ * be unset.  Built for (K,pad) in {(3,0),(3,1),(7,3)}; other shapes return L2I_E_UNSUPPORTED (use the per-parity
+ * l2i_conv2d_f32 calls). */
+int l2i_conv_transpose2d_f32(const l2i_conv_params* p, void* stream);
+
 /* out[i] = act_grad_table(x[i] + b[(i / step_b) % size_b], ref[i]) * scale   — the reference op, all six
  * act*10+grad cases (fused_bias_act_kernel.cu:36-47).  b / ref may be NULL (= the reference's empty tensors). */
 int l2i_fused_bias_act_f32(float* y, const float* x, const float* b, const float* ref, int64_t n,

@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvParams  # noqa: F401
 
 
+USE_FUSED_TRANSPOSED = True     # False: issue stride-2 transposed convs as four per-parity launches
 PROFILE = None      # bench.py sets this to a list: every launch then appends (start_event, end_event, algorithmic_flops)
 
 
@@ -78,6 +79,82 @@ def transposed_plan(w_oihw, pad):
             sub = w[:, :, ty, :][:, :, :, tx].contiguous()
             plan.append(Launch(sub, 1, pad_y, pad_x, step=2, off_y=py, off_x=px))
     return plan
+
+
+FUSED_TRANSPOSED_SHAPES = ((3, 0), (3, 1), (7, 3))        # (K, pad) instantiated in csrc/l2i_convt.hip
+_FUSED_KW = {'in_scale', 'in_mask', 'mask', 'out_scale', 'out_gain', 'tile_hint'}
+
+
+def _tr_geom(K, pad):
+    k0 = [(pi + pad) % 2 for pi in (0, 1)]
+    A = [(K - k0[pi] + 1) // 2 for pi in (0, 1)]
+    d = [(pi + pad - k0[pi]) // 2 for pi in (0, 1)]
+    cp = [A[pi] - 1 - d[pi] for pi in (0, 1)]
+    P = max(cp)
+    Q = max(A[pi] - 1 - cp[pi] for pi in (0, 1))
+    return k0, A, cp, P, Q
+
+
+def fused_transposed_taps(K, pad):
+    """[(ky, kx)] in the order the fused kernel walks the taps: for dy, dx (input offsets) / for py, px (output parities)."""
+    k0, A, cp, P, Q = _tr_geom(K, pad)
+    taps = []
+    for dy in range(-P, Q + 1):
+        for dx in range(-P, Q + 1):
+            for py in (0, 1):
+                for px in (0, 1):
+                    ay, ax = dy + cp[py], dx + cp[px]
+                    if 0 <= ay < A[py] and 0 <= ax < A[px]:
+                        taps.append((k0[py] + 2 * (A[py] - 1 - ay), k0[px] + 2 * (A[px] - 1 - ax)))
+    assert len(taps) == K * K and len(set(taps)) == K * K
+    return taps
+
+
+class FusedTransposed:
+    """One-launch stride-2 transposed conv (l2i_conv_transpose2d_f32): weights packed in the kernel's tap order."""
+    __slots__ = ('w', 'cin', 'cout', 'k', 'pad')
+
+    def __init__(self, w_oihw, pad):
+        w = torch.as_tensor(w_oihw, dtype=torch.float32)
+        self.cout, self.cin, self.k, _ = w.shape
+        self.pad = pad
+        taps = fused_transposed_taps(self.k, pad)
+        sel = torch.stack([w[:, :, ky, kx] for ky, kx in taps], 2)               # [Cout, Cin, K*K]
+        self.w = pack_weight(sel.reshape(self.cout, self.cin, self.k * self.k, 1))
+
+    def to(self, device):
+        self.w = self.w.to(device)
+        return self
+
+
+def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), out_scale=None, out_gain=1.0, tile_hint=0):
+    lib = _lib.load()
+    B, cin, H, W = x.shape
+    assert cin == F.cin and y.shape[0] == B and y.shape[1] == F.cout
+    p = ConvParams()
+    p.x, p.w, p.y = _lib.fptr(x), _lib.fptr(F.w), _lib.fptr(y)
+    p.B, p.Cin, p.H, p.W, p.Cout, p.CoutP = B, cin, H, W, F.cout, F.w.shape[2]
+    p.KH = p.KW = F.k
+    p.stride, p.pad_y, p.pad_x = 2, F.pad, F.pad
+    p.OHf, p.OWf = y.shape[2], y.shape[3]
+    p.OH, p.OW = (p.OHf + 1) // 2, (p.OWf + 1) // 2
+    p.oy_step = p.ox_step = 2
+    p.in_scale, p.in_mask = _lib.fptr(in_scale), _lib.fptr(in_mask)
+    p.mask_pos, p.mask_neg = mask
+    p.out_scale = _lib.fptr(out_scale)
+    p.act_gain, p.out_gain = 1.0, out_gain
+    if in_mask is not None:
+        assert in_mask.shape == x.shape
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.l2i_conv_transpose2d_f32(p, _lib.stream_ptr()), 'l2i_conv_transpose2d_f32')
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * B * F.cout * cin * F.k * F.k * H * W,
+                        (B, cin, F.cout, F.k, F.k, 2, H, W, int(p.OHf), int(p.OWf), 2, in_mask is not None, in_scale is not None)))
+        return y
+    _lib.check(lib.l2i_conv_transpose2d_f32(p, _lib.stream_ptr()), 'l2i_conv_transpose2d_f32')
+    return y
 
 
 def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0), out_scale=None, noise=None,
@@ -147,10 +224,14 @@ class FrozenConv2d:
         self.cout, self.cin, self.k, _ = w.shape
         self.stride, self.padding, self.transposed = stride, padding, transposed
         wt = w.transpose(0, 1).contiguous()                       # [Cin, Cout, K, K]: roles swapped for the gradient
+        self.fwd_fused = self.bwd_fused = None
+        fusable = (self.k, padding) in FUSED_TRANSPOSED_SHAPES
         if transposed:
             assert stride == 2
             self.fwd = transposed_plan(w, padding)
             self.bwd = correlation_plan(wt, 2, padding)           # dx[ci,i] = sum gy[co, 2i+k-pad] w[co,ci,k]
+            if fusable:
+                self.fwd_fused = FusedTransposed(w, padding).to(device)
         else:
             self.fwd = correlation_plan(w, stride, padding)
             if stride == 1:
@@ -158,6 +239,8 @@ class FrozenConv2d:
             else:
                 assert stride == 2
                 self.bwd = transposed_plan(wt, padding)           # dx[ci, 2o+k-pad] += gy[co,o] w[co,ci,k]
+                if fusable:
+                    self.bwd_fused = FusedTransposed(wt, padding).to(device)
         for L in self.fwd + self.bwd:
             if L is not None:
                 L.to(device)
@@ -171,10 +254,14 @@ class FrozenConv2d:
         oh, ow = self.out_hw(x.shape[2], x.shape[3])
         if out is None:
             out = torch.empty(x.shape[0], self.cout, oh, ow, device=x.device, dtype=torch.float32)
+        if self.fwd_fused is not None and USE_FUSED_TRANSPOSED and set(kw) <= _FUSED_KW:
+            return run_fused_transposed(self.fwd_fused, x, out, **kw)
         return run_plan(self.fwd, x, out, **kw)
 
     def dgrad(self, gy, in_hw, out=None, **kw):
         """Gradient w.r.t. the input of ``forward`` given the gradient ``gy`` w.r.t. its (pre-epilogue) output."""
         if out is None:
             out = torch.empty(gy.shape[0], self.cin, in_hw[0], in_hw[1], device=gy.device, dtype=torch.float32)
+        if self.bwd_fused is not None and USE_FUSED_TRANSPOSED and set(kw) <= _FUSED_KW:
+            return run_fused_transposed(self.bwd_fused, gy, out, **kw)
         return run_plan(self.bwd, gy, out, **kw)

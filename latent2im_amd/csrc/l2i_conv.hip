@@ -42,6 +42,8 @@ struct ConvLaunch {
     int in_elems;                      // CK*rows_c*IW   (VEC: in float4 units)
     int w_vec;                         // CK*KK*BM/4
     int vec_epi;                       // 1: LDS-transposed epilogue with 16-byte global accesses
+    int lstride, gstep;                // LDS-coordinate stride of the fragment reads / global step between staged elements
+                                       // (stride-2 1x1 convs gather only the pixels they use: lstride 1, gstep 2)
 };
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic) { return __umulhi(n, magic); }
@@ -52,7 +54,7 @@ template <int BM> struct WSlots { static constexpr int value = (BM == 128) ? 10 
 template <int WM, int WN, bool VEC, bool MASK>
 __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : 1) void conv_mfma_kernel(const l2i_conv_params p, const ConvLaunch L) {
     constexpr int BM = WM * 32;
-    constexpr int NIN = VEC ? 4 : 12;
+    constexpr int NIN = VEC ? (MASK ? 4 : 8) : 12;
     constexpr int NWV = WSlots<BM>::value;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lds_in = smem;                               // [CK][TB][IH][IWp]
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : 1) void conv_mfma_kernel(
         const int c = pi & (TW - 1);
         const int r = (pi >> L.tw_log2) & (TH - 1);
         const int tb = pi >> (L.tw_log2 + L.th_log2);
-        pixoff[n] = tb * L.planeS + (r * p.stride) * L.IWp + c * p.stride + half * CKh * L.plane;
+        pixoff[n] = tb * L.planeS + (r * L.lstride) * L.IWp + c * L.lstride + half * CKh * L.plane;
     }
     const int wlane = half * CKh * KK * BM + j;
 
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : 1) void conv_mfma_kernel(
             const unsigned r2 = row - c * L.rows_c;
             const unsigned tb = fast_div(r2, L.magic_ih);
             const int iy = (int)(r2 - tb * L.IH);
-            const int gy = iy0 + iy;
-            const int gx = ix0 + (int)(VEC ? ixu * 4 : ixu);
+            const int gy = iy0 + iy * L.gstep;
+            const int gx = ix0 + (int)(VEC ? ixu * 4 : ixu) * L.gstep;
             loff[u] = (int)(c * L.plane + tb * L.planeS + iy * L.IWp + (VEC ? ixu * 4 : ixu));
             if ((int)tb < nb && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
                 voff[u] = (unsigned)((((size_t)tb * p.Cin + c) * plane_x + (size_t)gy * p.W + gx) * sizeof(float));
@@ -391,8 +393,11 @@ static bool plan_tile(const l2i_conv_params& p, int wm, int wn, ConvLaunch& L, b
     L.tiles_y = (p.OH + TH - 1) / TH;
     L.bgroups = (p.B + TB - 1) / TB;
     L.mblocks = (p.CoutP + BM - 1) / BM;
-    L.IH = (TH - 1) * p.stride + p.KH;
-    L.IW = (TW - 1) * p.stride + p.KW;
+    const bool gather = (p.KH == 1 && p.KW == 1 && p.stride == 2);
+    L.lstride = gather ? 1 : p.stride;
+    L.gstep = gather ? 2 : 1;
+    L.IH = (TH - 1) * L.lstride + p.KH;
+    L.IW = (TW - 1) * L.lstride + p.KW;
     vec = (p.KW == 1 && p.KH == 1 && p.stride == 1 && p.pad_x == 0 && p.pad_y == 0 && (p.W % 4) == 0 && TW >= 4 &&
            (((uintptr_t)p.x) % 16) == 0 && (!p.in_mask || (((uintptr_t)p.in_mask) % 16) == 0));
     L.IWp = vec ? L.IW : (L.IW | 1);
@@ -404,7 +409,7 @@ static bool plan_tile(const l2i_conv_params& p, int wm, int wn, ConvLaunch& L, b
     const size_t per_c = (size_t)(L.plane + KK * BM) * sizeof(float);
     int ck = (int)((48 * 1024) / per_c);
     const int in_per_c = vec ? (L.rows_c * (L.IW / 4)) : (L.rows_c * L.IW);
-    const int ck_in = ((vec ? 4 : 12) * 256) / in_per_c;
+    const int ck_in = ((vec ? (p.in_mask ? 4 : 8) : 12) * 256) / in_per_c;
     const int ck_w = (nwv * 256) / (KK * BM / 4);
     if (ck > ck_in) ck = ck_in;
     if (ck > ck_w) ck = ck_w;

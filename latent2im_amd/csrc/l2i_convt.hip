@@ -1,0 +1,315 @@
+// l2i_convt.hip — stride-2 TRANSPOSED convolution with all four output parities in one launch (gfx950, fp32 MFMA).
+//
+//   y[b, co, 2*iy + ky - pad, 2*ix + kx - pad] += x[b, ci, iy, ix] * w[co, ci, ky, kx]
+//
+// Used for the forward of the StyleGAN2 up layers (conv_transpose2d(stride 2), reference networks.py:246-255) and for
+// the input-gradient of every stride-2 convolution on the path (discriminator conv2 of each ResBlock, ResNet-50
+// layer{2,3,4}.0.conv2, the 7x7 stem).  A transposed conv is four interleaved stride-1 correlations (one per output
+// parity) over the SAME input tile; issuing them as separate launches (l2i_conv2d_f32 with oy_step = 2) stages the tile
+// four times, gives each launch only 1-4 taps of matrix work per staged chunk, and writes every other output pixel.
+// Here one block keeps 4 accumulator sets (one per parity), walks all K*K taps per staged chunk (each tap feeds
+// exactly one parity: same MAC count as the dense form), and writes whole contiguous output rows: the two x-parities
+// are interleaved through a per-wave LDS transpose and stored 16 bytes per lane.
+//
+// Block = 256 threads = 4 waves along N; block tile = 32 output channels x (4*WN*32) INPUT-resolution positions t;
+// staging pipeline identical to l2i_conv.hip (buffer loads issued one chunk ahead, committed to LDS after the MFMAs).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "l2i.h"
+#include "l2i_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvTLaunch {
+    int tw_log2, th_log2, tb_log2;
+    int tiles_x, tiles_y, bgroups, mblocks;
+    int CK, IH, IW, IWp, planeS, plane, rows_c;
+    unsigned magic_iw, magic_rc, magic_ih;
+    int in_elems, w_vec;
+};
+
+__device__ __forceinline__ unsigned fast_div_t(unsigned n, unsigned magic) { return __umulhi(n, magic); }
+
+template <int K, int PAD> struct TrGeom {
+    static constexpr int k0(int pi) { return (pi + PAD) % 2; }
+    static constexpr int A(int pi) { return (K - k0(pi) + 1) / 2; }              // taps of parity pi
+    static constexpr int d(int pi) { return (pi + PAD - k0(pi)) / 2; }
+    static constexpr int pad(int pi) { return A(pi) - 1 - d(pi); }                // correlation padding of parity pi
+    static constexpr int P = pad(0) > pad(1) ? pad(0) : pad(1);                   // halo before the tile
+    static constexpr int q_(int pi) { return A(pi) - 1 - pad(pi); }
+    static constexpr int Q = q_(0) > q_(1) ? q_(0) : q_(1);                       // halo after the tile
+};
+
+template <int K, int PAD, int WN, bool MASK>
+__global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p, const ConvTLaunch L) {
+    using G = TrGeom<K, PAD>;
+    constexpr int BM = 32, KK = K * K, NIN = 12, NWV = 4, P = G::P, Q = G::Q;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds_in = smem;
+    float* lds_w = smem + L.CK * L.plane;
+    float* lds_sc = lds_w + L.CK * KK * BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const int TW = 1 << L.tw_log2, TH = 1 << L.th_log2;
+    int bid = blockIdx.x;
+    const int mblk = bid % L.mblocks; bid /= L.mblocks;
+    const int tx = bid % L.tiles_x; bid /= L.tiles_x;
+    const int ty = bid % L.tiles_y; bid /= L.tiles_y;
+    const int b0 = bid << L.tb_log2;
+    const int m0 = mblk * BM;
+    const int ty0 = ty << L.th_log2, tx0 = tx << L.tw_log2;        // tile origin in input-resolution positions t
+    const int iy0 = ty0 - P, ix0 = tx0 - P;                        // origin of the staged tile
+
+    const int CKh = L.CK >> 1;
+    int pixoff[WN], sbase[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int pi = (wave * WN + n) * 32 + j;
+        const int c = pi & (TW - 1), r = (pi >> L.tw_log2) & (TH - 1), tb = pi >> (L.tw_log2 + L.th_log2);
+        pixoff[n] = tb * L.planeS + r * L.IWp + c + half * CKh * L.plane;
+        sbase[n] = tb * L.CK + half * CKh;
+    }
+    const int wlane = half * CKh * KK * BM + j;
+
+    f32x16 acc[4][WN];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][n][r] = 0.f;
+
+    // ---- staging state (see l2i_conv.hip) ----
+    const size_t plane_x = (size_t)p.H * p.W;
+    const int nb = (p.B - b0) < (1 << L.tb_log2) ? (p.B - b0) : (1 << L.tb_log2);
+    const unsigned in_bytes = (unsigned)((size_t)nb * p.Cin * plane_x * sizeof(float));
+    const size_t grp_off = (size_t)b0 * p.Cin * plane_x;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + grp_off), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)((MASK ? p.in_mask : p.x) + grp_off), 0, in_bytes, 0x00020000);
+    const unsigned w_bytes = (unsigned)((size_t)p.Cin * KK * p.CoutP * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, w_bytes, 0x00020000);
+    const unsigned sc_bytes = (unsigned)((size_t)nb * p.Cin * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((p.in_scale ? p.in_scale : p.x) + (size_t)b0 * p.Cin), 0, p.in_scale ? sc_bytes : 0u, 0x00020000);
+
+    unsigned rin[NIN], rmk[MASK ? NIN : 1], voff[NIN];
+    int loff[NIN];
+    u32x4 rw[NWV];
+    unsigned rsc = 0;
+#pragma unroll
+    for (int u = 0; u < NIN; ++u) {
+        const unsigned e = tid + u * 256;
+        voff[u] = in_bytes;
+        loff[u] = -1;
+        if ((int)e < L.in_elems) {
+            const unsigned row = fast_div_t(e, L.magic_iw), ixu = e - row * L.IW;
+            const unsigned c = fast_div_t(row, L.magic_rc);
+            const unsigned r2 = row - c * L.rows_c;
+            const unsigned tb = fast_div_t(r2, L.magic_ih);
+            const int iy = (int)(r2 - tb * L.IH);
+            const int gy = iy0 + iy, gx = ix0 + (int)ixu;
+            loff[u] = (int)(c * L.plane + tb * L.planeS + iy * L.IWp + ixu);
+            if ((int)tb < nb && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                voff[u] = (unsigned)((((size_t)tb * p.Cin + c) * plane_x + (size_t)gy * p.W + gx) * sizeof(float));
+        }
+    }
+    constexpr int V = BM / 4;
+    const int wrow0 = tid / V, wc4 = tid - wrow0 * V;
+    const unsigned wvoff = (m0 + wc4 * 4 < p.CoutP) ? (unsigned)(((size_t)wrow0 * p.CoutP + m0 + wc4 * 4) * sizeof(float)) : w_bytes;
+    const unsigned wstep = (unsigned)((256 / V) * p.CoutP * sizeof(float));
+    const int TBCK = L.CK << L.tb_log2;
+    const unsigned scoff = (tid < TBCK) ? (unsigned)((((tid / L.CK) * p.Cin) + (tid % L.CK)) * sizeof(float)) : sc_bytes;
+
+    auto issue = [&](int c0) {
+        const unsigned so = (unsigned)((size_t)c0 * plane_x * sizeof(float));
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) {
+            rin[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff[u], so, 0);
+            if constexpr (MASK) rmk[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, voff[u], so, 0);
+        }
+        const unsigned sw = (unsigned)((size_t)c0 * KK * p.CoutP * sizeof(float));
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) rw[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff, sw + u * wstep, 0);
+        rsc = __builtin_amdgcn_raw_buffer_load_b32(rs_s, scoff, (unsigned)(c0 * sizeof(float)), 0);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) {
+            if (loff[u] >= 0) {
+                float v = __uint_as_float(rin[u]);
+                if constexpr (MASK) v *= (__uint_as_float(rmk[u]) > 0.f) ? p.mask_pos : p.mask_neg;
+                lds_in[loff[u]] = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) {
+            const int idx = tid + u * 256;
+            if (idx < L.w_vec) reinterpret_cast<u32x4*>(lds_w)[idx] = rw[u];
+        }
+        if (tid < TBCK) lds_sc[tid] = p.in_scale ? __uint_as_float(rsc) : 1.f;
+    };
+
+    issue(0);
+    for (int c0 = 0; c0 < p.Cin; c0 += L.CK) {
+        commit();
+        __syncthreads();
+        if (c0 + L.CK < p.Cin) issue(c0 + L.CK);
+        for (int cc = 0; cc < CKh; ++cc) {
+            const float* wr = lds_w + wlane + cc * KK * BM;
+            const float* ir = lds_in + cc * L.plane;
+            float sv[WN];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) sv[n] = lds_sc[sbase[n] + cc];
+            int slot = 0;                                   // compile-time after full unrolling
+#pragma unroll
+            for (int dy = -P; dy <= Q; ++dy) {
+#pragma unroll
+                for (int dx = -P; dx <= Q; ++dx) {
+                    float bfr[WN];
+                    const int toff = (dy + P) * L.IWp + (dx + P);
+#pragma unroll
+                    for (int n = 0; n < WN; ++n) bfr[n] = ir[pixoff[n] + toff] * sv[n];
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+#pragma unroll
+                        for (int px = 0; px < 2; ++px) {
+                            const int ay = dy + G::pad(py), ax = dx + G::pad(px);
+                            if (ay >= 0 && ay < G::A(py) && ax >= 0 && ax < G::A(px)) {
+                                const float a = wr[slot * BM];
+#pragma unroll
+                                for (int n = 0; n < WN; ++n)
+                                    acc[py * 2 + px][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr[n], acc[py * 2 + px][n], 0, 0, 0);
+                                ++slot;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: interleave the two x-parities through a per-wave LDS strip, write whole output rows ----
+    const size_t plane_o = (size_t)p.OHf * p.OWf;
+    float* strip = smem + wave * (32 * 64);                 // [32 channels][64 consecutive output pixels]
+    const int ch_l = lane >> 4, q4 = lane & 15;
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const int pi = (wave * WN + n) * 32 + 2 * q4;      // input-resolution position of this lane's 4 outputs
+        const int tcol = tx0 + (pi & (TW - 1));
+        const int trow = ty0 + ((pi >> L.tw_log2) & (TH - 1));
+        const int bb = b0 + (pi >> (L.tw_log2 + L.th_log2));
+        const int ox = 2 * tcol;
+        const float* osc = (bb < p.B && p.out_scale) ? p.out_scale + (size_t)bb * p.Cout : nullptr;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
+                strip[ch * 64 + 2 * j] = acc[py * 2][n][r];
+                strip[ch * 64 + 2 * j + 1] = acc[py * 2 + 1][n][r];
+            }
+            const int oy = 2 * trow + py;
+            const bool rowok = (bb < p.B) && (oy < p.OHf);
+            const size_t poff = (size_t)oy * p.OWf + ox;
+#pragma unroll 2
+            for (int i = 0; i < 8; ++i) {
+                const int ch = i * 4 + ch_l;
+                const int co = m0 + ch;
+                float4 v = *reinterpret_cast<const float4*>(&strip[ch * 64 + 4 * q4]);
+                if (rowok && co < p.Cout && ox < p.OWf) {
+                    float sc = p.out_gain;
+                    if (osc) sc *= osc[co];
+                    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                    float* dst = p.y + ((size_t)bb * p.Cout + co) * plane_o + poff;
+                    if (ox + 3 < p.OWf) {
+                        *reinterpret_cast<float4*>(dst) = v;                 // 4-byte aligned is enough on gfx950 (probed)
+                    } else {
+                        dst[0] = v.x;
+                        if (ox + 1 < p.OWf) dst[1] = v.y;
+                        if (ox + 2 < p.OWf) dst[2] = v.z;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static int ilog2c(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static unsigned magic_of(unsigned d) { return (unsigned)((0x100000000ULL + d - 1) / d); }
+
+template <int K, int PAD, int WN>
+static int launch_convt(const l2i_conv_params& p, hipStream_t st) {
+    using G = TrGeom<K, PAD>;
+    constexpr int BM = 32, BN = 128 * WN, KK = K * K;
+    ConvTLaunch L;
+    const int Ty = (p.OHf + 1) / 2, Tx = (p.OWf + 1) / 2;       // input-resolution positions that own an output
+    L.tw_log2 = ilog2c(Tx < 32 ? Tx : 32);
+    const int TW = 1 << L.tw_log2;
+    int th = BN / TW;
+    const int ty_p2 = 1 << ilog2c(Ty);
+    if (th > ty_p2) th = ty_p2;
+    L.th_log2 = ilog2c(th);
+    const int TH = 1 << L.th_log2;
+    L.tb_log2 = ilog2c(BN / (TH * TW));
+    const int TB = 1 << L.tb_log2;
+    if ((size_t)TB * p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: sample group >= 4 GiB");
+    L.tiles_x = (Tx + TW - 1) / TW;
+    L.tiles_y = (Ty + TH - 1) / TH;
+    L.bgroups = (p.B + TB - 1) / TB;
+    L.mblocks = (p.CoutP + BM - 1) / BM;
+    L.IH = TH + G::P + G::Q;
+    L.IW = TW + G::P + G::Q;
+    L.IWp = L.IW | 1;
+    L.planeS = L.IH * L.IWp;
+    L.plane = (TB * L.planeS + 3) & ~3;
+    L.rows_c = TB * L.IH;
+    const size_t per_c = (size_t)(L.plane + KK * BM) * sizeof(float);
+    int ck = (int)((48 * 1024) / per_c);
+    const int ck_in = (12 * 256) / (L.rows_c * L.IW);
+    const int ck_w = (4 * 256) / (KK * BM / 4);
+    if (ck > ck_in) ck = ck_in;
+    if (ck > ck_w) ck = ck_w;
+    ck &= ~1;
+    if (ck < 2) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: tile cannot be staged");
+    const int cin_even = (p.Cin + 1) & ~1;
+    if (ck > cin_even) ck = cin_even;
+    L.CK = ck;
+    L.in_elems = ck * L.rows_c * L.IW;
+    L.w_vec = ck * KK * BM / 4;
+    L.magic_iw = magic_of((unsigned)L.IW);
+    L.magic_rc = magic_of((unsigned)L.rows_c);
+    L.magic_ih = magic_of((unsigned)L.IH);
+    size_t lds = per_c * ck + (size_t)(ck << L.tb_log2) * sizeof(float);
+    if (lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
+    const long grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks;
+    if (grid <= 0 || grid > 0x7fffffffL) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: grid too large");
+    if (p.in_mask) hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, true>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
+    else hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, false>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+extern "C" int l2i_conv_transpose2d_f32(const l2i_conv_params* pp, void* stream) {
+    if (!pp) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: null params");
+    const l2i_conv_params& p = *pp;
+    if (!p.x || !p.w || !p.y) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: null tensor");
+    if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: non-positive dimension");
+    if (p.KH != p.KW || p.pad_y != p.pad_x) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: square kernels / symmetric padding only");
+    if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: CoutP must be Cout rounded up to 32");
+    const int full_h = (p.H - 1) * 2 - 2 * p.pad_y + p.KH, full_w = (p.W - 1) * 2 - 2 * p.pad_x + p.KW;
+    if (p.OHf < full_h || p.OWf < full_w || p.OHf > full_h + 1 || p.OWf > full_w + 1)
+        return l2i_set_error(L2I_E_ARG, "conv_transpose2d: output must be the natural size (or one larger: output_padding)");
+    if (p.bias || p.noise || p.residual || p.res_mask || p.out_mask || p.act != L2I_ACT_NONE || p.accumulate)
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: only in_scale / in_mask / out_scale / out_gain are fused here");
+    if ((((uintptr_t)p.w) % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: packed weights must be 16-byte aligned");
+    if ((size_t)p.Cin * p.KH * p.KW * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: weight pack >= 4 GiB");
+    hipStream_t st = (hipStream_t)stream;
+    if (p.KH == 3 && p.pad_y == 0) return launch_convt<3, 0, 2>(p, st);
+    if (p.KH == 3 && p.pad_y == 1) return launch_convt<3, 1, 2>(p, st);
+    if (p.KH == 7 && p.pad_y == 3) return launch_convt<7, 3, 2>(p, st);
+    return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: fused kernel built for (K,pad) in {(3,0),(3,1),(7,3)}");
+}

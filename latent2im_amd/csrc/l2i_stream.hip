@@ -162,12 +162,23 @@ __global__ __launch_bounds__(256) void upfirdn2d_k4_kernel(const UfdParams p) {
         const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
         const float* xin = p.x + mj * (long long)p.in_h * p.in_w;
         __syncthreads();
-        for (int e = threadIdx.x; e < IH * IW; e += 256) {
-            const int r = e / IW, c = e - r * IW;
-            const int gy = iy0 + r, gx = ix0 + c;
-            float v = 0.f;
-            if (gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w) v = xin[(long long)gy * p.in_w + gx];
-            tile[r * PITCH + c] = v;
+        {   // stage the footprint: all loads of a thread issued back-to-back (independent), then written to LDS
+            constexpr int NS = (IH * IW + 255) / 256;
+            float v[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int e = threadIdx.x + u * 256;
+                const int r = e / IW, c = e - r * IW;
+                const int gy = iy0 + r, gx = ix0 + c;
+                v[u] = 0.f;
+                if (e < IH * IW && gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w) v[u] = xin[(long long)gy * p.in_w + gx];
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int e = threadIdx.x + u * 256;
+                const int r = e / IW, c = e - r * IW;
+                if (e < IH * IW) tile[r * PITCH + c] = v[u];
+            }
         }
         __syncthreads();
         float win[5][7];

@@ -52,3 +52,27 @@ def emulate_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0,
     if accumulate:
         a = a + y[sl]
     y[sl] = a
+
+
+def emulate_fused_transposed(Fz, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), out_scale=None, out_gain=1.0, tile_hint=0):
+    """Semantics of l2i_conv_transpose2d_f32: unpack the fused tap order and run torch's conv_transpose2d."""
+    from latent2im_amd import conv
+    B, cin, H, W = x.shape
+    K = Fz.k
+    taps = conv.fused_transposed_taps(K, Fz.pad)
+    w = torch.zeros(Fz.cout, cin, K, K)
+    packed = Fz.w[:, :, :Fz.cout]                                   # [Cin, K*K, Cout]
+    for s, (ky, kx) in enumerate(taps):
+        w[:, :, ky, kx] = packed[:, s, :].t()
+    xi = x
+    if in_scale is not None:
+        xi = xi * in_scale.reshape(B, cin, 1, 1)
+    if in_mask is not None:
+        xi = xi * torch.where(in_mask > 0, torch.tensor(mask[0]), torch.tensor(mask[1]))
+    nat_h, nat_w = (H - 1) * 2 - 2 * Fz.pad + K, (W - 1) * 2 - 2 * Fz.pad + K
+    out = F.conv_transpose2d(xi, w.transpose(0, 1), stride=2, padding=Fz.pad,
+                             output_padding=(y.shape[2] - nat_h, y.shape[3] - nat_w))
+    if out_scale is not None:
+        out = out * out_scale.reshape(B, Fz.cout, 1, 1)
+    y.copy_(out * out_gain)
+    return y

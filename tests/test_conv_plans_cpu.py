@@ -12,6 +12,7 @@ from tests import emu
 @pytest.fixture(autouse=True)
 def _emulated(monkeypatch):
     monkeypatch.setattr(conv, 'run_launch', emu.emulate_launch)
+    monkeypatch.setattr(conv, 'run_fused_transposed', emu.emulate_fused_transposed)
 
 
 CASES = [  # (cin, cout, k, stride, pad, transposed, h, w)
@@ -38,6 +39,23 @@ def test_forward_and_dgrad_plans(cin, cout, k, stride, pad, tr, h, w):
     gref, = torch.autograd.grad(ref, x, gy)
     gx = fc.dgrad(gy, (h, w))
     np.testing.assert_allclose(gx.numpy(), gref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('cin,cout,k,pad,tr,h', [(6, 4, 3, 0, True, 5), (4, 6, 3, 1, False, 12), (4, 6, 3, 1, False, 11), (3, 8, 7, 3, False, 20),
+                                                 (4, 6, 3, 0, False, 9)])
+def test_fused_and_phase_transposed_agree(monkeypatch, fused, cin, cout, k, pad, tr, h):
+    monkeypatch.setattr(conv, 'USE_FUSED_TRANSPOSED', fused)
+    rs = np.random.RandomState(k + h)
+    wt = torch.from_numpy(rs.randn(cout, cin, k, k)).float()
+    x = torch.from_numpy(rs.randn(2, cin, h, h)).float().requires_grad_(True)
+    fc = conv.FrozenConv2d(wt, 2, pad, transposed=tr, device='cpu')
+    ref = F.conv_transpose2d(x, wt.transpose(0, 1), stride=2, padding=pad) if tr else F.conv2d(x, wt, stride=2, padding=pad)
+    gy = torch.from_numpy(rs.randn(*ref.shape)).float()
+    gref, = torch.autograd.grad(ref, x, gy)
+    np.testing.assert_allclose(fc.forward(x.detach()).numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(fc.dgrad(gy, (h, h)).numpy(), gref.numpy(), rtol=1e-4, atol=1e-4)
+    assert (fc.fwd_fused is not None) == tr and (fc.bwd_fused is not None) == (not tr)
 
 
 def test_pack_weight_layout():

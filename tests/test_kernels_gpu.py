@@ -78,6 +78,39 @@ def test_conv_prologue_epilogue_fusions():
     close(y0, res + F.conv2d(x, wt, padding=1), 1e-4, 2e-5)
 
 
+@pytest.mark.parametrize('cin,cout,k,pad,tr,h,w,b', [(24, 40, 3, 0, True, 17, 17, 2), (40, 24, 3, 1, False, 34, 30, 2), (3, 64, 7, 3, False, 64, 64, 1),
+                                                     (64, 3, 7, 3, False, 32, 32, 2), (512, 512, 3, 0, True, 4, 4, 3), (16, 32, 3, 0, False, 9, 9, 2)])
+def test_fused_transposed_conv_matches_per_parity_launches(cin, cout, k, pad, tr, h, w, b):
+    """One-launch stride-2 transposed conv (l2i_conv_transpose2d_f32) == the four per-parity l2i_conv2d_f32 launches == torch."""
+    rs = np.random.RandomState(cin + cout + h)
+    wt = T(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    fc = conv.FrozenConv2d(wt, 2, pad, transposed=tr, device=DEV)
+    g = lambda t: t.to(DEV)
+    if tr:      # forward of an up layer: style scale in, demod scale out
+        x, s, d = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cin) + 0.5), T(rs.rand(b, cout) + 0.5)
+        ref = F.conv_transpose2d(x * s[:, :, None, None], wt.transpose(0, 1), stride=2, padding=pad) * d[:, :, None, None]
+        y1 = fc.forward(g(x), in_scale=g(s), out_scale=g(d))
+        conv.USE_FUSED_TRANSPOSED = False
+        try:
+            y0 = fc.forward(g(x), in_scale=g(s), out_scale=g(d))
+        finally:
+            conv.USE_FUSED_TRANSPOSED = True
+    else:       # input-gradient of a stride-2 conv with a leaky-ReLU mask on the incoming gradient
+        oh, ow = fc.out_hw(h, w)
+        gy, y = T(rs.randn(b, cout, oh, ow)), T(rs.randn(b, cout, oh, ow))
+        xr = T(rs.randn(b, cin, h, w)).requires_grad_(True)
+        gm = gy * torch.where(y > 0, torch.tensor(1.0), torch.tensor(0.2))
+        ref, = torch.autograd.grad(F.conv2d(xr, wt, stride=2, padding=pad), xr, gm)
+        y1 = fc.dgrad(g(gy), (h, w), in_mask=g(y), mask=(1.0, 0.2))
+        conv.USE_FUSED_TRANSPOSED = False
+        try:
+            y0 = fc.dgrad(g(gy), (h, w), in_mask=g(y), mask=(1.0, 0.2))
+        finally:
+            conv.USE_FUSED_TRANSPOSED = True
+    close(y1, ref, 1e-4, 2e-5)
+    close(y0, ref, 1e-4, 2e-5)
+
+
 def test_fused_bias_act_golden(golden):
     gd = golden('fused_bias_act')
     x, b, ref = (T(gd[k]).to(DEV) for k in ('x', 'b', 'ref'))

@@ -35,3 +35,31 @@ print('step %.1f ms, conv %.1f ms in %d launches, %.1f TFLOP/s' % (e0.elapsed_ti
 print('%-74s %4s %9s %8s %6s' % ('(B,cin,cout,kh,kw,stride,H,W,OH,OW,step,mask,scale)', 'n', 'ms', 'TF/s', 'share'))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     print('%-74s %4d %9.3f %8.1f %5.1f%%' % (str(k), v[0], v[1], v[2] / v[1] / 1e9, 100 * v[1] / tot))
+
+
+def cat(d):
+    B, cin, cout, kh, kw, s, H, W, OH, OW, step, mask, scale = d
+    if cout <= 3:
+        return 'cout<=3'
+    if step == 2:
+        return 'phase(step2)'
+    if kh == 1 and kw == 1:
+        return '1x1 s%d' % s
+    if cin <= 4:
+        return 'cin<=3'
+    if H <= 32:
+        return 'kxk small map'
+    if s == 2:
+        return 'kxk s2'
+    return '3x3 big'
+
+
+cats = defaultdict(lambda: [0, 0.0, 0.0])
+for k, v in agg.items():
+    c = cat(k)
+    cats[c][0] += v[0]
+    cats[c][1] += v[1]
+    cats[c][2] += v[2]
+print('--- by category ---')
+for c, v in sorted(cats.items(), key=lambda kv: -kv[1][1]):
+    print('%-16s n=%4d ms=%8.2f  TF/s=%6.1f  share=%5.1f%%' % (c, v[0], v[1], v[2] / v[1] / 1e9, 100 * v[1] / tot))
