@@ -239,7 +239,7 @@ class FrozenConv2d:
             else:
                 assert stride == 2
                 self.bwd = transposed_plan(wt, padding)           # dx[ci, 2o+k-pad] += gy[co,o] w[co,ci,k]
-                if fusable:
+                if fusable and self.cin > 4:          # <= 4 output channels: per-parity launches take the direct VALU kernel
                     self.bwd_fused = FusedTransposed(wt, padding).to(device)
         for L in self.fwd + self.bwd:
             if L is not None:

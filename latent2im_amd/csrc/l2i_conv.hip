@@ -355,6 +355,121 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : 1) void conv_mfma_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Direct (VALU) path for layers with <= 4 output channels: the input-gradients that land on an RGB image (VGG conv1_1,
+// discriminator from_rgb, the per-parity pieces of the ResNet stem).  On the matrix path these fill 3 of the 32 rows of
+// an MFMA tile (11 TFLOP/s measured); here a thread owns a 4x1 column of pixels x 4 channels, reads its inputs from an
+// LDS tile and each tap's 4 weights as one broadcast float4.
+template <bool MASK>
+__global__ __launch_bounds__(256) void conv_direct_small_kernel(const l2i_conv_params p, int tiles_x, int tiles_y, int CK, int IH, int IW, int IWp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int KK = p.KH * p.KW;
+    float* tile = smem;                                  // [CK][IH][IWp]
+    float4* wl = reinterpret_cast<float4*>(smem + ((CK * IH * IWp + 3) & ~3));      // [CK][KK] float4 (4 output channels)
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int b = bid;
+    const int oy0 = ty * 32, ox0 = tx * 32;
+    const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+    const int col = threadIdx.x & 31, r0 = (threadIdx.x >> 5) * 4;
+    const size_t plane_x = (size_t)p.H * p.W;
+    float acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[r][o] = 0.f;
+
+    for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+        __syncthreads();
+        const int nel = CK * IH * IW;
+        for (int e0 = 0; e0 < nel; e0 += 256 * 8) {      // batches of 8 independent loads per thread
+            float v[8], mk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 256 + threadIdx.x;
+                const int c = e / (IH * IW), rem = e - c * (IH * IW);
+                const int iy = rem / IW, ix = rem - iy * IW;
+                const int gy = iy0 + iy, gx = ix0 + ix, ci = c0 + c;
+                v[u] = 0.f; mk[u] = 1.f;
+                if (e < nel && ci < p.Cin && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                    const size_t off = ((size_t)b * p.Cin + ci) * plane_x + (size_t)gy * p.W + gx;
+                    v[u] = p.x[off];
+                    if (MASK) mk[u] = p.in_mask[off];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 256 + threadIdx.x;
+                if (e < nel) {
+                    const int c = e / (IH * IW), rem = e - c * (IH * IW);
+                    const int iy = rem / IW, ix = rem - iy * IW;
+                    float t = v[u];
+                    if (MASK) t *= (mk[u] > 0.f) ? p.mask_pos : p.mask_neg;
+                    if (p.in_scale && c0 + c < p.Cin) t *= p.in_scale[(size_t)b * p.Cin + c0 + c];
+                    tile[(c * IH + iy) * IWp + ix] = t;
+                }
+            }
+        }
+        for (int e = threadIdx.x; e < CK * KK; e += 256) {
+            float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + e / KK < p.Cin) w4 = *reinterpret_cast<const float4*>(p.w + ((size_t)c0 * KK + e) * p.CoutP);
+            wl[e] = w4;
+        }
+        __syncthreads();
+        for (int c = 0; c < CK; ++c) {
+            const float* tc = tile + (c * IH + r0) * IWp + col;
+            const float4* wc = wl + c * KK;
+            for (int ky = 0; ky < p.KH; ++ky) {
+                for (int kx = 0; kx < p.KW; ++kx) {
+                    const float4 w4 = wc[ky * p.KW + kx];
+                    const float* tr = tc + ky * IWp + kx;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                   // static register indexing only (no scratch)
+                        const float x = tr[r * IWp];
+                        acc[r][0] += x * w4.x; acc[r][1] += x * w4.y; acc[r][2] += x * w4.z; acc[r][3] += x * w4.w;
+                    }
+                }
+            }
+        }
+    }
+    const size_t plane_o = (size_t)p.OHf * p.OWf;
+    const int ox = ox0 + col;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oy = oy0 + r0 + r;
+        if (oy < p.OH && ox < p.OW) {
+            const size_t poff = (size_t)(oy * p.oy_step + p.oy_off) * p.OWf + ox * p.ox_step + p.ox_off;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (o < p.Cout) {
+                    const size_t oidx = ((size_t)b * p.Cout + o) * plane_o + poff;
+                    float v = acc[r][o] * p.out_gain;
+                    if (p.accumulate) v += p.y[oidx];
+                    p.y[oidx] = v;
+                }
+            }
+        }
+    }
+}
+
+static int launch_direct_small(const l2i_conv_params& p, hipStream_t st) {
+    const int IH = 32 + p.KH - 1, IW = 32 + p.KW - 1, IWp = IW | 1, KK = p.KH * p.KW;
+    const size_t per_c = (size_t)IH * IWp * sizeof(float) + (size_t)KK * 16;
+    int ck = (int)((40 * 1024) / per_c);
+    if (ck > 16) ck = 16;
+    if (ck > p.Cin) ck = p.Cin;
+    if (ck < 1) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d(direct): kernel window too large");
+    const size_t lds = (((size_t)ck * IH * IWp + 3) & ~(size_t)3) * sizeof(float) + (size_t)ck * KK * 16;
+    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 31) / 32;
+    const long grid = (long)p.B * tiles_x * tiles_y;
+    if (grid <= 0 || grid > 0x7fffffffL) return l2i_set_error(L2I_E_ARG, "conv2d(direct): grid too large");
+    if (p.in_mask) hipLaunchKernelGGL(conv_direct_small_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, ck, IH, IW, IWp);
+    else hipLaunchKernelGGL(conv_direct_small_kernel<false>, dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, ck, IH, IW, IWp);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 static int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static unsigned magic_for(unsigned d) { return (unsigned)((0x100000000ULL + d - 1) / d); }    // exact while n*d < 2^32
 
@@ -447,6 +562,10 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
     if ((((uintptr_t)p.w) % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv2d: packed weights must be 16-byte aligned");
     if ((size_t)p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull || (size_t)p.Cin * p.KH * p.KW * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d: one sample / the weight pack must stay below 4 GiB (32-bit buffer offsets)");
+
+    if (p.Cout <= 4 && p.stride == 1 && p.KH <= 16 && p.tile_hint == 0 && !p.out_scale && !p.noise && !p.bias && !p.residual && !p.out_mask &&
+        p.act == L2I_ACT_NONE)
+        return launch_direct_small(p, (hipStream_t)stream);
 
     // ---- tile selection: minimise a simple time model  waves(grid / resident blocks) x cycles per block  ----
     //      cycles per block = MFMA issue (64 cycles each) + per-chunk barrier/commit cost + epilogue stores (hidden by co-resident blocks);
