@@ -46,7 +46,7 @@ struct ConvLaunch {
                                        // (stride-2 1x1 convs gather only the pixels they use: lstride 1, gstep 2)
 };
 
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic) { return __umulhi(n, magic); }
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }   // magic 0 encodes d == 1
 
 template <int BM> struct WSlots { static constexpr int value = (BM == 128) ? 10 : (BM == 64 ? 8 : 4); };
 

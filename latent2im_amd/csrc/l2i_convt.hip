@@ -30,7 +30,7 @@ struct ConvTLaunch {
     int in_elems, w_vec;
 };
 
-__device__ __forceinline__ unsigned fast_div_t(unsigned n, unsigned magic) { return __umulhi(n, magic); }
+__device__ __forceinline__ unsigned fast_div_t(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
 
 template <int K, int PAD> struct TrGeom {
     static constexpr int k0(int pi) { return (pi + PAD) % 2; }

@@ -308,6 +308,28 @@ class TransformGraph:
             best_im_out = self.get_logits({'w': latent_w_new})
         return best_im_out, alpha_org, out_zs
 
+    def vis_multi_image_batch_alphas(self, graph_inputs, filename, alphas_to_graph, alphas_to_target, batch_start,
+                                     layers=None, name=None, wgt=False, wmask=False, trainEmbed=False, computeL2=False,
+                                     given_w=None, index_=None):
+        """transform_base.py:606-659: one PNG strip per sample, one panel per requested alpha; file name
+        ``<filename>_sample<i>[_wgt]_<alpha_org>.png``.  Returns the list of written paths."""
+        from PIL import Image
+        zs_batch = graph_inputs['z']
+        ims_transformed = []
+        for ag in alphas_to_graph:
+            best_im_out, alpha_org, out_zs = self.apply_alpha({'z': torch.Tensor(zs_batch).to(self.device)}, ag, name=name,
+                                                              layers=layers, trainEmbed=trainEmbed, given_w=given_w, index_=index_)
+            ims_transformed.append(self.clip_ims(best_im_out.detach().cpu().numpy()))
+        written = []
+        for ii in range(zs_batch.shape[0]):
+            a = alpha_org[ii, index_].item() if (index_ is not None and len(self.attrList) > 1) else alpha_org[ii].reshape(-1)[0].item()
+            strip = np.concatenate([x[ii].transpose(1, 2, 0) for x in ims_transformed], axis=1)      # panels side by side
+            path = filename + '_sample{}'.format(ii + batch_start) + ('_wgt' if wgt else '') + '_%.2f.png' % a
+            print('Save in ', path)
+            Image.fromarray(strip).save(path)
+            written.append(path)
+        return written
+
     def vis_image_batch(self, graph_inputs, filename, batch_start, wgt=False, wmask=False, num_panels=7):
         raise NotImplementedError('Subclass should implement vis_image_batch')
 

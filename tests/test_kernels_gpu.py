@@ -25,6 +25,9 @@ CONV_CASES = [  # cin, cout, k, stride, pad, transposed, h, w, batch
     (16, 24, 1, 2, 0, False, 16, 16, 1), (12, 20, 3, 2, 0, True, 8, 8, 2), (32, 32, 3, 2, 0, True, 33, 33, 1),
     (512, 512, 3, 1, 1, False, 4, 4, 2), (130, 70, 3, 1, 1, False, 8, 8, 1), (5, 3, 3, 1, 1, False, 40, 40, 1),
     (64, 3, 7, 2, 3, False, 16, 16, 1),
+    # tiny maps (ResNet-50 tail at small inputs): several samples per tile, 1-pixel rows
+    (256, 512, 1, 2, 0, False, 2, 2, 4), (2048, 512, 1, 1, 0, False, 1, 1, 4), (512, 2048, 1, 1, 0, False, 1, 1, 3), (64, 64, 3, 1, 1, False, 1, 1, 5),
+    (128, 128, 3, 2, 1, False, 3, 3, 2),
 ]
 
 

@@ -183,5 +183,49 @@ def test_training_step_multi_attr_clamp_and_regonly(golden):
     assert float(r['grad'][:, 6:].abs().max()) == 0.0
 
 
+def test_train_cli_then_vis_cli_roundtrip(tmp_path):
+    """The two drop-in drivers end to end on the GPU: train.py (2 iterations at 32^2) writes opt.yml, log.txt, sample grids
+    and the pickled walk; vis_w.py loads them and writes one strip per sample.  apply_alpha == the oracle's two passes."""
+    import pickle
+    from latent2im_amd import trainer, vis, constants
+    models = str(tmp_path / 'models')
+    argv = ['--model', 'stylegan_v2_real', '--transform', 'face', '--num_samples', '8', '--learning_rate', '1e-3', '--latent', 'w',
+            '--walk_type', 'linear', '--loss', 'l2', '--attrList', 'Smiling', '--attrPath', './dataset/attributes_celeba.txt',
+            '--models_dir', models, '--overwrite_config', '--resolution', '32', '--batch_size', '4', '--n_epoch', '1', '--seed', '3',
+            '--model_save_freq', '1']
+    import os
+    os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        trainer.main(multi_attr=False, argv=argv)
+        out = os.path.join(models, 'stylegan_v2_real_face_linear_lr0.001_l2_w')
+        ck = os.path.join(out, 'model_w_1_final_walk_module.ckpt')
+        for f in ('opt.yml', 'opt.txt', 'log.txt', 'model_w_0_walk_module.ckpt'):
+            assert os.path.isfile(os.path.join(out, f)), f
+        assert len([f for f in os.listdir(os.path.join(out, 'results')) if f.endswith('.png')]) == 4
+        assert 'T, epc, bst, lss, alpha:' in open(os.path.join(out, 'log.txt')).read()
+        walk = torch.load(ck, map_location='cpu', weights_only=False)
+        assert type(walk).__module__ == 'graphs.stylegan_v2_real.transform_base' and tuple(walk.w.shape) == (1, 8, 512)
+        # opt.yml needs the additive flags for the visualiser to rebuild the same graph
+        written = vis.main([os.path.join(out, 'opt.yml'), '--save_path_w', ck, '--num_samples', '4', '--num_panels', '3', '--noise_seed', '1'])
+        assert len(written) == 4 and all(os.path.isfile(w) for w in written)
+        # apply_alpha against the oracle
+        gr = selfcheck.build_graph(32, ['Smiling'], 4)
+        with torch.no_grad():
+            gr.walk.w.copy_(walk.w.to(gr.device))
+        zs = synth.z_sample(4, seed=1)
+        alpha = np.full((4, 1), 0.8)
+        img1, a0, img0 = gr.apply_alpha({'z': zs}, alpha)
+        nets_ = dict(G=ostep.to_torch(synth.generator_state(32, seed=100)), R=ostep.to_torch(synth.resnet50_state(seed=300)))
+        ws = ostep.get_w(nets_['G'], T(zs).float(), 8)
+        x0 = ostep.get_logits(nets_['G'], ws)
+        p0 = ostep.get_reg_preds(nets_['R'], x0, [31])
+        x1 = ostep.get_logits(nets_['G'], ostep.walk_linear_multi_w(ws, T(alpha).float() - p0, walk.w.detach()))
+        close(img0, x0)
+        close(a0, p0)
+        close(img1, x1)
+    finally:
+        constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
 def test_smoke_entry():
     selfcheck.smoke()

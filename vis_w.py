@@ -1,0 +1,9 @@
+"""Drop-in for the reference's ``vis_w.py``:
+
+python vis_w.py models_celeba/stylegan_v2_real_face_linear_lr0.0001_l2_w/opt.yml --gpu 0 --noise_seed 0 \
+    --num_samples 30 --num_panels 10 --save_path_w ./models_celeba/.../model_w_10_final_walk_module.ckpt
+"""
+from latent2im_amd.vis import main
+
+if __name__ == '__main__':
+    main()
