@@ -52,7 +52,7 @@ template <int BM> struct WSlots { static constexpr int value = (BM == 128) ? 10 
 
 // NIN: input slots per thread per chunk (floats, or float4 when VEC); NWV: weight float4 slots per thread per chunk
 template <int WM, int WN, bool VEC, bool MASK>
-__global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : 1) void conv_mfma_kernel(const l2i_conv_params p, const ConvLaunch L) {
+__global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2 : 1)) void conv_mfma_kernel(const l2i_conv_params p, const ConvLaunch L) {
     constexpr int BM = WM * 32;
     constexpr int NIN = VEC ? (MASK ? 4 : 8) : 12;
     constexpr int NWV = WSlots<BM>::value;
@@ -474,7 +474,7 @@ static int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static unsigned magic_for(unsigned d) { return (unsigned)((0x100000000ULL + d - 1) / d); }    // exact while n*d < 2^32
 
 struct TileCfg { int wm, wn; };
-static const TileCfg kTiles[] = {{4, 2}, {2, 2}, {1, 4}, {2, 1}, {1, 1}, {1, 2}, {4, 1}};
+static const TileCfg kTiles[] = {{4, 2}, {2, 2}, {1, 4}, {2, 1}, {1, 1}, {1, 2}, {4, 1}, {2, 4}};
 static const int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int WM, int WN, bool VEC, bool MASK>
@@ -581,17 +581,22 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
         if (!plan_tile(p, kTiles[sel].wm, kTiles[sel].wn, Lbest, vbest, lbest, gbest))
             return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d: requested tile cannot be staged for this problem");
     } else {
-        static const int kOcc[5] = {1, 3, 3, 3, 4};           // waves per SIMD = blocks per CU allowed by VGPR+AGPR
+        // candidates: index into kTiles, blocks per CU allowed by VGPR+AGPR, measured MFMA-loop efficiency relative to (2,2)
+        // ((2,4) at 2 blocks/CU wins isolated micro-benchmarks by 3-10 % but loses in the full step — masked/scaled variants spill)
+        static const int kCand[6] = {1, 2, 3, 4, 0, 0};
+        static const int kOcc[6] = {3, 3, 3, 4, 1, 1};
+        static const double kEff[6] = {1.0, 1.0, 1.04, 1.08, 1.0, 1.0};
         double best_cost = 0.0;
-        for (int i = 0; i < 5; ++i) {
+        for (int ci = 0; ci < 5; ++ci) {
+            const int i = kCand[ci];
             if (kTiles[i].wm * 32 > p.CoutP) continue;
             if (!plan_tile(p, kTiles[i].wm, kTiles[i].wn, L, vec, lds, grid)) continue;
             int per_cu = (int)((160 * 1024) / (lds ? lds : 1));
-            if (per_cu > kOcc[i]) per_cu = kOcc[i];
+            if (per_cu > kOcc[ci]) per_cu = kOcc[ci];
             if (per_cu < 1) per_cu = 1;
             const long rounds = (grid + 255) / 256;                   // blocks each CU works through (all share its 4 matrix pipes)
             const int nchunks = (p.Cin + L.CK - 1) / L.CK;
-            const double mfma = 64.0 * kTiles[i].wm * kTiles[i].wn * (double)nchunks * (L.CK / 2) * p.KH * p.KW;
+            const double mfma = 64.0 * kTiles[i].wm * kTiles[i].wn * (double)nchunks * (L.CK / 2) * p.KH * p.KW * kEff[ci];
             const double ovh = 1500.0 * nchunks + 400.0 * kTiles[i].wm * kTiles[i].wn;     // barriers + commit, epilogue
             const double cost = (double)rounds * (mfma + ovh / per_cu);                     // co-resident blocks hide each other's overhead
             if (sel < 0 || cost < best_cost) { sel = i; best_cost = cost; Lbest = L; vbest = vec; lbest = lds; gbest = grid; }
@@ -607,7 +612,8 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
         case 3: e = launch_cfg<2, 1>(p, Lbest, (int)gbest, lbest, vbest, st); break;
         case 4: e = launch_cfg<1, 1>(p, Lbest, (int)gbest, lbest, vbest, st); break;
         case 5: e = launch_cfg<1, 2>(p, Lbest, (int)gbest, lbest, vbest, st); break;
-        default: e = launch_cfg<4, 1>(p, Lbest, (int)gbest, lbest, vbest, st); break;
+        case 6: e = launch_cfg<4, 1>(p, Lbest, (int)gbest, lbest, vbest, st); break;
+        default: e = launch_cfg<2, 4>(p, Lbest, (int)gbest, lbest, vbest, st); break;
     }
     if (e != hipSuccess) return l2i_set_error(L2I_E_LAUNCH, hipGetErrorString(e));
     return L2I_OK;

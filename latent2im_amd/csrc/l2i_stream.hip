@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UfdParams p) {
 // backward): one block = 32x64 outputs of one map; the 35x67 input footprint is staged once in LDS (coalesced rows),
 // each thread produces a 2x4 patch from a 5x7 register window (35 LDS dwords per 8 outputs), 16-byte stores.
 __global__ __launch_bounds__(256) void upfirdn2d_k4_kernel(const UfdParams p) {
-    constexpr int TH = 32, TW = 64, IH = TH + 3, IW = TW + 3, PITCH = 68;
+    constexpr int TH = 32, TW = 64, IH = TH + 3, IW = TW + 3, PITCH = 72, NQ = PITCH / 4;   // 18 float4 per staged row
     __shared__ __attribute__((aligned(16))) float tile[IH * PITCH];
     float kf[16];
 #pragma unroll
@@ -162,22 +162,32 @@ __global__ __launch_bounds__(256) void upfirdn2d_k4_kernel(const UfdParams p) {
         const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
         const float* xin = p.x + mj * (long long)p.in_h * p.in_w;
         __syncthreads();
-        {   // stage the footprint: all loads of a thread issued back-to-back (independent), then written to LDS
-            constexpr int NS = (IH * IW + 255) / 256;
-            float v[NS];
+        {   // stage the footprint with 16-byte loads (4-byte alignment suffices on gfx950), all of a thread's loads
+            // issued back-to-back; edge vectors fall back to guarded scalar loads
+            constexpr int NS = (IH * NQ + 255) / 256;
+            float4 v[NS];
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
                 const int e = threadIdx.x + u * 256;
-                const int r = e / IW, c = e - r * IW;
-                const int gy = iy0 + r, gx = ix0 + c;
-                v[u] = 0.f;
-                if (e < IH * IW && gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w) v[u] = xin[(long long)gy * p.in_w + gx];
+                const int r = e / NQ, q = e - r * NQ;
+                const int gy = iy0 + r, gx = ix0 + 4 * q;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < IH * NQ && gy >= 0 && gy < p.in_h) {
+                    const float* row = xin + (long long)gy * p.in_w;
+                    if (gx >= 0 && gx + 3 < p.in_w) {
+                        v[u] = *reinterpret_cast<const float4*>(row + gx);
+                    } else {
+                        if (gx >= 0 && gx < p.in_w) v[u].x = row[gx];
+                        if (gx + 1 >= 0 && gx + 1 < p.in_w) v[u].y = row[gx + 1];
+                        if (gx + 2 >= 0 && gx + 2 < p.in_w) v[u].z = row[gx + 2];
+                        if (gx + 3 >= 0 && gx + 3 < p.in_w) v[u].w = row[gx + 3];
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
                 const int e = threadIdx.x + u * 256;
-                const int r = e / IW, c = e - r * IW;
-                if (e < IH * IW) tile[r * PITCH + c] = v[u];
+                if (e < IH * NQ) *reinterpret_cast<float4*>(&tile[e * 4]) = v[u];     // e*4 == r*PITCH + 4q
             }
         }
         __syncthreads();
@@ -489,9 +499,31 @@ extern "C" int l2i_maxpool2d_fwd_f32(float* y, uint8_t* idx, const float* x, int
     return L2I_OK;
 }
 
+// k = 2, s = 2, pad = 0 (VGG): every input pixel belongs to exactly one window -> one thread per window writes its 2x2
+// inputs (gradient at the arg-max, zeros elsewhere) as two 8-byte stores.
+__global__ __launch_bounds__(256) void maxpool_bwd_k2s2_kernel(float* __restrict__ gx, const float* __restrict__ gy, const uint8_t* __restrict__ idx,
+                                                               long long planes, int H, int W, int OH, int OW) {
+    const long long total = planes * OH * OW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % OW);
+        const int oy = (int)((i / OW) % OH);
+        const long long pl = i / ((long long)OW * OH);
+        const float g = gy[i];
+        const int a = idx[i];
+        float* dst = gx + (pl * H + 2 * oy) * (long long)W + 2 * ox;
+        *reinterpret_cast<float2*>(dst) = make_float2(a == 0 ? g : 0.f, a == 1 ? g : 0.f);
+        *reinterpret_cast<float2*>(dst + W) = make_float2(a == 2 ? g : 0.f, a == 3 ? g : 0.f);
+    }
+}
+
 extern "C" int l2i_maxpool2d_bwd_f32(float* gx, const float* gy, const uint8_t* idx, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, void* stream) {
     if (!gx || !gy || !idx) return l2i_set_error(L2I_E_ARG, "maxpool_bwd: null tensor");
     if (planes <= 0 || H <= 0 || W <= 0 || k <= 0 || k > 15 || s <= 0 || OH <= 0 || OW <= 0) return l2i_set_error(L2I_E_ARG, "maxpool_bwd: bad geometry");
+    if (k == 2 && s == 2 && pad == 0 && H == 2 * OH && W == 2 * OW && (((uintptr_t)gx) % 8) == 0) {
+        hipLaunchKernelGGL(maxpool_bwd_k2s2_kernel, dim3(l2i_grid_for(planes * OH * OW, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, gx, gy, idx, (long long)planes, H, W, OH, OW);
+        L2I_CHECK_LAUNCH();
+        return L2I_OK;
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(l2i_grid_for(planes * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gx, gy, idx, (long long)planes, H, W, k, s, pad, OH, OW);
     L2I_CHECK_LAUNCH();
     return L2I_OK;

@@ -32,10 +32,10 @@ CONV_CASES = [  # cin, cout, k, stride, pad, transposed, h, w, batch
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-@pytest.mark.parametrize('hint', [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize('hint', [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_conv_forward_dgrad_vs_torch(case, hint):
     cin, cout, k, stride, pad, tr, h, w, b = case
-    if hint and [4, 2, 1, 2, 1, 1, 4][hint - 1] * 32 > (cout + 31) // 32 * 32 + 96:
+    if hint and [4, 2, 1, 2, 1, 1, 4, 2][hint - 1] * 32 > (cout + 31) // 32 * 32 + 96:
         pytest.skip('tile much larger than the layer')
     rs = np.random.RandomState(cin + 7 * cout + k + hint)
     wt = T(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))

@@ -38,7 +38,7 @@ def main():
         y = torch.empty(b, cout, oh, ow, device='cuda')
         macs = b * cout * cin * k * k * (res * res if tr else oh * ow)
         for hint in hints:
-            if hint and [4, 2, 1, 2, 1, 1, 4][hint - 1] * 32 > (cout + 31) // 32 * 32:
+            if hint and [4, 2, 1, 2, 1, 1, 4, 2][hint - 1] * 32 > (cout + 31) // 32 * 32:
                 continue
             try:
                 for _ in range(2):
