@@ -14,3 +14,6 @@ g_path = '/path/550000.pt'
 vgg_path = ''
 
 SYNTH_SEED_G, SYNTH_SEED_D, SYNTH_SEED_R, SYNTH_SEED_V = 100, 200, 300, 400
+
+# run the discriminator / VGG / regressor loss branches on separate HIP streams (see graph.TransformGraph.get_w_loss)
+CONCURRENT_LOSS_BRANCHES = True

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UfdParams p) {
 // backward): one block = 32x64 outputs of one map; the 35x67 input footprint is staged once in LDS (coalesced rows),
 // each thread produces a 2x4 patch from a 5x7 register window (35 LDS dwords per 8 outputs), 16-byte stores.
 __global__ __launch_bounds__(256) void upfirdn2d_k4_kernel(const UfdParams p) {
-    constexpr int TH = 32, TW = 64, IH = TH + 3, IW = TW + 3, PITCH = 72, NQ = PITCH / 4;   // 18 float4 per staged row
+    constexpr int TH = 32, TW = 64, IH = TH + 3, PITCH = 72, NQ = PITCH / 4;   // 18 float4 per staged row
     __shared__ __attribute__((aligned(16))) float tile[IH * PITCH];
     float kf[16];
 #pragma unroll

@@ -234,17 +234,34 @@ class TransformGraph:
         return [losses[i] for i in range(4)]
 
     # -- loss / optimiser ----------------------------------------------------------------------------------------
+    def _side_streams(self):
+        if getattr(self, '_streams', None) is None:
+            self._streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        return self._streams
+
     def get_w_loss(self, feed_dict, no_content_loss=False, no_gan_loss=False):
         """Total walk loss of optimizeParametersAll (transform_base.py:459-486) without the optimiser step."""
         logit = feed_dict['logit']
         gan_loss = content_losses = None
+        # The three loss branches (discriminator, VGG content, regressor) are independent forward+backward chains over
+        # the same image: each runs on its own HIP stream (autograd replays every node's backward on its forward
+        # stream), so the tail of one network's launches overlaps the next one's instead of leaving CUs idle.
+        cur = torch.cuda.current_stream()
+        side = self._side_streams() if constants.CONCURRENT_LOSS_BRANCHES else (cur, cur)
         if not no_gan_loss:
-            D_fake_result = self.module.netD(logit)
-            gan_loss = self.BCE_loss_logits(D_fake_result, torch.ones_like(D_fake_result))
+            side[0].wait_stream(cur)
+            with torch.cuda.stream(side[0]):
+                D_fake_result = self.module.netD(logit)
+                gan_loss = self.BCE_loss_logits(D_fake_result, torch.ones_like(D_fake_result))
         if not no_content_loss:
-            content_loss_list = self.get_content_loss(feed_dict['org'], feed_dict['logit'])
-            content_losses = sum(content_loss_list) / len(content_loss_list)
+            side[1].wait_stream(cur)
+            with torch.cuda.stream(side[1]):
+                content_loss_list = self.get_content_loss(feed_dict['org'], feed_dict['logit'])
+                content_losses = sum(content_loss_list) / len(content_loss_list)
         reg_loss = self.get_reg_loss(feed_dict)
+        if side[0] is not cur:
+            cur.wait_stream(side[0])
+            cur.wait_stream(side[1])
         loss = reg_loss if (no_content_loss and no_gan_loss) else 10 * reg_loss
         if not no_content_loss:
             loss = loss + 0.05 * content_losses
