@@ -32,7 +32,9 @@ def cpu_baseline(resolution, attrs, budget_s, full_loss=True):
     the benchmark resolution with batch 1 (per-image work is identical; D's stddev group is min(B,4))."""
     from latent2im_amd import synth
     from oracle import step as ostep
-    threads = os.cpu_count() or 1
+    # torch's CPU convs stop scaling (and collapse when oversubscribed: 256 threads on the 256-core box = 334 s per step,
+    # 32 threads = 18 s), so the port is timed on at most 32 cores and `cores` reports what was actually used
+    threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
     nets = dict(G=ostep.to_torch(synth.generator_state(resolution, seed=100)), D=ostep.to_torch(synth.discriminator_state(resolution, seed=200)),
                 R=ostep.to_torch(synth.resnet50_state(seed=300)), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400)))
@@ -65,9 +67,12 @@ def main():
     ap.add_argument('--reg_only', action='store_true', help='--no_content_loss --no_gan_loss')
     ap.add_argument('--cpu_baseline_s', type=float, default=12.0, help='CPU-oracle time budget (0 = skip)')
     ap.add_argument('--no_kernel_events', action='store_true', help='do not bracket conv launches with events')
+    ap.add_argument('--serial_streams', action='store_true', help='run the three loss branches on one stream (profiling aid: with\n                    concurrent streams the per-kernel durations rocprof reports include time shared with other kernels)')
     a = ap.parse_args()
 
-    from latent2im_amd import conv, dist, selfcheck, synth
+    from latent2im_amd import constants, conv, dist, selfcheck, synth
+    if a.serial_streams:
+        constants.CONCURRENT_LOSS_BRANCHES = False
     rk, world, local = dist.init_from_env()
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
@@ -107,6 +112,7 @@ def main():
     # launch stream.  Kept out of the timed region above because ~280 event pairs per step cost ~7 % wall on their own.
     prof, t_events = None, None
     if not a.no_kernel_events and rk == 0:
+        concurrent, constants.CONCURRENT_LOSS_BRANCHES = constants.CONCURRENT_LOSS_BRANCHES, False   # one stream: durations do not overlap
         conv.PROFILE = []
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -115,6 +121,7 @@ def main():
         torch.cuda.synchronize()
         t_events = (time.perf_counter() - t1) / a.steps * 1e3
         prof, conv.PROFILE = conv.PROFILE, None
+        constants.CONCURRENT_LOSS_BRANCHES = concurrent
     dist.barrier()
 
     if rk != 0:
@@ -133,8 +140,8 @@ def main():
                     algorithmic_tflop_per_step=round(tot_flop / a.steps / 1e12, 3),
                     ms_per_step_with_events=round(t_events, 2),
                     note='achieved = sum over conv launches (l2i_conv2d_f32 + l2i_conv_transpose2d_f32) of 2*MAC of the dense '
-                         'correlation / sum of their HIP-event durations, over a repeat of the timed steps with an event pair per '
-                         'launch; algorithmic TFLOP per image = algorithmic_tflop_per_step / batch')
+                         'correlation / sum of their HIP-event durations, over a repeat of the timed steps on ONE stream with an event pair '
+                         'per launch (the timed region itself runs the three loss branches on separate streams, without events); algorithmic TFLOP per image = algorithmic_tflop_per_step / batch')
     out = dict(metric='edited images/sec', value=round(value, 3), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(ms_per_step, 2), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
                data='synthetic',
@@ -143,6 +150,7 @@ def main():
                                                                           'reg-only loss' if a.reg_only else 'full loss (reg+content+GAN)', a.batch),
                            resolution=a.resolution, global_batch=global_b, per_gpu_batch=a.batch, attrs=attrs,
                            losses='reg' if a.reg_only else 'reg+content+gan', parallelism='dp%d' % world,
+                           loss_branch_streams=3 if constants.CONCURRENT_LOSS_BRANCHES else 1,
                            loss=float(r['loss'])),
                roofline=roof)
     if world == 1 and a.cpu_baseline_s > 0:

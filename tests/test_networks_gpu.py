@@ -183,6 +183,51 @@ def test_training_step_multi_attr_clamp_and_regonly(golden):
     assert float(r['grad'][:, 6:].abs().max()) == 0.0
 
 
+def test_full_size_1024_forward_parity_and_consistency():
+    """BASELINE configs 2-4 run at 1024^2: one sample through every network at full resolution against the CPU oracle
+    (seconds of CPU work), plus size-independent consistency properties of the kernels at the full bench shape."""
+    from latent2im_amd import conv
+    size = 1024
+    stG = synth.generator_state(size, seed=100)
+    G = Generator(stG, size, device=DEV)
+    PG = ostep.to_torch(stG)
+    z = T(synth.z_sample(1, seed=3)).float()
+    w = G.style(z.to(DEV))
+    lat = torch.stack([w * (1.0 + 0.02 * i) for i in range(G.n_latent)], 1).contiguous()
+    img = G.synthesis(lat)
+    wo = sg2.style_mlp(PG, z)
+    img_o = sg2.generator_synthesis(PG, torch.stack([wo * (1.0 + 0.02 * i) for i in range(G.n_latent)], 1), None)
+    close(img, img_o)
+    stR = synth.resnet50_state(seed=300)
+    close(ResNet50(stR, device=DEV)(img), onets.resnet50_forward(ostep.to_torch(stR), img_o))
+    stD = synth.discriminator_state(size, seed=200)
+    close(Discriminator(stD, size, device=DEV)(img), sg2.discriminator_forward(ostep.to_torch(stD), img_o))
+    stV = synth.vgg19_prefix_state(seed=400)
+    other = torch.roll(img_o, 7, 3)
+    V = VGG19Prefix(stV, device=DEV)
+    _, lo = ostep.content_loss(ostep.to_torch(stV), other, img_o)
+    close(V.content_losses(other.to(DEV), img), torch.stack(lo))
+    # consistency at the bench batch: fused transposed conv == per-parity launches; linearity of the conv in its input
+    x = torch.randn(8, 64, 512, 512, device=DEV)
+    up = G.layers[-2].conv                                             # 64 -> 32 up layer at 512 -> 1025
+    y1 = up.forward(x)
+    conv.USE_FUSED_TRANSPOSED = False
+    try:
+        y0 = up.forward(x)
+    finally:
+        conv.USE_FUSED_TRANSPOSED = True
+    assert float((y1 - y0).abs().max()) <= 1e-4 * float(y0.abs().max())
+    c = G.layers[-3].conv                                              # 64 -> 64 3x3 at 512
+    a, b = torch.randn_like(x), torch.randn_like(x)
+    lhs = c.forward(2.0 * a - 3.0 * b)
+    rhs = 2.0 * c.forward(a) - 3.0 * c.forward(b)
+    assert float((lhs - rhs).abs().max()) <= 1e-4 * float(rhs.abs().max())
+    # every tile configuration computes the same convolution
+    ref = c.forward(a)
+    for hint in (1, 2, 3, 4, 8):
+        assert float((c.forward(a, tile_hint=hint) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
 def test_train_cli_then_vis_cli_roundtrip(tmp_path):
     """The two drop-in drivers end to end on the GPU: train.py (2 iterations at 32^2) writes opt.yml, log.txt, sample grids
     and the pickled walk; vis_w.py loads them and writes one strip per sample.  apply_alpha == the oracle's two passes."""
