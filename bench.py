@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: v_mfma_f32_32x32x16_bf16, dense
 HBM_PEAK_GBS = 8000.0
 
 
@@ -67,12 +68,16 @@ def main():
     ap.add_argument('--reg_only', action='store_true', help='--no_content_loss --no_gan_loss')
     ap.add_argument('--cpu_baseline_s', type=float, default=12.0, help='CPU-oracle time budget (0 = skip)')
     ap.add_argument('--no_kernel_events', action='store_true', help='do not bracket conv launches with events')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x3'],
+                    help="matrix path: exact fp32 MFMA (default) or the opt-in 3-term bf16 split (fp32-class accuracy)")
+    ap.add_argument('--no_alt_precision', action='store_true', help='skip the extra timing of the other matrix path')
     ap.add_argument('--serial_streams', action='store_true', help='run the three loss branches on one stream (profiling aid: with\n                    concurrent streams the per-kernel durations rocprof reports include time shared with other kernels)')
     a = ap.parse_args()
 
     from latent2im_amd import constants, conv, dist, selfcheck, synth
     if a.serial_streams:
         constants.CONCURRENT_LOSS_BRANCHES = False
+    conv.PRECISION = a.precision
     rk, world, local = dist.init_from_env()
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
@@ -124,6 +129,24 @@ def main():
         constants.CONCURRENT_LOSS_BRANCHES = concurrent
     dist.barrier()
 
+    # the other matrix path, same steps, for the record (all ranks: the all-reduce is inside the step)
+    alt = None
+    if not a.no_alt_precision:
+        other = 'bf16x3' if a.precision == 'f32' else 'f32'
+        conv.PRECISION = other
+        one_step(0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t2 = time.perf_counter()
+        for i in range(a.steps):
+            one_step(a.warmup + i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_alt = dist.max_over_ranks(time.perf_counter() - t2, dev)
+        conv.PRECISION = a.precision
+        alt = dict(precision=other, value=round(global_b * a.steps / t_alt, 3), unit='images/s', ms_per_step=round(t_alt / a.steps * 1e3, 2),
+                   note='same workload and steps with the matrix path switched (see DESIGN.md section 2); not the headline value')
+
     if rk != 0:
         return
     ms_per_step = elapsed / a.steps * 1e3
@@ -133,8 +156,10 @@ def main():
         tot_ms = sum(q[0].elapsed_time(q[1]) for q in prof)
         tot_flop = sum(q[2] for q in prof)
         ach = tot_flop / (tot_ms * 1e-3) / 1e12
-        roof = dict(bound='mfma', kernel='conv_mfma_kernel / convt_mfma_kernel (l2i_conv2d_f32, l2i_conv_transpose2d_f32)', achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                    unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+        peak = PEAK_F32_MFMA_TFLOPS if a.precision == 'f32' else PEAK_BF16_MFMA_TFLOPS
+        roof = dict(bound='mfma', kernel='conv_mfma_kernel / convt_mfma_kernel (l2i_conv2d_f32, l2i_conv_transpose2d_f32)' if a.precision == 'f32'
+                    else 'conv_bf16x3_kernel + fp32 kernels for ineligible layers (algorithmic FLOPs; the split executes 3 MFMA FLOPs per algorithmic FLOP)',
+                    achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                     launches_per_step=len(prof) // a.steps, avg_launch_ms=round(tot_ms / len(prof), 4),
                     kernel_ms_per_step=round(tot_ms / a.steps, 2),
                     algorithmic_tflop_per_step=round(tot_flop / a.steps / 1e12, 3),
@@ -143,7 +168,7 @@ def main():
                          'correlation / sum of their HIP-event durations, over a repeat of the timed steps on ONE stream with an event pair '
                          'per launch (the timed region itself runs the three loss branches on separate streams, without events); algorithmic TFLOP per image = algorithmic_tflop_per_step / batch')
     out = dict(metric='edited images/sec', value=round(value, 3), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
-               ms_per_step=round(ms_per_step, 2), higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
+               ms_per_step=round(ms_per_step, 2), higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.precision,
                data='synthetic',
                config=dict(workload='StyleGAN2 FFHQ-shaped %d^2 generator (random-init), ResNet-50 regressor, %d attr, %s, '
                                     'batch %d per GPU, linear W+ walk' % (a.resolution, len(attrs),
@@ -152,7 +177,7 @@ def main():
                            losses='reg' if a.reg_only else 'reg+content+gan', parallelism='dp%d' % world,
                            loss_branch_streams=3 if constants.CONCURRENT_LOSS_BRANCHES else 1,
                            loss=float(r['loss'])),
-               roofline=roof)
+               roofline=roof, alt_precision=alt)
     if world == 1 and a.cpu_baseline_s > 0:
         out['cpu_baseline'] = cpu_baseline(a.resolution, attrs, a.cpu_baseline_s, full_loss=not a.reg_only)
     else:

@@ -74,6 +74,8 @@ typedef struct l2i_conv_params {
     float act_slope, act_gain, out_gain;
     int32_t accumulate;
     int32_t tile_hint;      /* 0 = auto, else 1..N selects a tile configuration (tuning / tests) */
+    const void* w_hi;       /* l2i_conv2d_bf16x3_f32 only: bf16 planes [Cin/16][KH*KW][CoutP][2][8], hi = bf16(w), */
+    const void* w_lo;       /*                              lo = bf16(w - hi); NULL for the fp32 entry points */
 } l2i_conv_params;
 
 int l2i_conv2d_f32(const l2i_conv_params* p, void* stream);
@@ -87,6 +89,13 @@ int l2i_conv2d_f32(const l2i_conv_params* p, void* stream);
  * be unset.  Built for (K,pad) in {(3,0),(3,1),(7,3)}; other shapes return L2I_E_UNSUPPORTED (use the per-parity
  * l2i_conv2d_f32 calls). */
 int l2i_conv_transpose2d_f32(const l2i_conv_params* p, void* stream);
+
+/* OPT-IN split-precision variant of l2i_conv2d_f32 for stride-1 layers on large maps (Cin % 16 == 0, OW >= 32, kernel <=
+ * 3x3): operands are split x = bf16(x) + bf16(x - bf16(x)) and a*b is evaluated as ah*bh + ah*bl + al*bh on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative product error <= ~2^-17).  fp32 tensors in and out, same
+ * prologue / epilogue fusions; `w` is ignored, `w_hi` / `w_lo` are the host-split weight planes.  Nothing on the default
+ * path calls it (latent2im_amd.conv.PRECISION selects it). */
+int l2i_conv2d_bf16x3_f32(const l2i_conv_params* p, void* stream);
 
 /* out[i] = act_grad_table(x[i] + b[(i / step_b) % size_b], ref[i]) * scale   — the reference op, all six
  * act*10+grad cases (fused_bias_act_kernel.cu:36-47).  b / ref may be NULL (= the reference's empty tensors). */

@@ -32,12 +32,14 @@ class ConvParams(ctypes.Structure):
         ('residual', c_p), ('res_mask', c_p), ('out_mask', c_p),
         ('act', c_i), ('act_slope', c_f), ('act_gain', c_f), ('out_gain', c_f),
         ('accumulate', c_i), ('tile_hint', c_i),
+        ('w_hi', c_p), ('w_lo', c_p),
     ]
 
 
 _SIGNATURES = {
     'l2i_conv2d_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv_transpose2d_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
+    'l2i_conv2d_bf16x3_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_fused_bias_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
     'l2i_upfirdn2d_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                 c_i, c_p, c_f, c_p, c_p, c_i, c_f, c_f, c_p]),

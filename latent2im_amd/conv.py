@@ -15,6 +15,9 @@ from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvParams  # noqa: F401
 
 
+import os as _os
+
+PRECISION = _os.environ.get('L2I_PRECISION', 'f32')      # 'bf16x3': eligible stride-1 layers take the split-precision bf16 MFMA kernel (opt-in)
 USE_FUSED_TRANSPOSED = True     # False: issue stride-2 transposed convs as four per-parity launches
 PROFILE = None      # bench.py sets this to a list: every launch then appends (start_event, end_event, algorithmic_flops)
 
@@ -29,15 +32,41 @@ def pack_weight(w):
     return p.contiguous()
 
 
+def pack_weight_bf16x3(w):
+    """[Cout, Cin, KH, KW] fp32 -> (hi, lo) bf16 planes laid out [Cin/16][KH*KW][CoutP][2][8] (as int16 tensors):
+    hi = bf16(w) (round to nearest even), lo = bf16(w - hi)."""
+    w = torch.as_tensor(w, dtype=torch.float32)
+    cout, cin, kh, kw = w.shape
+    assert cin % 16 == 0
+    coutp = (cout + 31) // 32 * 32
+    full = torch.zeros(coutp, cin, kh, kw, dtype=torch.float32)
+    full[:cout] = w
+    hi = full.to(torch.bfloat16)
+    lo = (full - hi.float()).to(torch.bfloat16)
+
+    def lay(t):          # [CoutP, Cin, KH, KW] -> [Cin/16, KH*KW, CoutP, 2, 8]
+        t = t.reshape(coutp, cin // 16, 2, 8, kh * kw).permute(1, 4, 0, 2, 3).contiguous()
+        return t.view(torch.int16)
+    return lay(hi), lay(lo)
+
+
 class Launch:
     """One call of the kernel: a stride-1/2 correlation writing every (oy_step, ox_step)-th output pixel."""
-    __slots__ = ('w', 'cin', 'cout', 'kh', 'kw', 'stride', 'pad_y', 'pad_x', 'step', 'off_y', 'off_x')
+    __slots__ = ('w', 'cin', 'cout', 'kh', 'kw', 'stride', 'pad_y', 'pad_x', 'step', 'off_y', 'off_x', 'w16', 'w_src')
 
     def __init__(self, w_oihw, stride, pad_y, pad_x, step=1, off_y=0, off_x=0, device=None):
         self.cout, self.cin, self.kh, self.kw = w_oihw.shape
         self.w = pack_weight(w_oihw).to(device) if device is not None else pack_weight(w_oihw)
         self.stride, self.pad_y, self.pad_x = stride, pad_y, pad_x
         self.step, self.off_y, self.off_x = step, off_y, off_x
+        self.w16 = None                                        # (hi, lo) planes, built on first bf16x3 use
+        self.w_src = torch.as_tensor(w_oihw, dtype=torch.float32) if (stride == 1 and self.cin % 16 == 0 and self.kh <= 3 and self.kw <= 3) else None
+
+    def bf16x3_planes(self):
+        if self.w16 is None and self.w_src is not None:
+            hi, lo = pack_weight_bf16x3(self.w_src)
+            self.w16 = (hi.to(self.w.device), lo.to(self.w.device))
+        return self.w16
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -192,15 +221,20 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         assert residual.shape == y.shape
     if out_mask is not None:
         assert out_mask.shape == y.shape
+    entry, name = lib.l2i_conv2d_f32, 'l2i_conv2d_f32'
+    if PRECISION == 'bf16x3' and L.step == 1 and OW >= 32 and L.w_src is not None and L.cout > 4:
+        planes = L.bf16x3_planes()
+        p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
+        entry, name = lib.l2i_conv2d_bf16x3_f32, 'l2i_conv2d_bf16x3_f32'
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.check(lib.l2i_conv2d_f32(p, _lib.stream_ptr()), 'l2i_conv2d_f32')
+        _lib.check(entry(p, _lib.stream_ptr()), name)
         e1.record()
         PROFILE.append((e0, e1, 2.0 * B * L.cout * cin * L.kh * L.kw * OH * OW,
                         (B, cin, L.cout, L.kh, L.kw, L.stride, H, W, OH, OW, L.step, in_mask is not None, in_scale is not None)))
         return
-    _lib.check(lib.l2i_conv2d_f32(p, _lib.stream_ptr()), 'l2i_conv2d_f32')
+    _lib.check(entry(p, _lib.stream_ptr()), name)
 
 
 def run_plan(plan, x, y, accumulate=False, **kw):

@@ -114,6 +114,40 @@ def test_fused_transposed_conv_matches_per_parity_launches(cin, cout, k, pad, tr
     close(y0, ref, 1e-4, 2e-5)
 
 
+@pytest.mark.parametrize('cin,cout,k,h,w,b', [(64, 64, 3, 64, 64, 2), (32, 32, 3, 40, 96, 1), (128, 96, 1, 32, 64, 2), (16, 40, 3, 33, 37, 1),
+                                              (512, 512, 3, 32, 32, 1)])
+def test_bf16x3_split_precision_conv(cin, cout, k, h, w, b):
+    """Opt-in bf16 MFMA path with the 3-term operand split: fp32-class accuracy (products exact to ~2^-17), same fused
+    prologue / epilogue semantics, forward and input-gradient."""
+    rs = np.random.RandomState(cin + cout + h)
+    wt = T(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    x, s, d = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cin) + 0.5), T(rs.rand(b, cout) + 0.5)
+    bias, msk = T(rs.randn(cout)), T(rs.randn(b, cin, h, w))
+    g = lambda t: t.to(DEV)
+    fc = conv.FrozenConv2d(wt, 1, k // 2, device=DEV)
+    xd = x.double()
+    ref = F.leaky_relu(F.conv2d(xd * s.double()[:, :, None, None], wt.double(), padding=k // 2) * d.double()[:, :, None, None]
+                       + bias.double()[None, :, None, None], 0.2) * 2 ** 0.5
+    xm = xd * torch.where(msk > 0, torch.tensor(1.0, dtype=torch.float64), torch.tensor(0.2, dtype=torch.float64))
+    ref2 = F.conv2d(xm, wt.double(), padding=k // 2)
+    gy = T(rs.randn(b, cout, h, w))
+    xr = xd.clone().requires_grad_(True)
+    gref, = torch.autograd.grad(F.conv2d(xr, wt.double(), padding=k // 2), xr, gy.double())
+    conv.PRECISION = 'bf16x3'
+    try:
+        y = fc.forward(g(x), in_scale=g(s), out_scale=g(d), bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+        y2 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.2))
+        gx = fc.dgrad(g(gy), (h, w))
+    finally:
+        conv.PRECISION = 'f32'
+    y32 = fc.forward(g(x), in_scale=g(s), out_scale=g(d), bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    for got, want in ((y, ref), (y2, ref2), (gx, gref)):
+        err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+        assert err < 2e-5, err
+    e32 = float((y32.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert e32 < 5e-6, e32                     # the exact-fp32 kernel, for scale
+
+
 def test_fused_bias_act_golden(golden):
     gd = golden('fused_bias_act')
     x, b, ref = (T(gd[k]).to(DEV) for k in ('x', 'b', 'ref'))

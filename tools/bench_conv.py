@@ -29,6 +29,8 @@ SHAPES = [  # name, cin, cout, k, stride, pad, transposed, res, batch
 
 def main():
     hints = [int(h) for h in sys.argv[1].split(',')] if len(sys.argv) > 1 else [0, 1, 2, 3]
+    if len(sys.argv) > 2:
+        conv.PRECISION = sys.argv[2]
     rows = []
     for name, cin, cout, k, stride, pad, tr, res, b in SHAPES:
         w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
