@@ -222,7 +222,7 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
     if out_mask is not None:
         assert out_mask.shape == y.shape
     entry, name = lib.l2i_conv2d_f32, 'l2i_conv2d_f32'
-    if PRECISION == 'bf16x3' and L.step == 1 and OW >= 32 and L.w_src is not None and L.cout > 4:
+    if PRECISION == 'bf16x3' and L.step == 1 and OW >= 32 and L.w_src is not None and L.cout > 4 and L.kh * L.kw > 1:     # 1x1 layers are HBM-bound
         planes = L.bf16x3_planes()
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
         entry, name = lib.l2i_conv2d_bf16x3_f32, 'l2i_conv2d_bf16x3_f32'

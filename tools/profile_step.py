@@ -7,7 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from latent2im_amd import conv, selfcheck, synth
+from latent2im_amd import constants, conv, selfcheck, synth
+
+constants.CONCURRENT_LOSS_BRANCHES = False          # one stream: per-launch durations do not overlap
 
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
