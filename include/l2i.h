@@ -97,6 +97,14 @@ int l2i_conv_transpose2d_f32(const l2i_conv_params* p, void* stream);
  * path calls it (latent2im_amd.conv.PRECISION selects it). */
 int l2i_conv2d_bf16x3_f32(const l2i_conv_params* p, void* stream);
 
+/* 3x3 stride-1 layers (KH = KW = 3, stride 1, dense output window, Cin % 8 == 0, output rows 16-byte aligned multiples of
+ * 4 pixels) as Winograd F(2x2,3x3) on the fp32 matrix cores: exact-fp32 products and accumulation like l2i_conv2d_f32,
+ * 2.25x fewer of them (the algorithm vendor libraries select for the reference's F.conv2d 3x3 calls too).  Same struct,
+ * same prologue / epilogue fusions; `w` is the TRANSFORMED pack U = G g G^T laid out [Cin][4][CoutP][4]
+ * (latent2im_amd/conv.py:pack_weight_wino).  tile_hint: 0 auto, 1 = 32-channel blocks, 2 = 64-channel blocks.
+ * Shapes outside the constraints return L2I_E_UNSUPPORTED (callers use l2i_conv2d_f32). */
+int l2i_conv2d_wino_f32(const l2i_conv_params* p, void* stream);
+
 /* out[i] = act_grad_table(x[i] + b[(i / step_b) % size_b], ref[i]) * scale   — the reference op, all six
  * act*10+grad cases (fused_bias_act_kernel.cu:36-47).  b / ref may be NULL (= the reference's empty tensors). */
 int l2i_fused_bias_act_f32(float* y, const float* x, const float* b, const float* ref, int64_t n,

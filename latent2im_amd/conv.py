@@ -18,6 +18,8 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvParams  # noqa: F401
 import os as _os
 
 PRECISION = _os.environ.get('L2I_PRECISION', 'f32')      # 'bf16x3': eligible stride-1 layers take the split-precision bf16 MFMA kernel (opt-in)
+USE_WINOGRAD = _os.environ.get('L2I_WINOGRAD', '1') != '0'    # 3x3 stride-1 layers on maps >= 32 wide take the F(2x2,3x3) fp32 kernel
+WINO_TILE_HINT = 0              # tests: 1 / 2 force the 32- / 64-channel block variant
 USE_FUSED_TRANSPOSED = True     # False: issue stride-2 transposed convs as four per-parity launches
 PROFILE = None      # bench.py sets this to a list: every launch then appends (start_event, end_event, algorithmic_flops)
 
@@ -50,9 +52,26 @@ def pack_weight_bf16x3(w):
     return lay(hi), lay(lo)
 
 
+_WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+
+
+def pack_weight_wino(w):
+    """[Cout, Cin, 3, 3] -> Winograd F(2x2,3x3) weights U = G g G^T (computed in float64, stored fp32) laid out
+    [Cin, 4 (i), CoutP, 4 (j)]: the kernel reads one float4 = the four j positions of row i for one (cin, cout)."""
+    w = torch.as_tensor(w, dtype=torch.float64)
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    G = torch.as_tensor(_WINO_G)
+    U = torch.einsum('ik,ockl,jl->ocij', G, w, G)                 # [Cout, Cin, 4, 4]
+    coutp = (cout + 31) // 32 * 32
+    p = torch.zeros(cin, 4, coutp, 4, dtype=torch.float32)
+    p[:, :, :cout, :] = U.permute(1, 2, 0, 3).float()
+    return p.contiguous()
+
+
 class Launch:
     """One call of the kernel: a stride-1/2 correlation writing every (oy_step, ox_step)-th output pixel."""
-    __slots__ = ('w', 'cin', 'cout', 'kh', 'kw', 'stride', 'pad_y', 'pad_x', 'step', 'off_y', 'off_x', 'w16', 'w_src')
+    __slots__ = ('w', 'cin', 'cout', 'kh', 'kw', 'stride', 'pad_y', 'pad_x', 'step', 'off_y', 'off_x', 'w16', 'w_src', 'wino')
 
     def __init__(self, w_oihw, stride, pad_y, pad_x, step=1, off_y=0, off_x=0, device=None):
         self.cout, self.cin, self.kh, self.kw = w_oihw.shape
@@ -60,13 +79,19 @@ class Launch:
         self.stride, self.pad_y, self.pad_x = stride, pad_y, pad_x
         self.step, self.off_y, self.off_x = step, off_y, off_x
         self.w16 = None                                        # (hi, lo) planes, built on first bf16x3 use
-        self.w_src = torch.as_tensor(w_oihw, dtype=torch.float32) if (stride == 1 and self.cin % 16 == 0 and self.kh <= 3 and self.kw <= 3) else None
+        self.wino = None                                       # Winograd pack, built on first use
+        self.w_src = torch.as_tensor(w_oihw, dtype=torch.float32) if (stride == 1 and self.cin % 8 == 0 and self.kh <= 3 and self.kw <= 3) else None
 
     def bf16x3_planes(self):
         if self.w16 is None and self.w_src is not None:
             hi, lo = pack_weight_bf16x3(self.w_src)
             self.w16 = (hi.to(self.w.device), lo.to(self.w.device))
         return self.w16
+
+    def wino_pack(self):
+        if self.wino is None and self.w_src is not None and self.kh == 3 and self.kw == 3:
+            self.wino = pack_weight_wino(self.w_src).to(self.w.device)
+        return self.wino
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -222,10 +247,15 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
     if out_mask is not None:
         assert out_mask.shape == y.shape
     entry, name = lib.l2i_conv2d_f32, 'l2i_conv2d_f32'
-    if PRECISION == 'bf16x3' and L.step == 1 and OW >= 32 and L.w_src is not None and L.cout > 4 and L.kh * L.kw > 1:     # 1x1 layers are HBM-bound
+    if PRECISION == 'bf16x3' and L.step == 1 and OW >= 32 and L.w_src is not None and L.cin % 16 == 0 and L.cout > 4 and L.kh * L.kw > 1:     # 1x1 layers are HBM-bound
         planes = L.bf16x3_planes()
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
         entry, name = lib.l2i_conv2d_bf16x3_f32, 'l2i_conv2d_bf16x3_f32'
+    elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
+          and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise)):
+        p.w = _lib.fptr(L.wino_pack())
+        p.tile_hint = WINO_TILE_HINT
+        entry, name = lib.l2i_conv2d_wino_f32, 'l2i_conv2d_wino_f32'
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -235,6 +265,10 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
                         (B, cin, L.cout, L.kh, L.kw, L.stride, H, W, OH, OW, L.step, in_mask is not None, in_scale is not None)))
         return
     _lib.check(entry(p, _lib.stream_ptr()), name)
+
+
+def _wino_aligned(*tensors):
+    return all(t is None or t.data_ptr() % 16 == 0 for t in tensors)
 
 
 def run_plan(plan, x, y, accumulate=False, **kw):

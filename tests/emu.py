@@ -76,3 +76,19 @@ def emulate_fused_transposed(Fz, x, y, in_scale=None, in_mask=None, mask=(1.0, 0
         out = out * out_scale.reshape(B, Fz.cout, 1, 1)
     y.copy_(out * out_gain)
     return y
+
+
+def wino_conv(x, U, cout, pad):
+    """What l2i_conv2d_wino_f32 computes before its epilogue, from the packed U = G g G^T [Cin,4,CoutP,4]: per 2x2 output
+    tile  Y = A^T [ sum_c U[c] . (B^T d_c B) ] A  (zero padding, odd sizes via overhanging tiles)."""
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=x.dtype)
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=x.dtype)
+    n, cin, H, W = x.shape
+    OH, OW = H + 2 * pad - 2, W + 2 * pad - 2
+    ty, tx = (OH + 1) // 2, (OW + 1) // 2
+    xp = F.pad(x, [pad, 2 * tx + 2 - W - pad, pad, 2 * ty + 2 - H - pad])
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                             # [n, cin, ty, tx, 4, 4]
+    V = torch.einsum('ik,nctukl,jl->nctuij', Bt, d, Bt)
+    M = torch.einsum('cioj,nctuij->notuij', U.to(x.dtype)[:, :, :cout, :], V)
+    Y = torch.einsum('ai,notuij,bj->notaub', At, M, At)               # [n, cout, ty, 2, tx, 2]
+    return Y.reshape(n, cout, 2 * ty, 2 * tx)[:, :, :OH, :OW]

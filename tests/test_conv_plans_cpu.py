@@ -78,3 +78,27 @@ def test_epilogue_and_prologue_semantics():
     ref = F.conv2d(x * s[:, :, None, None], wt, padding=1) * d[:, :, None, None] + 0.3 * nz + b[None, :, None, None]
     ref = F.leaky_relu(ref, 0.2) * 2 ** 0.5
     np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('cin,cout,h,w,pad', [(8, 5, 6, 8, 1), (16, 40, 7, 9, 1), (8, 32, 8, 8, 0)])
+def test_winograd_pack_layout_and_transform(cin, cout, h, w, pad):
+    """pack_weight_wino + the kernel's transforms (tests/emu.py:wino_conv) reproduce the direct correlation exactly in
+    float64 — pins the [Cin][4][CoutP][4] layout and the G / B / A matrices the HIP kernel hard-codes."""
+    rs = np.random.RandomState(cin + cout)
+    wt = torch.tensor(rs.randn(cout, cin, 3, 3))
+    x = torch.tensor(rs.randn(2, cin, h, w))
+    U = conv.pack_weight_wino(wt)
+    assert U.shape == (cin, 4, (cout + 31) // 32 * 32, 4) and U.dtype == torch.float32
+    U64 = torch.einsum('ik,ockl,jl->ocij', torch.tensor(conv._WINO_G), wt, torch.tensor(conv._WINO_G)).permute(1, 2, 0, 3)
+    assert torch.allclose(U[:, :, :cout, :].double(), U64, rtol=1e-6, atol=1e-7)
+    got = emu.wino_conv(x, U64.contiguous(), cout, pad)
+    want = F.conv2d(x, wt, padding=pad)
+    assert torch.allclose(got, want, rtol=1e-10, atol=1e-10)
+    # the flipped / transposed weights of the input-gradient plan go through the same pack
+    fc = conv.FrozenConv2d(wt.float(), 1, 1, device='cpu')
+    gy = torch.tensor(rs.randn(2, cout, h, w))
+    xr = x.clone().requires_grad_(True)
+    gref, = torch.autograd.grad(F.conv2d(xr, wt, padding=1), xr, gy)
+    Ub = fc.bwd[0].wino_pack()
+    if Ub is not None:                                   # needs Cin(of the gradient conv) = cout % 8 == 0
+        assert torch.allclose(emu.wino_conv(gy, Ub.double(), cin, 1), gref, rtol=1e-5, atol=1e-5)

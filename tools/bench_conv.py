@@ -31,6 +31,8 @@ def main():
     hints = [int(h) for h in sys.argv[1].split(',')] if len(sys.argv) > 1 else [0, 1, 2, 3]
     if len(sys.argv) > 2:
         conv.PRECISION = sys.argv[2]
+    if len(sys.argv) > 3:
+        conv.USE_WINOGRAD = sys.argv[3] != '0'
     rows = []
     for name, cin, cout, k, stride, pad, tr, res, b in SHAPES:
         w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
