@@ -252,7 +252,8 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
         entry, name = lib.l2i_conv2d_bf16x3_f32, 'l2i_conv2d_bf16x3_f32'
     elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
-          and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise)):
+          and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise)
+          and not (in_mask is not None and L.cout <= 32 and WINO_TILE_HINT == 0)):      # masked 32-channel layers: the direct kernel is faster
         p.w = _lib.fptr(L.wino_pack())
         p.tile_hint = WINO_TILE_HINT
         entry, name = lib.l2i_conv2d_wino_f32, 'l2i_conv2d_wino_f32'
@@ -262,7 +263,8 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         _lib.check(entry(p, _lib.stream_ptr()), name)
         e1.record()
         PROFILE.append((e0, e1, 2.0 * B * L.cout * cin * L.kh * L.kw * OH * OW,
-                        (B, cin, L.cout, L.kh, L.kw, L.stride, H, W, OH, OW, L.step, in_mask is not None, in_scale is not None)))
+                        (B, cin, L.cout, L.kh, L.kw, L.stride, H, W, OH, OW, L.step, in_mask is not None, in_scale is not None,
+                         ''.join(c for c, t in zip('dnbrmoa', (out_scale, noise, bias, residual, res_mask, out_mask, accumulate or None)) if t is not None) + str(act))))
         return
     _lib.check(entry(p, _lib.stream_ptr()), name)
 

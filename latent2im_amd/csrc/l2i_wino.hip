@@ -65,7 +65,7 @@ template <int WCH> struct WinoGeom {
     static constexpr int NV4 = CK * 4 * NT;            // float4 of V per chunk: [c][i][tile] x (4 j)
     static constexpr int NU4 = CK * 4 * BM;            // float4 of U per chunk: [c][i][ch] x (4 j)
     static constexpr int NWV = NU4 / 256;
-    static constexpr int NSLOT = NIN + NWV;            // staging slots per thread per chunk
+    static constexpr int NSLOT = NIN;                  // register staging slots per thread per chunk (raw tile); U goes global -> LDS directly
     static constexpr int NITEM = CK * NT / 256;        // (channel, tile) transform items per thread per chunk
     static constexpr int STAGE = NV4 * 4 + NU4 * 4 + 512;         // floats: V | U | demod[256] | bias[256]
     static constexpr int RAWBUF = NRAW + 64;           // + a dump row for the slots past the end of the tile
@@ -109,15 +109,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const l2i_conv_params
     __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : p.x), 0, p.bias ? (unsigned)(p.Cout * sizeof(float)) : 0u, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = rs_null, rs_m = rs_null, rs_s = rs_null, rs_o = rs_null;
     unsigned voff[NIN];
-    unsigned wvoff = 0, ovoff = 0;
+    unsigned wvoff = 0, ovoff = 0;                         // wvoff: U cursor (one chunk behind the raw cursor)
     const unsigned wstep = (unsigned)((256 / BM) * p.CoutP * 16);
     unsigned rin[NIN];
     unsigned rmk[MASK ? NIN : 1];
-    u32x4 rw[NWV];
     unsigned rsc[NITEM], ros = 0, rbi = 0;
     float sc_cur[NITEM];                                   // style scales of the chunk whose raw tile is in LDS
 
     auto setup = [&](int w) {
+        asm volatile(".p2align 8");        // fixed placement of each phase: this kernel loses up to 30 % at unlucky code offsets (measured)
         int b, m0, oy0, ox0;
         decode(w, b, m0, oy0, ox0);
         const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
@@ -135,36 +135,33 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const l2i_conv_params
             const int c = e / PLANE, rem = e - c * PLANE;
             const int iy = rem / IW, ix = rem - iy * IW;
             const int gy = iy0 + iy, gx = ix0 + ix;
-            voff[u] = in_bytes;
-            if (e < NRAW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                voff[u] = (unsigned)c * plane_b + (unsigned)(gy * p.W + gx) * 4u;
+            const bool ok = (e < NRAW) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
+            voff[u] = ok ? (unsigned)c * plane_b + (unsigned)(gy * p.W + gx) * 4u : in_bytes;
         }
-        wvoff = (unsigned)(((tid / BM) * p.CoutP + m0 + (tid % BM)) * 16);
         ovoff = (tid < BM) ? (unsigned)((m0 + tid) * sizeof(float)) : 0xFFFFFFF0u;
     };
-    auto drain = [&]() { rs_x = rs_null; rs_m = rs_null; rs_s = rs_null; rs_o = rs_null; rs_w = rs_null; rs_b = rs_null; };   // loads past the last chunk: no traffic
+    auto drain = [&]() { rs_x = rs_null; rs_m = rs_null; rs_s = rs_null; rs_o = rs_null; rs_b = rs_null; };   // loads past the last chunk: no traffic
 
-    // slot s < NIN: one raw element; NIN <= s < NSLOT: one float4 of U.  Everything here is branch-free so that the
-    // instruction scheduler may place it between MFMAs.
+    // slot s: one element of the raw halo tile.  Everything here is branch-free so that the instruction scheduler may
+    // place it between MFMAs.
     auto issue_slot = [&](int s, int c0) {
-        if (s < NIN) {
-            const unsigned so = (unsigned)c0 * plane_b;
-            rin[s] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff[s], so, 0);
-            if constexpr (MASK) rmk[s] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, voff[s], so, 0);
-        } else {
-            const unsigned sw = (unsigned)((size_t)c0 * 4 * p.CoutP * 16);
-            rw[s - NIN] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff, sw + (s - NIN) * wstep, 0);
-        }
+        const unsigned so = (unsigned)c0 * plane_b;
+        rin[s] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff[s], so, 0);
+        if constexpr (MASK) rmk[s] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, voff[s], so, 0);
     };
-    auto commit_slot = [&](int s, float* stage) {
-        if (s < NIN) {
-            const int e = tid + s * 256;
-            float v = __uint_as_float(rin[s]);
-            if constexpr (MASK) v *= (__uint_as_float(rmk[s]) > 0.f) ? p.mask_pos : p.mask_neg;
-            raw[(s * 256 + 255 < NRAW || e < NRAW) ? e : NRAW + lane] = v;       // [c][iy][ix], pitch IW: the slot index is the LDS offset
-        } else {
-            reinterpret_cast<u32x4*>(stage + NV4 * 4)[tid + (s - NIN) * 256] = rw[s - NIN];
-        }
+    auto commit_slot = [&](int s) {
+        const int e = tid + s * 256;
+        float v = __uint_as_float(rin[s]);
+        if constexpr (MASK) v *= (__uint_as_float(rmk[s]) > 0.f) ? p.mask_pos : p.mask_neg;
+        raw[(s * 256 + 255 < NRAW || e < NRAW) ? e : NRAW + lane] = v;           // [c][iy][ix], pitch IW: the slot index is the LDS offset
+    };
+    // U of one chunk: NWV pieces of 1 KiB per wave, global -> LDS without touching registers (buffer_load_dwordx4 ... lds:
+    // lane l of the wave lands at piece base + 16 l, which is exactly the [c][i][ch] float4 order of the pack)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_u = [&](int k, float* stage, int c0) {
+        const unsigned sw = (unsigned)((size_t)c0 * 4 * p.CoutP * 16);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(stage + NV4 * 4 + (k * 256 + wave_u * 64) * 4), 16,
+                                                 wvoff, sw + k * wstep, 0, 0);
     };
     auto issue_misc = [&](int c0) {
 #pragma unroll
@@ -182,6 +179,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const l2i_conv_params
     };
     // input transform of the chunk, once per block: V[c][i][tile] = (B^T d B)[i][0..3] * style(c)
     auto transform = [&](float* stage) {
+        asm volatile(".p2align 8");        // fixed placement of each phase: this kernel loses up to 30 % at unlucky code offsets (measured)
         float4* V4 = reinterpret_cast<float4*>(stage);
 #pragma unroll
         for (int u = 0; u < NITEM; ++u) {
@@ -221,8 +219,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const l2i_conv_params
     // ---- MFMA over one chunk: lanes 0-31 take channel cc, lanes 32-63 channel cc + CK/2.  Between the MFMAs: the LDS
     //      fragment reads of the next k-pair, and this k-pair's share of the staging slots (LDS write of chunk f+1, then
     //      the global load of chunk f+2 into the same register) ----
-    auto compute = [&](const float* stage, float* nstage, int c0_issue, auto first_tag) {
+    auto compute = [&](const float* stage, float* nstage, int c0_raw, int c0_u, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        asm volatile(".p2align 8");        // fixed placement of each phase: this kernel loses up to 30 % at unlucky code offsets (measured)
         const float4* vb4 = reinterpret_cast<const float4*>(stage) + half * CKh * 4 * NT + wt * 32 + j;
         const float4* ub4 = reinterpret_cast<const float4*>(stage + NV4 * 4) + half * CKh * 4 * BM + wch * 32 + j;
         float4 bn[4], an[4];
@@ -238,9 +237,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const l2i_conv_params
             for (int i = 0; i < 4; ++i) { a4[i] = an[i]; b4[i] = bn[i]; }
             __builtin_amdgcn_sched_barrier(0);
             if (cc + 1 < CKh) fetch(cc + 1);              // next k-pair's fragments are in flight during these 16 MFMAs
-            if (cc == 0) { commit_misc(nstage); issue_misc(c0_issue); }
+            if (cc == 0) {                                // chunk f+1: registers -> LDS (raw tile, epilogue tables); U: global -> LDS
+                commit_misc(nstage);
 #pragma unroll
-            for (int s = (cc * NSLOT) / CKh; s < ((cc + 1) * NSLOT) / CKh; ++s) { commit_slot(s, nstage); issue_slot(s, c0_issue); }
+                for (int s = 0; s < NSLOT; ++s) commit_slot(s);
+            }
+            if (cc == (CKh > 2 ? 1 : 0)) {
+#pragma unroll
+                for (int k = 0; k < NWV; ++k) dma_u(k, nstage, c0_u);
+            }
+            if (cc == CKh - 1) {                          // chunk f+2: global -> registers
+                issue_misc(c0_raw);
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) issue_slot(s, c0_raw);
+            }
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const l2i_conv_params
     // ---- inverse transform (lane-local) -> per-wave LDS transpose -> fused epilogue with 16-byte global accesses ----
     const size_t plane_o = (size_t)p.OHf * p.OWf;
     auto epilogue = [&](int w, float* stage) {
+        asm volatile(".p2align 8");        // fixed placement of each phase: this kernel loses up to 30 % at unlucky code offsets (measured)
         int b, m0, oy0, ox0;
         decode(w, b, m0, oy0, ox0);
         const float* tab = stage + NV4 * 4 + NU4 * 4;
@@ -338,18 +349,27 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const l2i_conv_params
         }
     };
 
-    // ---- flat pipeline over f = (work item, chunk): while the MFMAs of f run, chunk f+1 moves registers -> LDS and
-    //      chunk f+2 global -> registers; between two MFMA phases only the input transform of f+1 is exposed ----
-    int iw = vb, ic = 0;                                   // issue cursor (work item, chunk)
+    // ---- flat pipeline over f = (work item, chunk): while the MFMAs of f run, the raw tile of f+1 moves registers -> LDS,
+    //      U of f+1 global -> LDS and the raw tile of f+2 global -> registers; between two MFMA phases only the input
+    //      transform of f+1 is exposed ----
+    int iw = vb, ic = 0;                                   // raw cursor (work item, chunk): next chunk to load into registers
+    int iwu = vb, icu = 0;                                 // U cursor: next chunk to copy into LDS
     auto advance = [&]() { if (++ic == L.nchunks) { ic = 0; iw += G; } };
+    const unsigned wv_base = (unsigned)(((tid / BM) * p.CoutP + (tid % BM)) * 16);
+    auto setup_u = [&]() { wvoff = wv_base + (unsigned)((iwu % L.mblocks) * BM * 16); };
+    auto advance_u = [&]() { if (++icu == L.nchunks) { icu = 0; iwu += G; } };
     setup(iw);
+    setup_u();
+#pragma unroll
+    for (int k = 0; k < NWV; ++k) dma_u(k, smem, 0);
+    advance_u();
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) issue_slot(s, 0);
     issue_misc(0);
     advance();
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) commit_slot(s, smem);
     commit_misc(smem);
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) commit_slot(s);
     if (1 < iters) {
         if (ic == 0) setup(iw);
 #pragma unroll
@@ -365,13 +385,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const l2i_conv_params
 #ifdef WINO_TIMING
     unsigned long long tlast = __builtin_readcyclecounter();
 #endif
-    auto pre = [&]() {                                     // staging state for the chunk issued during this MFMA phase (f + 2)
+    auto pre = [&]() {                                     // staging state for the chunks issued during this MFMA phase
         if (it + 2 < iters) { if (ic == 0) setup(iw); } else drain();
+        if (it + 1 < iters) { if (icu == 0) setup_u(); } else rs_w = rs_null;
         TSTAMP(0);
     };
     auto post = [&](bool last_chunk) {
         TSTAMP(2);
         if (it + 2 < iters) advance();
+        if (it + 1 < iters) advance_u();
         float* nxt = smem + ((it + 1) & 1) * STAGE;
         if (last_chunk) {
             epilogue(cw, smem + (it & 1) * STAGE);
@@ -388,11 +410,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const l2i_conv_params
     };
     for (int t = 0; t < nmine; ++t) {                      // the first chunk of a tile is peeled: its MFMAs start from a zero constant
         pre();
-        compute(smem + (it & 1) * STAGE, smem + ((it + 1) & 1) * STAGE, ic * CK, std::true_type());
+        compute(smem + (it & 1) * STAGE, smem + ((it + 1) & 1) * STAGE, ic * CK, icu * CK, std::true_type());
         for (int c = 1; c < L.nchunks; ++c) {
             post(false);
             pre();
-            compute(smem + (it & 1) * STAGE, smem + ((it + 1) & 1) * STAGE, ic * CK, std::false_type());
+            compute(smem + (it & 1) * STAGE, smem + ((it + 1) & 1) * STAGE, ic * CK, icu * CK, std::false_type());
         }
         post(true);
     }
@@ -446,6 +468,8 @@ extern "C" int l2i_conv2d_wino_f32(const l2i_conv_params* pp, void* stream) {
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino: output rows must be 16-byte aligned multiples of 4 pixels");
     if ((size_t)p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull || (size_t)p.Cin * 16 * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino: one sample / the weight pack must stay below 4 GiB (32-bit buffer offsets)");
+    if ((size_t)p.Cout * p.OHf * p.OWf * sizeof(float) >= 0xFFFFFFF0ull)
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino: one output sample must stay below 4 GiB (32-bit buffer offsets)");
     hipStream_t st = (hipStream_t)stream;
     int wch = p.tile_hint;
     if (wch == 0) wch = (p.CoutP % 64 == 0) ? 2 : 1;

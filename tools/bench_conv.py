@@ -9,7 +9,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from latent2im_amd import conv
+from latent2im_amd import conv, _lib
+
+if os.environ.get('L2I_LIB_PATH'):          # A/B runs of two builds in one session
+    _lib.LIB_PATH = os.environ['L2I_LIB_PATH']
 
 SHAPES = [  # name, cin, cout, k, stride, pad, transposed, res, batch
     ('g64_512', 512, 512, 3, 1, 1, False, 64, 8),

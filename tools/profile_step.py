@@ -40,7 +40,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
 
 
 def cat(d):
-    B, cin, cout, kh, kw, s, H, W, OH, OW, step, mask, scale = d
+    B, cin, cout, kh, kw, s, H, W, OH, OW, step, mask, scale = d[:13]
     if cout <= 3:
         return 'cout<=3'
     if step == 2:
