@@ -101,7 +101,7 @@ int l2i_conv2d_bf16x3_f32(const l2i_conv_params* p, void* stream);
  * 4 pixels) as Winograd F(2x2,3x3) on the fp32 matrix cores: exact-fp32 products and accumulation like l2i_conv2d_f32,
  * 2.25x fewer of them (the algorithm vendor libraries select for the reference's F.conv2d 3x3 calls too).  Same struct,
  * same prologue / epilogue fusions; `w` is the TRANSFORMED pack U = G g G^T laid out [Cin][4][CoutP][4]
- * (latent2im_amd/conv.py:pack_weight_wino).  tile_hint: 0 auto, 1 = 32-channel blocks, 2 = 64-channel blocks.
+ * (latent2im_amd/conv.py:pack_weight_wino).  tile_hint must be 0.
  * Shapes outside the constraints return L2I_E_UNSUPPORTED (callers use l2i_conv2d_f32). */
 int l2i_conv2d_wino_f32(const l2i_conv_params* p, void* stream);
 

@@ -19,7 +19,6 @@ import os as _os
 
 PRECISION = _os.environ.get('L2I_PRECISION', 'f32')      # 'bf16x3': eligible stride-1 layers take the split-precision bf16 MFMA kernel (opt-in)
 USE_WINOGRAD = _os.environ.get('L2I_WINOGRAD', '1') != '0'    # 3x3 stride-1 layers on maps >= 32 wide take the F(2x2,3x3) fp32 kernel
-WINO_TILE_HINT = 0              # tests: 1 / 2 force the 32- / 64-channel block variant
 USE_FUSED_TRANSPOSED = True     # False: issue stride-2 transposed convs as four per-parity launches
 PROFILE = None      # bench.py sets this to a list: every launch then appends (start_event, end_event, algorithmic_flops)
 
@@ -252,10 +251,8 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
         entry, name = lib.l2i_conv2d_bf16x3_f32, 'l2i_conv2d_bf16x3_f32'
     elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
-          and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise)
-          and not (in_mask is not None and L.cout <= 32 and WINO_TILE_HINT == 0)):      # masked 32-channel layers: the direct kernel is faster
+          and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise)):
         p.w = _lib.fptr(L.wino_pack())
-        p.tile_hint = WINO_TILE_HINT
         entry, name = lib.l2i_conv2d_wino_f32, 'l2i_conv2d_wino_f32'
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

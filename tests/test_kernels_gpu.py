@@ -151,9 +151,8 @@ def test_bf16x3_split_precision_conv(cin, cout, k, h, w, b):
 @pytest.mark.parametrize('cin,cout,h,w,b', [(64, 64, 64, 64, 2), (32, 32, 40, 96, 1), (128, 96, 32, 64, 2), (16, 40, 36, 36, 1),
                                             (512, 512, 32, 32, 1), (8, 64, 64, 128, 3), (64, 128, 128, 32, 1)])
 def test_winograd_3x3_conv(cin, cout, h, w, b):
-    """F(2x2,3x3) fp32 kernel vs a float64 reference: every prologue / epilogue fusion, partial tiles, both channel-block
-    variants, forward and input-gradient; and the kernel is really the one that ran (different bits than the direct one
-    is not required, but the entry point is checked through conv.PROFILE-free dispatch conditions)."""
+    """F(2x2,3x3) fp32 kernel vs a float64 reference: every prologue / epilogue fusion, partial tiles, channel counts that
+    do not fill a block, forward and input-gradient; the direct kernel on the same problem for scale."""
     rs = np.random.RandomState(cin + cout + h)
     wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
     x, s, d = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cin) + 0.5), T(rs.rand(b, cout) + 0.5)
@@ -173,26 +172,16 @@ def test_winograd_3x3_conv(cin, cout, h, w, b):
     gy = T(rs.randn(b, cout, h, w))
     xr = D(x).clone().requires_grad_(True)
     gref, = torch.autograd.grad(c64(xr), xr, D(gy))
-    hints = [0, 1] + ([2] if cout % 64 == 0 else [])
-    calls = []
-    lib = conv._lib.load()
-    for hint in hints:
-        conv.WINO_TILE_HINT = hint
-        try:
-            y1 = fc.forward(g(x), in_scale=g(s), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
-            y2 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.2), bias=g(bias), residual=g(res), res_mask=g(rmk), act=conv.ACT_RELU)
-            y3 = g(y_prev).clone()
-            fc.forward(g(x), out=y3, out_mask=g(omk), out_gain=0.5, accumulate=True)
-            if hint == 2 and cin % 64 != 0:
-                conv.WINO_TILE_HINT = 0
-            gx = fc.dgrad(g(gy), (h, w)) if cout % 8 == 0 else None
-        finally:
-            conv.WINO_TILE_HINT = 0
-        for got, want in ((y1, ref1), (y2, ref2), (y3, ref3), (gx, gref)):
-            if got is None:
-                continue
-            err = float((got.double().cpu() - want).abs().max() / want.abs().max())
-            assert err < 5e-6, (hint, err)
+    y1 = fc.forward(g(x), in_scale=g(s), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    y2 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.2), bias=g(bias), residual=g(res), res_mask=g(rmk), act=conv.ACT_RELU)
+    y3 = g(y_prev).clone()
+    fc.forward(g(x), out=y3, out_mask=g(omk), out_gain=0.5, accumulate=True)
+    gx = fc.dgrad(g(gy), (h, w)) if cout % 8 == 0 else None
+    for got, want in ((y1, ref1), (y2, ref2), (y3, ref3), (gx, gref)):
+        if got is None:
+            continue
+        err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+        assert err < 5e-6, err
     # the direct kernel on the same problem, for scale (and as a cross-check of the dispatch switch)
     conv.USE_WINOGRAD = False
     try:
