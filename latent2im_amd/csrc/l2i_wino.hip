@@ -33,6 +33,18 @@
 #include "l2i_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed fp32 VALU (two independent lanes of work per issue slot).  Inline asm because hipcc scalarises most f32x2
+// arithmetic (and cannot see hazards inside asm: see pk_mul_op).
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// pk_mul_op: the product feeds an MFMA next, the 2 wait states of "VALU write -> MFMA read" ride in the same asm statement
+__device__ __forceinline__ f32x2 pk_mul_op(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// (a.lo + b.hi, a.lo - b.hi)
+__device__ __forceinline__ f32x2 pk_lo_pm_hi(f32x2 a, f32x2 b) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
 
 struct WinoLaunch {
     int tiles_x, tiles_y, mblocks;
@@ -160,19 +172,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
         fetch_a(0, 0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            float t[4][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                          // B^T d
-                const float d0 = (q < 2) ? (q == 0 ? dn[0][0].x : dn[0][0].y) : (q == 2 ? dn[0][1].x : dn[0][1].y);
-                const float d1 = (q < 2) ? (q == 0 ? dn[1][0].x : dn[1][0].y) : (q == 2 ? dn[1][1].x : dn[1][1].y);
-                const float d2 = (q < 2) ? (q == 0 ? dn[2][0].x : dn[2][0].y) : (q == 2 ? dn[2][1].x : dn[2][1].y);
-                const float d3 = (q < 2) ? (q == 0 ? dn[3][0].x : dn[3][0].y) : (q == 2 ? dn[3][1].x : dn[3][1].y);
-                t[0][q] = d0 - d2;
-                t[1][q] = d1 + d2;
-                t[2][q] = d2 - d1;
-                t[3][q] = d1 - d3;
+            // Measured (tools/probes/mfma_valu_overlap_probe.hip): a VALU instruction costs ~4 cycles of fp32 matrix time at any
+            // occupancy, so the transform is written on register pairs (v_pk_add_f32 / v_pk_mul_f32: two lanes of work per issue
+            // slot).  Pairs are the column pairs (0,1) and (2,3) of the patch, exactly what ds_read2_b64 delivers.
+            f32x2 t01[4], t23[4];                                  // B^T d, rows i = 0..3
+            {
+                const f32x2 d0a = {dn[0][0].x, dn[0][0].y}, d0b = {dn[0][1].x, dn[0][1].y};
+                const f32x2 d1a = {dn[1][0].x, dn[1][0].y}, d1b = {dn[1][1].x, dn[1][1].y};
+                const f32x2 d2a = {dn[2][0].x, dn[2][0].y}, d2b = {dn[2][1].x, dn[2][1].y};
+                const f32x2 d3a = {dn[3][0].x, dn[3][0].y}, d3b = {dn[3][1].x, dn[3][1].y};
+                t01[0] = pk_sub(d0a, d2a); t23[0] = pk_sub(d0b, d2b);
+                t01[1] = pk_add(d1a, d2a); t23[1] = pk_add(d1b, d2b);
+                t01[2] = pk_sub(d2a, d1a); t23[2] = pk_sub(d2b, d1b);
+                t01[3] = pk_sub(d1a, d3a); t23[3] = pk_sub(d1b, d3b);
             }
             const float sc = tab[par * CK + 4 * s + kq];
+            const f32x2 scp = {sc, sc};
             if (s == 0) fetch_d(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -180,18 +195,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
                 if (i < 3) fetch_a(s, i + 1);
                 else if (s == 0) fetch_a(1, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                const float v0 = (t[i][0] - t[i][2]) * sc;         // (B^T d) B, times the style scale of the channel
-                const float v1 = (t[i][1] + t[i][2]) * sc;
-                const float v2 = (t[i][2] - t[i][1]) * sc;
-                const float v3 = (t[i][1] - t[i][3]) * sc;
-                acc[i * 4 + 0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, v0, (FIRST && s == 0) ? zero : acc[i * 4 + 0][0], 0, 0, 0);
-                acc[i * 4 + 0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, v0, (FIRST && s == 0) ? zero : acc[i * 4 + 0][1], 0, 0, 0);
-                acc[i * 4 + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, v1, (FIRST && s == 0) ? zero : acc[i * 4 + 1][0], 0, 0, 0);
-                acc[i * 4 + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, v1, (FIRST && s == 0) ? zero : acc[i * 4 + 1][1], 0, 0, 0);
-                acc[i * 4 + 2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, v2, (FIRST && s == 0) ? zero : acc[i * 4 + 2][0], 0, 0, 0);
-                acc[i * 4 + 2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, v2, (FIRST && s == 0) ? zero : acc[i * 4 + 2][1], 0, 0, 0);
-                acc[i * 4 + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, v3, (FIRST && s == 0) ? zero : acc[i * 4 + 3][0], 0, 0, 0);
-                acc[i * 4 + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, v3, (FIRST && s == 0) ? zero : acc[i * 4 + 3][1], 0, 0, 0);
+                // (B^T d) B: (v0, v3) = (t0 - t2, t1 - t3);  (v1, v2) = (t2 + t1, t2 - t1); then the style scale of the channel
+                const f32x2 v03 = pk_mul_op(pk_sub(t01[i], t23[i]), scp);
+                const f32x2 v12 = pk_mul_op(pk_lo_pm_hi(t23[i], t01[i]), scp);
+                acc[i * 4 + 0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, v03.x, (FIRST && s == 0) ? zero : acc[i * 4 + 0][0], 0, 0, 0);
+                acc[i * 4 + 0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, v03.x, (FIRST && s == 0) ? zero : acc[i * 4 + 0][1], 0, 0, 0);
+                acc[i * 4 + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, v12.x, (FIRST && s == 0) ? zero : acc[i * 4 + 1][0], 0, 0, 0);
+                acc[i * 4 + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, v12.x, (FIRST && s == 0) ? zero : acc[i * 4 + 1][1], 0, 0, 0);
+                acc[i * 4 + 2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, v12.y, (FIRST && s == 0) ? zero : acc[i * 4 + 2][0], 0, 0, 0);
+                acc[i * 4 + 2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, v12.y, (FIRST && s == 0) ? zero : acc[i * 4 + 2][1], 0, 0, 0);
+                acc[i * 4 + 3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, v03.y, (FIRST && s == 0) ? zero : acc[i * 4 + 3][0], 0, 0, 0);
+                acc[i * 4 + 3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, v03.y, (FIRST && s == 0) ? zero : acc[i * 4 + 3][1], 0, 0, 0);
             }
         }
     };
