@@ -20,7 +20,7 @@ import os as _os
 PRECISION = _os.environ.get('L2I_PRECISION', 'f32')      # 'bf16x3': eligible stride-1 layers take the split-precision bf16 MFMA kernel (opt-in)
 USE_WINOGRAD = _os.environ.get('L2I_WINOGRAD', '1') != '0'    # 3x3 stride-1 layers on maps >= 32 wide take the F(2x2,3x3) fp32 kernel
 USE_FUSED_TRANSPOSED = True     # False: issue stride-2 transposed convs as four per-parity launches
-PROFILE = None      # bench.py sets this to a list: every launch then appends (start_event, end_event, algorithmic_flops)
+PROFILE = None      # bench.py sets this to a list: every launch then appends (start_event, end_event, algorithmic_flops, shape, entry point)
 
 
 def pack_weight(w):
@@ -204,7 +204,7 @@ def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), 
         _lib.check(lib.l2i_conv_transpose2d_f32(p, _lib.stream_ptr()), 'l2i_conv_transpose2d_f32')
         e1.record()
         PROFILE.append((e0, e1, 2.0 * B * F.cout * cin * F.k * F.k * H * W,
-                        (B, cin, F.cout, F.k, F.k, 2, H, W, int(p.OHf), int(p.OWf), 2, in_mask is not None, in_scale is not None)))
+                        (B, cin, F.cout, F.k, F.k, 2, H, W, int(p.OHf), int(p.OWf), 2, in_mask is not None, in_scale is not None), 'l2i_conv_transpose2d_f32'))
         return y
     _lib.check(lib.l2i_conv_transpose2d_f32(p, _lib.stream_ptr()), 'l2i_conv_transpose2d_f32')
     return y
@@ -261,7 +261,8 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         e1.record()
         PROFILE.append((e0, e1, 2.0 * B * L.cout * cin * L.kh * L.kw * OH * OW,
                         (B, cin, L.cout, L.kh, L.kw, L.stride, H, W, OH, OW, L.step, in_mask is not None, in_scale is not None,
-                         ''.join(c for c, t in zip('dnbrmoa', (out_scale, noise, bias, residual, res_mask, out_mask, accumulate or None)) if t is not None) + str(act))))
+                         ''.join(c for c, t in zip('dnbrmoa', (out_scale, noise, bias, residual, res_mask, out_mask, accumulate or None)) if t is not None) + str(act)),
+                        name))
         return
     _lib.check(entry(p, _lib.stream_ptr()), name)
 

@@ -27,7 +27,7 @@ e1.record()
 torch.cuda.synchronize()
 prof, conv.PROFILE = conv.PROFILE, None
 agg = defaultdict(lambda: [0, 0.0, 0.0])
-for a, b, fl, d in prof:
+for a, b, fl, d, _name in prof:
     k = d
     agg[k][0] += 1
     agg[k][1] += a.elapsed_time(b)
