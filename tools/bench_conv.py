@@ -27,6 +27,10 @@ SHAPES = [  # name, cin, cout, k, stride, pad, transposed, res, batch
     ('r_1x1_2048', 1024, 2048, 1, 1, 0, False, 32, 8),
     ('r_stem', 3, 64, 7, 2, 3, False, 1024, 8),
     ('v_64', 64, 64, 3, 1, 1, False, 1024, 4),
+    ('r_256_1024', 256, 1024, 1, 1, 0, False, 64, 8),
+    ('r_1024_256', 1024, 256, 1, 1, 0, False, 64, 8),
+    ('r_2048_512', 2048, 512, 1, 1, 0, False, 32, 8),
+    ('r_512_128', 512, 128, 1, 1, 0, False, 128, 8),
 ]
 
 
