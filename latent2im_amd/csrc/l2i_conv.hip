@@ -359,7 +359,9 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
 // discriminator from_rgb, the per-parity pieces of the ResNet stem).  On the matrix path these fill 3 of the 32 rows of
 // an MFMA tile (11 TFLOP/s measured); here a thread owns a 4x1 column of pixels x 4 channels, reads its inputs from an
 // LDS tile and each tap's 4 weights as one broadcast float4.
-template <bool MASK>
+// TKH x TKW: compile-time window (0 = run-time p.KH x p.KW): the tap loop unrolls, the thread's (TKH+3) x TKW input window is read
+// once per channel and every LDS read is in flight before the first FMA (the rolled loop waited out one LDS latency per tap)
+template <bool MASK, int TKH, int TKW>
 __global__ __launch_bounds__(256) void conv_direct_small_kernel(const l2i_conv_params p, int tiles_x, int tiles_y, int CK, int IH, int IW, int IWp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int KK = p.KH * p.KW;
@@ -381,32 +383,59 @@ __global__ __launch_bounds__(256) void conv_direct_small_kernel(const l2i_conv_p
 
     for (int c0 = 0; c0 < p.Cin; c0 += CK) {
         __syncthreads();
-        const int nel = CK * IH * IW;
-        for (int e0 = 0; e0 < nel; e0 += 256 * 8) {      // batches of 8 independent loads per thread
-            float v[8], mk[8];
+        // staging: thread = (row group, 4-column slot); 16-byte global loads (4-byte alignment suffices on gfx950), rows of the
+        // [CK][IH] stack walked 16 apart with an incremental (channel, iy) pair — no integer divisions, 5 loads in flight per thread
+        {
+            const int sq = threadIdx.x & 15, sgrp = threadIdx.x >> 4;      // 16 slots x 4 columns cover IW <= 64
+            const int lx = sq * 4, gx = ix0 + lx;
+            const bool slot_on = lx < IW;
+            const bool full = slot_on && lx + 3 < IW && gx >= 0 && gx + 3 < p.W;
+            const int nrows = CK * IH;
+            int c = 0, iy = sgrp;
+            while (iy >= IH) { iy -= IH; ++c; }
+            for (int r0s = sgrp; r0s < nrows; r0s += 16 * 5) {
+                float4 v[5], mk[5];
+                int cs[5], iys[5];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * 256 + threadIdx.x;
-                const int c = e / (IH * IW), rem = e - c * (IH * IW);
-                const int iy = rem / IW, ix = rem - iy * IW;
-                const int gy = iy0 + iy, gx = ix0 + ix, ci = c0 + c;
-                v[u] = 0.f; mk[u] = 1.f;
-                if (e < nel && ci < p.Cin && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                    const size_t off = ((size_t)b * p.Cin + ci) * plane_x + (size_t)gy * p.W + gx;
-                    v[u] = p.x[off];
-                    if (MASK) mk[u] = p.in_mask[off];
+                for (int u = 0; u < 5; ++u) {
+                    cs[u] = c; iys[u] = iy;
+                    const int gy = iy0 + iy, ci = c0 + c;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f); mk[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (r0s + 16 * u < nrows && slot_on && ci < p.Cin && gy >= 0 && gy < p.H) {
+                        const size_t off = ((size_t)b * p.Cin + ci) * plane_x + (size_t)gy * p.W;
+                        if (full) {
+                            v[u] = *reinterpret_cast<const float4*>(p.x + off + gx);
+                            if (MASK) mk[u] = *reinterpret_cast<const float4*>(p.in_mask + off + gx);
+                        } else {
+                            float* vv = reinterpret_cast<float*>(&v[u]);
+                            float* mm = reinterpret_cast<float*>(&mk[u]);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (lx + q < IW && gx + q >= 0 && gx + q < p.W) {
+                                    vv[q] = p.x[off + gx + q];
+                                    if (MASK) mm[q] = p.in_mask[off + gx + q];
+                                }
+                        }
+                    }
+                    iy += 16;
+                    while (iy >= IH) { iy -= IH; ++c; }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * 256 + threadIdx.x;
-                if (e < nel) {
-                    const int c = e / (IH * IW), rem = e - c * (IH * IW);
-                    const int iy = rem / IW, ix = rem - iy * IW;
-                    float t = v[u];
-                    if (MASK) t *= (mk[u] > 0.f) ? p.mask_pos : p.mask_neg;
-                    if (p.in_scale && c0 + c < p.Cin) t *= p.in_scale[(size_t)b * p.Cin + c0 + c];
-                    tile[(c * IH + iy) * IWp + ix] = t;
+                for (int u = 0; u < 5; ++u) {
+                    if (r0s + 16 * u < nrows && slot_on) {
+                        float sc = 1.f;
+                        if (p.in_scale && c0 + cs[u] < p.Cin) sc = p.in_scale[(size_t)b * p.Cin + c0 + cs[u]];
+                        const float* vv = reinterpret_cast<const float*>(&v[u]);
+                        const float* mm = reinterpret_cast<const float*>(&mk[u]);
+                        float* dst = tile + (cs[u] * IH + iys[u]) * IWp + lx;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (lx + q < IW) {
+                                float t = vv[q] * sc;
+                                if (MASK) t *= (mm[q] > 0.f) ? p.mask_pos : p.mask_neg;
+                                dst[q] = t;
+                            }
+                    }
                 }
             }
         }
@@ -419,14 +448,34 @@ __global__ __launch_bounds__(256) void conv_direct_small_kernel(const l2i_conv_p
         for (int c = 0; c < CK; ++c) {
             const float* tc = tile + (c * IH + r0) * IWp + col;
             const float4* wc = wl + c * KK;
-            for (int ky = 0; ky < p.KH; ++ky) {
-                for (int kx = 0; kx < p.KW; ++kx) {
-                    const float4 w4 = wc[ky * p.KW + kx];
-                    const float* tr = tc + ky * IWp + kx;
+            if constexpr (TKH > 0) {
+                float win[TKH + 3][TKW];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {                   // static register indexing only (no scratch)
-                        const float x = tr[r * IWp];
-                        acc[r][0] += x * w4.x; acc[r][1] += x * w4.y; acc[r][2] += x * w4.z; acc[r][3] += x * w4.w;
+                for (int y = 0; y < TKH + 3; ++y)
+#pragma unroll
+                    for (int xk = 0; xk < TKW; ++xk) win[y][xk] = tc[y * IWp + xk];
+#pragma unroll
+                for (int ky = 0; ky < TKH; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < TKW; ++kx) {
+                        const float4 w4 = wc[ky * TKW + kx];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x = win[r + ky][kx];
+                            acc[r][0] += x * w4.x; acc[r][1] += x * w4.y; acc[r][2] += x * w4.z; acc[r][3] += x * w4.w;
+                        }
+                    }
+                }
+            } else {
+                for (int ky = 0; ky < p.KH; ++ky) {
+                    for (int kx = 0; kx < p.KW; ++kx) {
+                        const float4 w4 = wc[ky * p.KW + kx];
+                        const float* tr = tc + ky * IWp + kx;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {                   // static register indexing only (no scratch)
+                            const float x = tr[r * IWp];
+                            acc[r][0] += x * w4.x; acc[r][1] += x * w4.y; acc[r][2] += x * w4.z; acc[r][3] += x * w4.w;
+                        }
                     }
                 }
             }
@@ -463,8 +512,20 @@ static int launch_direct_small(const l2i_conv_params& p, hipStream_t st) {
     const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 31) / 32;
     const long grid = (long)p.B * tiles_x * tiles_y;
     if (grid <= 0 || grid > 0x7fffffffL) return l2i_set_error(L2I_E_ARG, "conv2d(direct): grid too large");
-    if (p.in_mask) hipLaunchKernelGGL(conv_direct_small_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, ck, IH, IW, IWp);
-    else hipLaunchKernelGGL(conv_direct_small_kernel<false>, dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, ck, IH, IW, IWp);
+#define L2I_SMALL(TKH_, TKW_)                                                                                                              \
+    do {                                                                                                                              \
+        if (p.in_mask) hipLaunchKernelGGL((conv_direct_small_kernel<true, TKH_, TKW_>), dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, ck, IH, IW, IWp); \
+        else hipLaunchKernelGGL((conv_direct_small_kernel<false, TKH_, TKW_>), dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, ck, IH, IW, IWp);          \
+    } while (0)
+    // windows on the path: 3x3 (VGG / discriminator gradients onto RGB), 1x1 (from_rgb), and the 4x4 / 4x3 / 3x4 / 3x3 parity pieces of
+    // the ResNet stem's 7x7 stride-2 gradient
+    if (p.KH == 3 && p.KW == 3) L2I_SMALL(3, 3);
+    else if (p.KH == 4 && p.KW == 4) L2I_SMALL(4, 4);
+    else if (p.KH == 4 && p.KW == 3) L2I_SMALL(4, 3);
+    else if (p.KH == 3 && p.KW == 4) L2I_SMALL(3, 4);
+    else if (p.KH == 1 && p.KW == 1) L2I_SMALL(1, 1);
+    else L2I_SMALL(0, 0);
+#undef L2I_SMALL
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }
