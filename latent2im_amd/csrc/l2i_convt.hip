@@ -23,7 +23,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvTLaunch {
-    int tw_log2, th_log2, tb_log2;
+    int TW, TH, tb_log2;               // tile = 2^tb samples x TH rows x TW columns of positions (TW even; TW*TH*2^tb <= 128*WN slots)
+    unsigned magic_tw, magic_th;
     int tiles_x, tiles_y, bgroups, mblocks;
     int CK, IH, IW, IWp, planeS, plane, rows_c;
     unsigned magic_iw, magic_rc, magic_ih;
@@ -52,14 +53,14 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p
     float* lds_sc = lds_w + L.CK * KK * BM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
-    const int TW = 1 << L.tw_log2, TH = 1 << L.th_log2;
+    const int TW = L.TW, TH = L.TH;
     int bid = blockIdx.x;
     const int mblk = bid % L.mblocks; bid /= L.mblocks;
     const int tx = bid % L.tiles_x; bid /= L.tiles_x;
     const int ty = bid % L.tiles_y; bid /= L.tiles_y;
     const int b0 = bid << L.tb_log2;
     const int m0 = mblk * BM;
-    const int ty0 = ty << L.th_log2, tx0 = tx << L.tw_log2;        // tile origin in input-resolution positions t
+    const int ty0 = ty * TH, tx0 = tx * TW;                        // tile origin in input-resolution positions t
     const int iy0 = ty0 - P, ix0 = tx0 - P;                        // origin of the staged tile
 
     const int CKh = L.CK >> 1;
@@ -67,8 +68,12 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
         const int pi = (wave * WN + n) * 32 + j;
-        const int c = pi & (TW - 1), r = (pi >> L.tw_log2) & (TH - 1), tb = pi >> (L.tw_log2 + L.th_log2);
-        pixoff[n] = tb * L.planeS + r * L.IWp + c + half * CKh * L.plane;
+        const int rowi = (int)fast_div_t((unsigned)pi, L.magic_tw), c = pi - rowi * TW;
+        int tb = (int)fast_div_t((unsigned)rowi, L.magic_th);
+        int r = rowi - tb * TH;
+        const bool used = tb < (1 << L.tb_log2);                   // slots past TB*TH*TW (tiles that do not fill 128*WN positions) idle on pixel 0
+        if (!used) { tb = 0; r = 0; }
+        pixoff[n] = tb * L.planeS + r * L.IWp + (used ? c : 0) + half * CKh * L.plane;
         sbase[n] = tb * L.CK + half * CKh;
     }
     const int wlane = half * CKh * KK * BM + j;
@@ -198,9 +203,11 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
         const int pi = (wave * WN + n) * 32 + 2 * q4;      // input-resolution position of this lane's 4 outputs
-        const int tcol = tx0 + (pi & (TW - 1));
-        const int trow = ty0 + ((pi >> L.tw_log2) & (TH - 1));
-        const int bb = b0 + (pi >> (L.tw_log2 + L.th_log2));
+        const int rowi = (int)fast_div_t((unsigned)pi, L.magic_tw);
+        const int tbi = (int)fast_div_t((unsigned)rowi, L.magic_th);
+        const int tcol = tx0 + (pi - rowi * TW);
+        const int trow = ty0 + (rowi - tbi * TH);
+        const int bb = tbi < (1 << L.tb_log2) ? b0 + tbi : p.B;       // unused slots: no sample
         const int ox = 2 * tcol;
         const float* osc = (bb < p.B && p.out_scale) ? p.out_scale + (size_t)bb * p.Cout : nullptr;
 #pragma unroll
@@ -247,14 +254,33 @@ static int launch_convt(const l2i_conv_params& p, hipStream_t st) {
     constexpr int BM = 32, BN = 128 * WN, KK = K * K;
     ConvTLaunch L;
     const int Ty = (p.OHf + 1) / 2, Tx = (p.OWf + 1) / 2;       // input-resolution positions that own an output
-    L.tw_log2 = ilog2c(Tx < 32 ? Tx : 32);
-    const int TW = 1 << L.tw_log2;
-    int th = BN / TW;
-    const int ty_p2 = 1 << ilog2c(Ty);
-    if (th > ty_p2) th = ty_p2;
-    L.th_log2 = ilog2c(th);
-    const int TH = 1 << L.th_log2;
-    L.tb_log2 = ilog2c(BN / (TH * TW));
+    // pixel tile: small maps pack samples into power-of-two tiles; maps >= 32 positions wide (one sample per tile) take the
+    // even-width tile that wastes the fewest of the 128*WN slots on the (2H+1)-wide maps of pad 0 (65 positions: 22 x 11 tiles
+    // cover 66 x 66, the 32 x 8 grid 96 x 72).  Measured alternative, not kept: restricting the launch to H x W positions and
+    // computing the one-pixel edge row / column separately (thin l2i_conv2d_f32 launches or a dedicated VALU kernel) — the edge
+    // work walks all of Cin in a handful of blocks and cost more than the tiles it saved.
+    int TW, TH;
+    if (Tx < 32) {
+        TW = 1 << ilog2c(Tx);
+        int th = BN / TW;
+        const int ty_p2 = 1 << ilog2c(Ty);
+        if (th > ty_p2) th = ty_p2;
+        TH = 1 << ilog2c(th);
+        L.tb_log2 = ilog2c(BN / (TH * TW));
+    } else {
+        long best = -1;
+        TW = 32; TH = BN / 32;
+        for (int tw = 64; tw >= 8; tw -= 2) {
+            const int th = BN / tw;
+            const long tiles = (long)((Tx + tw - 1) / tw) * ((Ty + th - 1) / th);
+            const long cost = tiles * 4096 + (long)(th + G::P + G::Q) * (tw + G::P + G::Q) + (tw == 32 ? 0 : 1);   // ties: smaller halo, then 32 wide
+            if (best < 0 || cost < best) { best = cost; TW = tw; TH = th; }
+        }
+        L.tb_log2 = 0;
+    }
+    L.TW = TW; L.TH = TH;
+    L.magic_tw = TW == 1 ? 0u : magic_of((unsigned)TW);
+    L.magic_th = TH == 1 ? 0u : magic_of((unsigned)TH);
     const int TB = 1 << L.tb_log2;
     if ((size_t)TB * p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: sample group >= 4 GiB");
     L.tiles_x = (Tx + TW - 1) / TW;
@@ -313,3 +339,4 @@ extern "C" int l2i_conv_transpose2d_f32(const l2i_conv_params* pp, void* stream)
     if (p.KH == 7 && p.pad_y == 3) return launch_convt<7, 3, 2>(p, st);
     return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: fused kernel built for (K,pad) in {(3,0),(3,1),(7,3)}");
 }
+

@@ -27,6 +27,11 @@ SHAPES = [  # name, cin, cout, k, stride, pad, transposed, res, batch
     ('r_1x1_2048', 1024, 2048, 1, 1, 0, False, 32, 8),
     ('r_stem', 3, 64, 7, 2, 3, False, 1024, 8),
     ('v_64', 64, 64, 3, 1, 1, False, 1024, 4),
+    ('g_up128', 512, 256, 3, 2, 0, True, 64, 8),
+    ('g_up128_p1', 512, 256, 3, 2, 1, True, 64, 8),
+    ('g_up64', 512, 512, 3, 2, 0, True, 32, 8),
+    ('g_up64_p1', 512, 512, 3, 2, 1, True, 32, 8),
+    ('g_up512_p1', 128, 64, 3, 2, 1, True, 256, 8),
     ('r_256_1024', 256, 1024, 1, 1, 0, False, 64, 8),
     ('r_1024_256', 1024, 256, 1, 1, 0, False, 64, 8),
     ('r_2048_512', 2048, 512, 1, 1, 0, False, 32, 8),
