@@ -39,6 +39,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // arithmetic (and cannot see hazards inside asm: see pk_mul_op).
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // pk_mul_op: the product feeds an MFMA next, the 2 wait states of "VALU write -> MFMA read" ride in the same asm statement
 __device__ __forceinline__ f32x2 pk_mul_op(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // (a.lo + b.hi, a.lo - b.hi)
@@ -238,19 +239,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int chn = blk * 16 + 4 * kq + r;
-            float t0[4], t1[4];
+        for (int hp = 0; hp < 2; ++hp) {                           // accumulator rows (r, r+1) = channels (chn, chn+1) as one register pair
+            f32x2 a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = hp ? f32x2{acc[q][blk][2], acc[q][blk][3]} : f32x2{acc[q][blk][0], acc[q][blk][1]};
+            f32x2 t0[4], t1[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {                          // A^T M
-                t0[c] = acc[c][blk][r] + acc[4 + c][blk][r] + acc[8 + c][blk][r];
-                t1[c] = acc[4 + c][blk][r] - acc[8 + c][blk][r] - acc[12 + c][blk][r];
+                t0[c] = pk_add(pk_add(a[c], a[4 + c]), a[8 + c]);
+                t1[c] = pk_sub(pk_sub(a[4 + c], a[8 + c]), a[12 + c]);
             }
-            float2 y0, y1;
-            y0.x = t0[0] + t0[1] + t0[2]; y0.y = t0[1] - t0[2] - t0[3];
-            y1.x = t1[0] + t1[1] + t1[2]; y1.y = t1[1] - t1[2] - t1[3];
-            *reinterpret_cast<float2*>(&strip[chn * 64 + 2 * n]) = y0;
-            *reinterpret_cast<float2*>(&strip[chn * 64 + 32 + 2 * n]) = y1;
+            const f32x2 y00 = pk_add(pk_add(t0[0], t0[1]), t0[2]), y01 = pk_sub(pk_sub(t0[1], t0[2]), t0[3]);
+            const f32x2 y10 = pk_add(pk_add(t1[0], t1[1]), t1[2]), y11 = pk_sub(pk_sub(t1[1], t1[2]), t1[3]);
+            const int chn = blk * 16 + 4 * kq + 2 * hp;
+            float* s0 = &strip[chn * 64 + 2 * n];
+            s0[0] = y00.x; s0[1] = y01.x; s0[32] = y10.x; s0[33] = y11.x;
+            s0[64] = y00.y; s0[65] = y01.y; s0[96] = y10.y; s0[97] = y11.y;
         }
     }
     __syncthreads();                                   // epilogue tables visible (the strips themselves are per wave)
@@ -270,30 +274,36 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
         const int co = m0 + chn;
         float4 v = *reinterpret_cast<const float4*>(&strip[chn * 64 + row * 32 + col]);
         if (pok && co < p.Cout) {
-            const float sc = tab[32 + chn];
-            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+            const float sc = tab[32 + chn], bv = tab[64 + chn];
+            f32x2 va = {v.x, v.y}, vb = {v.z, v.w};
+            const f32x2 scp = {sc, sc};
+            va = pk_mul(va, scp); vb = pk_mul(vb, scp);
             const size_t oidx = ((size_t)b * p.Cout + co) * plane_o + poff;
             if (p.out_mask) {
                 const float4 mk = *reinterpret_cast<const float4*>(p.out_mask + oidx);
-                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                va.x = mk.x > 0.f ? va.x : 0.f; va.y = mk.y > 0.f ? va.y : 0.f; vb.x = mk.z > 0.f ? vb.x : 0.f; vb.y = mk.w > 0.f ? vb.y : 0.f;
             }
-            const float bv = tab[64 + chn];
-            v.x += nz.x + bv; v.y += nz.y + bv; v.z += nz.z + bv; v.w += nz.w + bv;
+            const f32x2 bvp = {bv, bv};
+            va = pk_add(va, pk_add(f32x2{nz.x, nz.y}, bvp)); vb = pk_add(vb, pk_add(f32x2{nz.z, nz.w}, bvp));
             if (p.residual) {
                 float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
                 if (p.res_mask) {
                     const float4 mk = *reinterpret_cast<const float4*>(p.res_mask + oidx);
                     rv.x = mk.x > 0.f ? rv.x : 0.f; rv.y = mk.y > 0.f ? rv.y : 0.f; rv.z = mk.z > 0.f ? rv.z : 0.f; rv.w = mk.w > 0.f ? rv.w : 0.f;
                 }
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                va = pk_add(va, f32x2{rv.x, rv.y}); vb = pk_add(vb, f32x2{rv.z, rv.w});
             }
-            if (p.act == L2I_ACT_LRELU) {
-                v.x = (v.x > 0.f ? v.x : v.x * p.act_slope) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.act_slope) * p.act_gain;
-                v.z = (v.z > 0.f ? v.z : v.z * p.act_slope) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.act_slope) * p.act_gain;
+            if (p.act == L2I_ACT_LRELU) {                          // max(v, slope v) == (v > 0 ? v : slope v) for 0 <= slope <= 1
+                const f32x2 slp = {p.act_slope, p.act_slope}, gnp = {p.act_gain, p.act_gain};
+                const f32x2 ta = pk_mul(va, slp), tb = pk_mul(vb, slp);
+                va = pk_mul(f32x2{__builtin_fmaxf(va.x, ta.x), __builtin_fmaxf(va.y, ta.y)}, gnp);
+                vb = pk_mul(f32x2{__builtin_fmaxf(vb.x, tb.x), __builtin_fmaxf(vb.y, tb.y)}, gnp);
             } else if (p.act == L2I_ACT_RELU) {
-                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                va.x = __builtin_fmaxf(va.x, 0.f); va.y = __builtin_fmaxf(va.y, 0.f); vb.x = __builtin_fmaxf(vb.x, 0.f); vb.y = __builtin_fmaxf(vb.y, 0.f);
             }
-            v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain;
+            const f32x2 ogp = {p.out_gain, p.out_gain};
+            va = pk_mul(va, ogp); vb = pk_mul(vb, ogp);
+            v = make_float4(va.x, va.y, vb.x, vb.y);
             if (p.accumulate) {
                 const float4 o = *reinterpret_cast<const float4*>(p.y + oidx);
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
