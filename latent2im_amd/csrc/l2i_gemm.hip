@@ -1,0 +1,187 @@
+// l2i_gemm.hip — 1x1 stride-1 convolution without prologue fusions (the forward bottleneck 1x1s of ResNet-50: half of its
+// launches) as a plain fp32 GEMM  y[co, px] = sum_ci w[ci, co] x[ci, px]  per sample.
+//
+// Same MFMA mapping as l2i_conv.hip (M = out-channels from the [Cin][CoutP] pack, N = pixels, v_mfma_f32_32x32x2_f32; lane
+// halves take channels p and p + CK/2 of a chunk), but built on what the Winograd kernel taught about this chip: a VALU
+// instruction costs ~4 cycles of fp32-MFMA time at any occupancy, while LDS and memory instructions ride free beside MFMAs.
+// With no mask / scale to apply, both operand tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds: an x row of 256
+// pixels is exactly one 1 KiB wave instruction) — no staging registers, no commit pass, no per-tap pointer arithmetic: the K
+// loop is ds_read + MFMA only (fragment addresses are lane base + compile-time offsets).  Double-buffered stages, one
+// barrier per 16-channel chunk, three blocks per CU.  Epilogue = the wide LDS-transposed one of l2i_conv.hip (bias,
+// residual (+mask), output mask, activation, gains, accumulate).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "l2i.h"
+#include "l2i_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace gm {
+constexpr int CK = 16, CKh = 8, BN = 256;              // channels per chunk, pixels per block (4 waves x 64)
+}
+
+template <int WM>
+__global__ __launch_bounds__(256, 3) void gemm1x1_kernel(const l2i_conv_params p, int tiles, int mblocks, int total) {
+    using namespace gm;
+    constexpr int BM = WM * 32;
+    constexpr int XS = CK * BN, WS = CK * BM, STAGE = XS + WS;     // floats per stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    // XCD-aware order: the channel blocks of one pixel tile run on the same XCD and share the x tile in its L2
+    const int G = gridDim.x;
+    int w = (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
+    if (w >= total) return;
+    const int mblk = w % mblocks; w /= mblocks;
+    const int tile = w % tiles;
+    const int b = w / tiles;
+    const int m0 = mblk * BM, px0 = tile * BN;
+    const size_t HW = (size_t)p.H * p.W;
+
+    const unsigned x_bytes = (unsigned)((size_t)p.Cin * HW * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.Cin * HW), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((size_t)p.Cin * p.CoutP * sizeof(float)), 0x00020000);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // x: wave k-th piece = row (k * 4 + wave) of the chunk, lane l = pixels px0 + 4 l .. + 3   (1 KiB contiguous in global and in LDS)
+    const unsigned xvoff = (unsigned)((px0 + lane * 4) * sizeof(float));
+    const unsigned xrow_b = (unsigned)(HW * sizeof(float));
+    // w: piece = 64 float4 = (256 / BM) rows of BM channels; float4 index q = piece * 64 + lane -> row q / (BM/4), column q % (BM/4)
+    constexpr int WV = BM / 4;                         // float4 per weight row
+    constexpr int WPIECES = CK * WV / 64;              // pieces per chunk (8 for BM = 128, 4 for BM = 64), spread over the 4 waves
+    constexpr int WPW = (WPIECES + 3) / 4;
+
+    auto issue = [&](int c0, float* stage) {
+        // inline asm, not the builtin: hipcc cannot tell the DMA target from the stage being read and would drain vmcnt before the
+        // next ds_read (see l2i_wino.hip)
+        const unsigned lds_x = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)stage;
+#pragma unroll
+        for (int k = 0; k < CK / 4; ++k) {
+            const int row = k * 4 + wave_u;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(xvoff), "s"(rs_x), "s"(__builtin_amdgcn_readfirstlane(lds_x + row * BN * 4)), "s"((unsigned)(c0 + row) * xrow_b));
+        }
+#pragma unroll
+        for (int k = 0; k < WPW; ++k) {
+            const int piece = k * 4 + wave_u;
+            if (piece < WPIECES) {
+                const int q = piece * 64 + lane;
+                const unsigned wv = (unsigned)((((q / WV)) * p.CoutP + m0 + (q % WV) * 4) * sizeof(float));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(wv), "s"(rs_w), "s"(__builtin_amdgcn_readfirstlane(lds_x + (XS + piece * 256) * 4)),
+                               "s"((unsigned)((size_t)c0 * p.CoutP * sizeof(float))));
+            }
+        }
+    };
+
+    f32x16 acc[WM][2];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int nchunks = p.Cin / CK;
+    issue(0, smem);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        float* st = smem + (ch & 1) * STAGE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's tiles have landed
+        __syncthreads();                                   // ... for every wave; the other stage is free to refill
+        if (ch + 1 < nchunks) issue((ch + 1) * CK, smem + ((ch + 1) & 1) * STAGE);
+        const float* xb = st + half * CKh * BN + wave * 64 + j;
+        const float* wb = st + XS + half * CKh * BM + j;
+#pragma unroll
+        for (int pp = 0; pp < CKh; ++pp) {
+            float a[WM], bb[2];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) a[m] = wb[pp * BM + m * 32];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bb[n] = xb[pp * BN + n * 32];
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                       // the stages become the transpose strips
+
+    // ---- epilogue (as l2i_conv.hip, epilogue A): per-wave LDS transpose -> 16-byte global accesses ----
+    float* reg = smem + wave * (32 * 64);                  // [32 channels][64 pixels] of this wave
+    const int ch_l = lane >> 4, px = (lane & 15) * 4;
+    const size_t pix = (size_t)px0 + wave * 64 + px;
+    const bool pok = pix < HW;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) reg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + q * 32 + j] = acc[m][q][r];
+#pragma unroll 2
+        for (int i = 0; i < 8; ++i) {
+            const int chn = i * 4 + ch_l;
+            const int co = m0 + m * 32 + chn;
+            float4 v = *reinterpret_cast<const float4*>(&reg[chn * 64 + px]);
+            if (pok && co < p.Cout) {
+                if (p.out_scale) { const float sc = p.out_scale[(size_t)b * p.Cout + co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+                const size_t oidx = ((size_t)b * p.Cout + co) * HW + pix;
+                if (p.out_mask) {
+                    const float4 mk = *reinterpret_cast<const float4*>(p.out_mask + oidx);
+                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                }
+                if (p.noise) {
+                    const float4 nz = *reinterpret_cast<const float4*>(p.noise + (size_t)b * HW + pix);
+                    v.x += nz.x * p.noise_w; v.y += nz.y * p.noise_w; v.z += nz.z * p.noise_w; v.w += nz.w * p.noise_w;
+                }
+                if (p.bias) { const float bv = p.bias[co]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
+                if (p.residual) {
+                    float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
+                    if (p.res_mask) {
+                        const float4 mk = *reinterpret_cast<const float4*>(p.res_mask + oidx);
+                        rv.x = mk.x > 0.f ? rv.x : 0.f; rv.y = mk.y > 0.f ? rv.y : 0.f; rv.z = mk.z > 0.f ? rv.z : 0.f; rv.w = mk.w > 0.f ? rv.w : 0.f;
+                    }
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                if (p.act == L2I_ACT_LRELU) {
+                    v.x = (v.x > 0.f ? v.x : v.x * p.act_slope) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.act_slope) * p.act_gain;
+                    v.z = (v.z > 0.f ? v.z : v.z * p.act_slope) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.act_slope) * p.act_gain;
+                } else if (p.act == L2I_ACT_RELU) {
+                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                }
+                v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain;
+                if (p.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(p.y + oidx);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *reinterpret_cast<float4*>(p.y + oidx) = v;
+            }
+        }
+    }
+}
+
+// eligibility: 1x1, stride 1, no padding, dense output window, no mask / scale prologue, whole 256-pixel tiles inside a sample
+bool l2i_gemm1x1_eligible(const l2i_conv_params& p) {
+    auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
+    const size_t HW = (size_t)p.H * p.W;
+    return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_y == 0 && p.pad_x == 0 && !p.in_mask && !p.in_scale && p.oy_step == 1 && p.ox_step == 1 &&
+           p.oy_off == 0 && p.ox_off == 0 && p.OH == p.H && p.OW == p.W && p.OHf == p.H && p.OWf == p.W && (HW % gm::BN) == 0 && (p.Cin % gm::CK) == 0 &&
+           (p.CoutP % 64) == 0 && al16(p.x) && al16(p.y) && al16(p.w) && al16(p.residual) && al16(p.res_mask) && al16(p.out_mask) && al16(p.noise) &&
+           (size_t)p.Cin * HW * sizeof(float) < 0xFFFFFFF0ull;
+}
+
+int l2i_launch_gemm1x1(const l2i_conv_params& p, hipStream_t st) {
+    const int tiles = (int)(((size_t)p.H * p.W) / gm::BN);
+    const bool wide = (p.CoutP % 128) == 0;
+    const int BM = wide ? 128 : 64;
+    const int mblocks = p.CoutP / BM;
+    const long total = (long)p.B * tiles * mblocks;
+    if (total <= 0 || total > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv2d(1x1 gemm): grid too large");
+    const unsigned grid = (unsigned)((total + 7) & ~7L);
+    const size_t lds = (size_t)2 * (gm::CK * gm::BN + gm::CK * BM) * sizeof(float);
+    if (wide) hipLaunchKernelGGL((gemm1x1_kernel<4>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
+    else hipLaunchKernelGGL((gemm1x1_kernel<2>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}

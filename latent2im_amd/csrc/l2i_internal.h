@@ -5,6 +5,10 @@
 
 int l2i_set_error(int code, const char* msg);   // records msg for l2i_last_error(), returns code
 
+struct l2i_conv_params;
+bool l2i_gemm1x1_eligible(const l2i_conv_params& p);              // l2i_gemm.hip: DMA-fed GEMM form of unmasked 1x1 stride-1 layers
+int l2i_launch_gemm1x1(const l2i_conv_params& p, hipStream_t st);
+
 #define L2I_CHECK_LAUNCH()                                                      \
     do {                                                                        \
         hipError_t e_ = hipGetLastError();                                      \

@@ -192,6 +192,30 @@ def test_winograd_3x3_conv(cin, cout, h, w, b):
     assert e0 < 5e-6, e0
 
 
+@pytest.mark.parametrize('cin,cout,h,w,b', [(64, 256, 32, 32, 2), (256, 64, 16, 64, 1), (1024, 256, 16, 16, 2), (128, 512, 16, 32, 3), (16, 64, 64, 64, 1)])
+def test_gemm_1x1_conv(cin, cout, h, w, b):
+    """Unmasked 1x1 stride-1 layers take the DMA-fed GEMM kernel (l2i_gemm.hip) inside l2i_conv2d_f32; same results as the generic
+    implicit-GEMM kernel (forced with a tile hint) and as a float64 reference, with the epilogue fusions ResNet-50 uses."""
+    rs = np.random.RandomState(cin + cout + h)
+    wt = T(rs.randn(cout, cin, 1, 1) / np.sqrt(cin))
+    x, bias = T(rs.randn(b, cin, h, w)), T(rs.randn(cout))
+    res, rmk, omk, y_prev = (T(rs.randn(b, cout, h, w)) for _ in range(4))
+    g = lambda t: t.to(DEV)
+    fc = conv.FrozenConv2d(wt, 1, 0, device=DEV)
+    D = lambda t: t.double()
+    c64 = F.conv2d(D(x), D(wt))
+    ref1 = torch.relu(c64 + D(bias)[None, :, None, None] + D(res))
+    ref2 = F.leaky_relu(torch.where(omk > 0, c64, torch.zeros_like(c64)) + torch.where(rmk > 0, D(res), torch.zeros_like(c64)), 0.2) * 2 ** 0.5 * 0.5 + D(y_prev)
+    for hint in (0, 2):                  # 0: GEMM kernel, 2: generic kernel
+        y1 = fc.forward(g(x), bias=g(bias), residual=g(res), act=conv.ACT_RELU, tile_hint=hint)
+        y2 = g(y_prev).clone()
+        fc.forward(g(x), out=y2, out_mask=g(omk), residual=g(res), res_mask=g(rmk), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5, out_gain=0.5,
+                   accumulate=True, tile_hint=hint)
+        for got, want in ((y1, ref1), (y2, ref2)):
+            err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+            assert err < 5e-6, (hint, err)
+
+
 def test_fused_bias_act_golden(golden):
     gd = golden('fused_bias_act')
     x, b, ref = (T(gd[k]).to(DEV) for k in ('x', 'b', 'ref'))
