@@ -1,10 +1,11 @@
-// l2i_gemm.hip — 1x1 stride-1 convolution without prologue fusions (the forward bottleneck 1x1s of ResNet-50: half of its
-// launches) as a plain fp32 GEMM  y[co, px] = sum_ci w[ci, co] x[ci, px]  per sample.
+// l2i_gemm.hip — 1x1 stride-1 convolution without a style scale (the bottleneck 1x1s of ResNet-50, forward and input-gradient:
+// half of its launches) as a plain fp32 GEMM  y[co, px] = sum_ci w[ci, co] x[ci, px]  per sample.
 //
 // Same MFMA mapping as l2i_conv.hip (M = out-channels from the [Cin][CoutP] pack, N = pixels, v_mfma_f32_32x32x2_f32; lane
 // halves take channels p and p + CK/2 of a chunk), but built on what the Winograd kernel taught about this chip: a VALU
 // instruction costs ~4 cycles of fp32-MFMA time at any occupancy, while LDS and memory instructions ride free beside MFMAs.
-// With no mask / scale to apply, both operand tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds: an x row of 256
+// Both operand tiles (and the activation-gradient mask tile of the backward launches, applied to the B fragments: 3 VALU per
+// 2*WM MFMAs) go global -> LDS by DMA (buffer_load_dwordx4 ... lds: an x row of 256
 // pixels is exactly one 1 KiB wave instruction) — no staging registers, no commit pass, no per-tap pointer arithmetic: the K
 // loop is ds_read + MFMA only (fragment addresses are lane base + compile-time offsets).  Double-buffered stages, one
 // barrier per 16-channel chunk, three blocks per CU.  Epilogue = the wide LDS-transposed one of l2i_conv.hip (bias,
@@ -21,11 +22,11 @@ namespace gm {
 constexpr int CK = 16, CKh = 8, BN = 256;              // channels per chunk, pixels per block (4 waves x 64)
 }
 
-template <int WM>
-__global__ __launch_bounds__(256, 3) void gemm1x1_kernel(const l2i_conv_params p, int tiles, int mblocks, int total) {
+template <int WM, bool MASK>
+__global__ __launch_bounds__(256, MASK ? 2 : 3) void gemm1x1_kernel(const l2i_conv_params p, int tiles, int mblocks, int total) {
     using namespace gm;
     constexpr int BM = WM * 32;
-    constexpr int XS = CK * BN, WS = CK * BM, STAGE = XS + WS;     // floats per stage
+    constexpr int XS = CK * BN, MS = MASK ? CK * BN : 0, WS = CK * BM, STAGE = XS + MS + WS;     // floats per stage: x | gradient mask | w
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(256, 3) void gemm1x1_kernel(const l2i_conv_params p
 
     const unsigned x_bytes = (unsigned)((size_t)p.Cin * HW * sizeof(float));
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.Cin * HW), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)((MASK ? p.in_mask : p.x) + (size_t)b * p.Cin * HW), 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((size_t)p.Cin * p.CoutP * sizeof(float)), 0x00020000);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // x: wave k-th piece = row (k * 4 + wave) of the chunk, lane l = pixels px0 + 4 l .. + 3   (1 KiB contiguous in global and in LDS)
@@ -61,6 +63,9 @@ __global__ __launch_bounds__(256, 3) void gemm1x1_kernel(const l2i_conv_params p
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(xvoff), "s"(rs_x), "s"(__builtin_amdgcn_readfirstlane(lds_x + row * BN * 4)), "s"((unsigned)(c0 + row) * xrow_b));
+            if constexpr (MASK)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(xvoff), "s"(rs_m), "s"(__builtin_amdgcn_readfirstlane(lds_x + (XS + row * BN) * 4)), "s"((unsigned)(c0 + row) * xrow_b));
         }
 #pragma unroll
         for (int k = 0; k < WPW; ++k) {
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(256, 3) void gemm1x1_kernel(const l2i_conv_params p
                 const unsigned wv = (unsigned)((((q / WV)) * p.CoutP + m0 + (q % WV) * 4) * sizeof(float));
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(wv), "s"(rs_w), "s"(__builtin_amdgcn_readfirstlane(lds_x + (XS + piece * 256) * 4)),
+                             : "=&s"(keep) : "v"(wv), "s"(rs_w), "s"(__builtin_amdgcn_readfirstlane(lds_x + (XS + MS + piece * 256) * 4)),
                                "s"((unsigned)((size_t)c0 * p.CoutP * sizeof(float))));
             }
         }
@@ -92,14 +97,17 @@ __global__ __launch_bounds__(256, 3) void gemm1x1_kernel(const l2i_conv_params p
         __syncthreads();                                   // ... for every wave; the other stage is free to refill
         if (ch + 1 < nchunks) issue((ch + 1) * CK, smem + ((ch + 1) & 1) * STAGE);
         const float* xb = st + half * CKh * BN + wave * 64 + j;
-        const float* wb = st + XS + half * CKh * BM + j;
+        const float* wb = st + XS + MS + half * CKh * BM + j;
 #pragma unroll
         for (int pp = 0; pp < CKh; ++pp) {
             float a[WM], bb[2];
 #pragma unroll
             for (int m = 0; m < WM; ++m) a[m] = wb[pp * BM + m * 32];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) bb[n] = xb[pp * BN + n * 32];
+            for (int n = 0; n < 2; ++n) {
+                bb[n] = xb[pp * BN + n * 32];
+                if constexpr (MASK) bb[n] *= (xb[XS + pp * BN + n * 32] > 0.f) ? p.mask_pos : p.mask_neg;   // activation-gradient mask: 3 VALU per fragment
+            }
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -161,27 +169,41 @@ __global__ __launch_bounds__(256, 3) void gemm1x1_kernel(const l2i_conv_params p
     }
 }
 
-// eligibility: 1x1, stride 1, no padding, dense output window, no mask / scale prologue, whole 256-pixel tiles inside a sample
+// eligibility: 1x1, stride 1, no padding, dense output window, no style scale, whole 256-pixel tiles inside a sample
 bool l2i_gemm1x1_eligible(const l2i_conv_params& p) {
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
     const size_t HW = (size_t)p.H * p.W;
-    return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_y == 0 && p.pad_x == 0 && !p.in_mask && !p.in_scale && p.oy_step == 1 && p.ox_step == 1 &&
+    return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_y == 0 && p.pad_x == 0 && !p.in_scale && p.oy_step == 1 && p.ox_step == 1 &&
            p.oy_off == 0 && p.ox_off == 0 && p.OH == p.H && p.OW == p.W && p.OHf == p.H && p.OWf == p.W && (HW % gm::BN) == 0 && (p.Cin % gm::CK) == 0 &&
-           (p.CoutP % 64) == 0 && al16(p.x) && al16(p.y) && al16(p.w) && al16(p.residual) && al16(p.res_mask) && al16(p.out_mask) && al16(p.noise) &&
+           (p.CoutP % 64) == 0 && al16(p.x) && al16(p.in_mask) && al16(p.y) && al16(p.w) && al16(p.residual) && al16(p.res_mask) && al16(p.out_mask) && al16(p.noise) &&
            (size_t)p.Cin * HW * sizeof(float) < 0xFFFFFFF0ull;
 }
 
 int l2i_launch_gemm1x1(const l2i_conv_params& p, hipStream_t st) {
     const int tiles = (int)(((size_t)p.H * p.W) / gm::BN);
-    const bool wide = (p.CoutP % 128) == 0;
+    const bool wide = (p.CoutP % 128) == 0 && (long)p.B * tiles * (p.CoutP / 128) >= 512;     // small grids: 64-channel blocks fill more CUs
     const int BM = wide ? 128 : 64;
     const int mblocks = p.CoutP / BM;
     const long total = (long)p.B * tiles * mblocks;
     if (total <= 0 || total > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv2d(1x1 gemm): grid too large");
     const unsigned grid = (unsigned)((total + 7) & ~7L);
-    const size_t lds = (size_t)2 * (gm::CK * gm::BN + gm::CK * BM) * sizeof(float);
-    if (wide) hipLaunchKernelGGL((gemm1x1_kernel<4>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
-    else hipLaunchKernelGGL((gemm1x1_kernel<2>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
+    const bool mask = p.in_mask != nullptr;
+    const size_t lds = (size_t)2 * (gm::CK * gm::BN * (mask ? 2 : 1) + gm::CK * BM) * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            done = true;
+        }
+    }
+    if (wide) {
+        if (mask) hipLaunchKernelGGL((gemm1x1_kernel<4, true>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
+        else hipLaunchKernelGGL((gemm1x1_kernel<4, false>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
+    } else {
+        if (mask) hipLaunchKernelGGL((gemm1x1_kernel<2, true>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
+        else hipLaunchKernelGGL((gemm1x1_kernel<2, false>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
+    }
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }

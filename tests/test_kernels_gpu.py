@@ -206,8 +206,13 @@ def test_gemm_1x1_conv(cin, cout, h, w, b):
     c64 = F.conv2d(D(x), D(wt))
     ref1 = torch.relu(c64 + D(bias)[None, :, None, None] + D(res))
     ref2 = F.leaky_relu(torch.where(omk > 0, c64, torch.zeros_like(c64)) + torch.where(rmk > 0, D(res), torch.zeros_like(c64)), 0.2) * 2 ** 0.5 * 0.5 + D(y_prev)
+    msk = T(rs.randn(b, cin, h, w))
+    xm = D(x) * torch.where(msk > 0, torch.tensor(1.0, dtype=torch.float64), torch.tensor(0.2, dtype=torch.float64))
+    ref3 = F.conv2d(xm, D(wt)) + torch.where(rmk > 0, D(res), torch.zeros_like(c64))
     for hint in (0, 2):                  # 0: GEMM kernel, 2: generic kernel
         y1 = fc.forward(g(x), bias=g(bias), residual=g(res), act=conv.ACT_RELU, tile_hint=hint)
+        y3 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.2), residual=g(res), res_mask=g(rmk), tile_hint=hint)
+        assert float((y3.double().cpu() - ref3).abs().max() / ref3.abs().max()) < 5e-6, hint
         y2 = g(y_prev).clone()
         fc.forward(g(x), out=y2, out_mask=g(omk), residual=g(res), res_mask=g(rmk), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5, out_gain=0.5,
                    accumulate=True, tile_hint=hint)
