@@ -162,7 +162,7 @@ def main():
         exe_flop = tot_flop - sum(q[2] for q in wino) * (1.0 - 16.0 / 36.0)      # F(2x2,3x3): 16 multiplies per 2x2 tile instead of 36
         exe = exe_flop / (tot_ms * 1e-3) / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if a.precision == 'f32' else PEAK_BF16_MFMA_TFLOPS
-        roof = dict(bound='mfma', kernel='conv_wino_kernel / conv_mfma_kernel / convt_mfma_kernel (l2i_conv2d_wino_f32, l2i_conv2d_f32, l2i_conv_transpose2d_f32)' if a.precision == 'f32'
+        roof = dict(bound='mfma', kernel='conv_wino_kernel / conv_mfma_kernel + gemm1x1_kernel / convt_mfma_kernel (l2i_conv2d_wino_f32, l2i_conv2d_f32, l2i_conv_transpose2d_f32)' if a.precision == 'f32'
                     else 'conv_bf16x3_kernel + fp32 kernels for ineligible layers (algorithmic FLOPs; the split executes 3 MFMA FLOPs per algorithmic FLOP)',
                     achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                     launches_per_step=len(prof) // a.steps, avg_launch_ms=round(tot_ms / len(prof), 4),
