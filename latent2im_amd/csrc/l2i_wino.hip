@@ -113,26 +113,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
     unsigned rmk[MASK ? NIN : 1];
     unsigned rsc = 0;
 
-    auto issue = [&](int c0, float* ustage) {
-        const unsigned so = (unsigned)c0 * plane_b;
-#pragma unroll
-        for (int u = 0; u < NIN; ++u) {
-            rin[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff[u], so, 0);
-            if constexpr (MASK) rmk[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, voff[u], so, 0);
-        }
-        rsc = __builtin_amdgcn_raw_buffer_load_b32(rs_s, svoff, (unsigned)(c0 * sizeof(float)), 0);
-        const unsigned sw = (unsigned)((size_t)c0 * 4 * p.CoutP * 16);
-        // U: global -> LDS without registers (buffer_load_dwordx4 ... lds: lane l of the wave lands at M0 base + 16 l).  Written
-        // as inline asm on purpose: through the builtin, hipcc cannot tell the DMA's LDS target from the stage being read and
-        // puts s_waitcnt vmcnt(0) in front of the next ds_read — the whole prefetch (raw tile loads included) would be drained
-        // before the MFMAs start.  The explicit vmcnt(0) before the publishing barrier is in the chunk loop.
-        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(ustage + wave_u * 256);
-#pragma unroll
-        for (int k = 0; k < NWV; ++k) {
+    // Staging of the next chunk, one slot at a time: slots 0..NWV-1 = U pieces, global -> LDS without registers (buffer_load_dwordx4
+    // ... lds: lane l of the wave lands at M0 base + 16 l; inline asm on purpose: through the builtin, hipcc cannot tell the DMA's
+    // LDS target from the stage being read and drains vmcnt before the next ds_read; the explicit vmcnt(0) before the publishing
+    // barrier is in the chunk loop), slots NWV.. = raw halo elements (+ the style scale) into registers.  `on` = false (no next
+    // chunk) swaps in null descriptors: no traffic, zeros.  compute() issues two slots per MFMA group, between the MFMAs.
+    const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0u, 0x00020000);
+    constexpr int NSLOT = NWV + NIN + 1;
+    auto issue_slot = [&](int sl, int c0, float* ustage, bool on) {
+        if (sl < NWV) {
+            const unsigned sw = (unsigned)((size_t)c0 * 4 * p.CoutP * 16);
+            const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(ustage + wave_u * 256);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(wvoff), "s"(rs_w), "s"(__builtin_amdgcn_readfirstlane(lds0 + k * 4096)), "s"(sw + k * wstep));
+                         : "=&s"(keep) : "v"(wvoff), "s"(on ? rs_w : rs_null), "s"(__builtin_amdgcn_readfirstlane(lds0 + sl * 4096)), "s"(sw + sl * wstep));
+        } else if (sl < NWV + NIN) {
+            const int u = sl - NWV;
+            const unsigned so = (unsigned)c0 * plane_b;
+            rin[u] = __builtin_amdgcn_raw_buffer_load_b32(on ? rs_x : rs_null, voff[u], so, 0);
+            if constexpr (MASK) rmk[u] = __builtin_amdgcn_raw_buffer_load_b32(on ? rs_m : rs_null, voff[u], so, 0);
+        } else if (sl == NWV + NIN) {
+            rsc = __builtin_amdgcn_raw_buffer_load_b32(on ? rs_s : rs_null, svoff, (unsigned)(c0 * sizeof(float)), 0);
         }
+    };
+    auto issue = [&](int c0, float* ustage) {
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) issue_slot(sl, c0, ustage, true);
     };
     auto commit = [&](int par) {
         float* raw = rawbuf + par * RAWBUF;
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
     f32x4 acc[16][2];                                  // first defined by the MFMAs of the peeled first chunk (C = 0 constant)
 
     // ---- one chunk: 2 K-steps of 4 channels; lane (kq, n) transforms the patch of (channel 4 s + kq, tile (wave, n)) ----
-    auto compute = [&](int par, auto first_tag) {
+    auto compute = [&](int par, auto first_tag, int c0n, float* un, bool on) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const float4* u4 = reinterpret_cast<const float4*>(ubuf + par * NU4 * 4) + n;
@@ -195,6 +201,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
                 const float4 a0 = a0n, a1 = a1n;
                 if (i < 3) fetch_a(s, i + 1);
                 else if (s == 0) fetch_a(1, 0);
+                issue_slot(2 * (4 * s + i), c0n, un, on);            // next chunk: two staging slots per MFMA group, issued beside the MFMAs
+                issue_slot(2 * (4 * s + i) + 1, c0n, un, on);
                 __builtin_amdgcn_sched_barrier(0);
                 // (B^T d) B: (v0, v3) = (t0 - t2, t1 - t3);  (v1, v2) = (t2 + t1, t2 - t1); then the style scale of the channel
                 const f32x2 v03 = pk_mul_op(pk_sub(t01[i], t23[i]), scp);
@@ -211,21 +219,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
         }
     };
 
+    static_assert(wg::NWV + wg::NIN + 1 <= 16, "two staging slots per MFMA group, 8 groups per chunk");
     issue(0, ubuf);
     commit(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the chunk's U DMA has landed
     __syncthreads();
-    if (1 < L.nchunks) issue(CK, ubuf + NU4 * 4);
-    compute(0, std::true_type());
+    compute(0, std::true_type(), CK, ubuf + NU4 * 4, 1 < L.nchunks);
     for (int ch = 1; ch < L.nchunks; ++ch) {
         const int par = ch & 1;
         commit(par);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's U DMA (issued one chunk ago) has landed
         __syncthreads();                                   // raw tile of this chunk written; every wave is past the MFMAs of the previous chunk,
                                                            // so the other raw / U stage may be refilled
-        if (ch + 1 < L.nchunks) issue((ch + 1) * CK, ubuf + (par ^ 1) * NU4 * 4);
-        compute(par, std::false_type());
+        compute(par, std::false_type(), (ch + 1) * CK, ubuf + (par ^ 1) * NU4 * 4, ch + 1 < L.nchunks);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (null-descriptor DMA of the last chunk)
     __syncthreads();                                       // the U stages become the transpose strips
 
     // ---- epilogue: lane-local inverse transform -> per-wave LDS transpose (aliases the U stages) -> 16-byte accesses ----
