@@ -53,31 +53,28 @@ __global__ __launch_bounds__(256, MASK ? 2 : 3) void gemm1x1_kernel(const l2i_co
     constexpr int WPIECES = CK * WV / 64;              // pieces per chunk (8 for BM = 128, 4 for BM = 64), spread over the 4 waves
     constexpr int WPW = (WPIECES + 3) / 4;
 
-    auto issue = [&](int c0, float* stage) {
-        // inline asm, not the builtin: hipcc cannot tell the DMA target from the stage being read and would drain vmcnt before the
-        // next ds_read (see l2i_wino.hip)
+    // Staging of the next chunk in DMA slots (inline asm, not the builtin: hipcc cannot tell the DMA target from the stage being read
+    // and would drain vmcnt before the next ds_read, see l2i_wino.hip): slots 0..3 = x rows (k*4 + wave) (+ the mask rows), slots
+    // 4..4+WPW-1 = weight pieces.  The K loop issues one slot per k-pair, between the MFMAs; `on` = false swaps in null descriptors.
+    const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0u, 0x00020000);
+    auto issue_slot = [&](int sl, int c0, float* stage, bool on) {
         const unsigned lds_x = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)stage;
-#pragma unroll
-        for (int k = 0; k < CK / 4; ++k) {
-            const int row = k * 4 + wave_u;
-            unsigned keep;
+        unsigned keep;
+        if (sl < CK / 4) {
+            const int row = sl * 4 + wave_u;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(xvoff), "s"(rs_x), "s"(__builtin_amdgcn_readfirstlane(lds_x + row * BN * 4)), "s"((unsigned)(c0 + row) * xrow_b));
+                         : "=&s"(keep) : "v"(xvoff), "s"(on ? rs_x : rs_null), "s"(__builtin_amdgcn_readfirstlane(lds_x + row * BN * 4)), "s"((unsigned)(c0 + row) * xrow_b));
             if constexpr (MASK)
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(xvoff), "s"(rs_m), "s"(__builtin_amdgcn_readfirstlane(lds_x + (XS + row * BN) * 4)), "s"((unsigned)(c0 + row) * xrow_b));
-        }
-#pragma unroll
-        for (int k = 0; k < WPW; ++k) {
-            const int piece = k * 4 + wave_u;
-            if (piece < WPIECES) {
-                const int q = piece * 64 + lane;
-                const unsigned wv = (unsigned)((((q / WV)) * p.CoutP + m0 + (q % WV) * 4) * sizeof(float));
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(wv), "s"(rs_w), "s"(__builtin_amdgcn_readfirstlane(lds_x + (XS + MS + piece * 256) * 4)),
-                               "s"((unsigned)((size_t)c0 * p.CoutP * sizeof(float))));
-            }
+                             : "=&s"(keep) : "v"(xvoff), "s"(on ? rs_m : rs_null), "s"(__builtin_amdgcn_readfirstlane(lds_x + (XS + row * BN) * 4)), "s"((unsigned)(c0 + row) * xrow_b));
+        } else if (sl < CK / 4 + WPW) {
+            const int piece = (sl - CK / 4) * 4 + wave_u;
+            const int q = (piece < WPIECES ? piece : 0) * 64 + lane;
+            const unsigned wv = (unsigned)((((q / WV)) * p.CoutP + m0 + (q % WV) * 4) * sizeof(float));
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(wv), "s"((on && piece < WPIECES) ? rs_w : rs_null),
+                           "s"(__builtin_amdgcn_readfirstlane(lds_x + (XS + MS + (piece < WPIECES ? piece : 0) * 256) * 4)),
+                           "s"((unsigned)((size_t)c0 * p.CoutP * sizeof(float))));
         }
     };
 
@@ -90,12 +87,14 @@ __global__ __launch_bounds__(256, MASK ? 2 : 3) void gemm1x1_kernel(const l2i_co
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     const int nchunks = p.Cin / CK;
-    issue(0, smem);
+#pragma unroll
+    for (int sl = 0; sl < CK / 4 + WPW; ++sl) issue_slot(sl, 0, smem, true);
     for (int ch = 0; ch < nchunks; ++ch) {
         float* st = smem + (ch & 1) * STAGE;
+        float* nx = smem + ((ch + 1) & 1) * STAGE;
+        const bool on = ch + 1 < nchunks;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's tiles have landed
         __syncthreads();                                   // ... for every wave; the other stage is free to refill
-        if (ch + 1 < nchunks) issue((ch + 1) * CK, smem + ((ch + 1) & 1) * STAGE);
         const float* xb = st + half * CKh * BN + wave * 64 + j;
         const float* wb = st + XS + MS + half * CKh * BM + j;
 #pragma unroll
@@ -108,12 +107,14 @@ __global__ __launch_bounds__(256, MASK ? 2 : 3) void gemm1x1_kernel(const l2i_co
                 bb[n] = xb[pp * BN + n * 32];
                 if constexpr (MASK) bb[n] *= (xb[XS + pp * BN + n * 32] > 0.f) ? p.mask_pos : p.mask_neg;   // activation-gradient mask: 3 VALU per fragment
             }
+            issue_slot(pp, (ch + 1) * CK, nx, on);         // next chunk, one DMA slot per k-pair, beside the MFMAs
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[n], acc[m][n], 0, 0, 0);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (null-descriptor DMA of the last chunk)
     __syncthreads();                                       // the stages become the transpose strips
 
     // ---- epilogue (as l2i_conv.hip, epilogue A): per-wave LDS transpose -> 16-byte global accesses ----
