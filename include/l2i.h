@@ -76,6 +76,10 @@ typedef struct l2i_conv_params {
     int32_t tile_hint;      /* 0 = auto, else 1..N selects a tile configuration (tuning / tests) */
     const void* w_hi;       /* l2i_conv2d_bf16x3_f32 only: bf16 planes [Cin/16][KH*KW][CoutP][2][8], hi = bf16(w), */
     const void* w_lo;       /*                              lo = bf16(w - hi); NULL for the fp32 entry points */
+    float* ws;              /* l2i_conv2d_f32 split-K workspace: ksplit * B*Cout*OHf*OWf floats, or NULL */
+    int32_t ksplit;         /* > 1: the input channels are cut into ksplit ranges computed by separate blocks (raw partial sums in ws),
+                               then one reduction pass applies the epilogue: for 4x4..16x16 maps, whose whole K = Cin*KH*KW would
+                               otherwise be walked serially by a dozen blocks.  0 / 1: off. */
 } l2i_conv_params;
 
 int l2i_conv2d_f32(const l2i_conv_params* p, void* stream);

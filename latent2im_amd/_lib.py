@@ -33,6 +33,7 @@ class ConvParams(ctypes.Structure):
         ('act', c_i), ('act_slope', c_f), ('act_gain', c_f), ('out_gain', c_f),
         ('accumulate', c_i), ('tile_hint', c_i),
         ('w_hi', c_p), ('w_lo', c_p),
+        ('ws', c_p), ('ksplit', c_i),
     ]
 
 

@@ -19,6 +19,8 @@ import os as _os
 
 PRECISION = _os.environ.get('L2I_PRECISION', 'f32')      # 'bf16x3': eligible stride-1 layers take the split-precision bf16 MFMA kernel (opt-in)
 USE_WINOGRAD = _os.environ.get('L2I_WINOGRAD', '1') != '0'    # 3x3 stride-1 layers on maps >= 32 wide take the F(2x2,3x3) fp32 kernel
+SPLIT_K = _os.environ.get('L2I_SPLIT_K', '1') != '0'    # 4x4 .. 16x16 maps: cut Cin into ranges computed by separate blocks (l2i.h: ksplit / ws)
+_WS = {}            # split-K workspaces, one per (device, stream)
 USE_FUSED_TRANSPOSED = True     # False: issue stride-2 transposed convs as four per-parity launches
 PROFILE = None      # bench.py sets this to a list: every launch then appends (start_event, end_event, algorithmic_flops, shape, entry point)
 
@@ -180,6 +182,22 @@ class FusedTransposed:
         return self
 
 
+def _split_k(p, px, cin, y):
+    """Small maps (<= 2048 positions per launch) with many input channels: cut Cin into ranges computed by separate blocks."""
+    if not (SPLIT_K and px <= 2048 and cin >= 256):
+        return
+    ks = 16 if px <= 128 else (8 if px <= 512 else 4)
+    while ks > 1 and (cin % ks or (cin // ks) % 2 or cin // ks < 16):
+        ks //= 2
+    if ks > 1:
+        need = ks * y.numel()
+        key = (y.device, torch.cuda.current_stream(y.device).cuda_stream)      # the loss branches run on their own streams
+        ws = _WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _WS[key] = torch.empty(max(need, 1 << 22), device=y.device, dtype=torch.float32)
+        p.ws, p.ksplit = _lib.fptr(ws), ks
+
+
 def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), out_scale=None, out_gain=1.0, tile_hint=0):
     lib = _lib.load()
     B, cin, H, W = x.shape
@@ -198,6 +216,7 @@ def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), 
     p.act_gain, p.out_gain = 1.0, out_gain
     if in_mask is not None:
         assert in_mask.shape == x.shape
+    _split_k(p, B * H * W, cin, y)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -246,6 +265,8 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
     if out_mask is not None:
         assert out_mask.shape == y.shape
     entry, name = lib.l2i_conv2d_f32, 'l2i_conv2d_f32'
+    if L.kh * L.kw > 1 and L.cout > 4:
+        _split_k(p, B * OH * OW, cin, y)
     if PRECISION == 'bf16x3' and L.step == 1 and OW >= 32 and L.w_src is not None and L.cin % 16 == 0 and L.cout > 4 and L.kh * L.kw > 1:     # 1x1 layers are HBM-bound
         planes = L.bf16x3_planes()
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])

@@ -43,6 +43,7 @@ struct ConvLaunch {
     int w_vec;                         // CK*KK*BM/4
     int vec_epi;                       // 1: LDS-transposed epilogue with 16-byte global accesses
     int lstride, gstep;                // LDS-coordinate stride of the fragment reads / global step between staged elements
+    int ksplit, cin_per;               // split-K: ksplit channel ranges of cin_per (multiple of CK) channels, raw partial sums into p.ws
                                        // (stride-2 1x1 convs gather only the pixels they use: lstride 1, gstep 2)
 };
 
@@ -73,10 +74,14 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
     const int mblk = bid % L.mblocks; bid /= L.mblocks;
     const int tx = bid % L.tiles_x; bid /= L.tiles_x;
     const int ty = bid % L.tiles_y; bid /= L.tiles_y;
-    const int b0 = bid << L.tb_log2;
+    const int bgrp = bid % L.bgroups;
+    const int split = bid / L.bgroups;                  // 0 unless split-K
+    const int b0 = bgrp << L.tb_log2;
     const int m0 = mblk * BM;
     const int oy0 = ty << L.th_log2, ox0 = tx << L.tw_log2;
     const int iy0 = oy0 * p.stride - p.pad_y, ix0 = ox0 * p.stride - p.pad_x;
+    const int c_begin = split * L.cin_per;
+    const int c_end = (c_begin + L.cin_per < p.Cin) ? c_begin + L.cin_per : p.Cin;
 
     // ---- per-lane fragment bases: pixel index within the tile = q*32 + j -> (tb, row, col) ----
     const int CKh = L.CK >> 1;
@@ -202,11 +207,11 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
 #pragma unroll
     for (int n = 0; n < WN; ++n) sbase[n] = ((((wave * WN + n) * 32 + j) >> (L.tw_log2 + L.th_log2)) * L.CK) + half * CKh;
 
-    issue(0);
-    for (int c0 = 0; c0 < p.Cin; c0 += L.CK) {
+    issue(c_begin);
+    for (int c0 = c_begin; c0 < c_end; c0 += L.CK) {
         commit();
         __syncthreads();
-        if (c0 + L.CK < p.Cin) issue(c0 + L.CK);        // in flight during the MFMA loop below
+        if (c0 + L.CK < c_end) issue(c0 + L.CK);        // in flight during the MFMA loop below
         // ---- MFMA over the chunk: lanes 0-31 take channel cc, lanes 32-63 channel cc + CK/2 ----
         for (int cc = 0; cc < CKh; ++cc) {
             const float* wr = lds_w + wlane + cc * KK * BM;
@@ -239,6 +244,28 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
     //      low-K layers; after the transpose a lane owns 4 consecutive pixels of one channel: 4x fewer, 4x wider
     //      global instructions for y, residual, masks and noise alike.
     const size_t plane_o = (size_t)p.OHf * p.OWf;
+    if (L.ksplit > 1) {
+        // split-K: raw partial sums of this channel range, laid out like y; splitk_epilogue_kernel reduces them and applies the fusions
+        float* wsp = p.ws + (size_t)split * p.B * p.Cout * plane_o;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int pi = (wave * WN + n) * 32 + j;
+            const int ox = ox0 + (pi & (TW - 1));
+            const int oy = oy0 + ((pi >> L.tw_log2) & (TH - 1));
+            const int bb = b0 + (pi >> (L.tw_log2 + L.th_log2));
+            if (oy < p.OH && ox < p.OW && bb < p.B) {
+                const size_t poff = (size_t)(oy * p.oy_step + p.oy_off) * p.OWf + ox * p.ox_step + p.ox_off;
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = m0 + 4 * half + m * 32 + (r & 3) + 8 * (r >> 2);
+                        if (co < p.Cout) wsp[((size_t)bb * p.Cout + co) * plane_o + poff] = acc[m][n][r];
+                    }
+            }
+        }
+        return;
+    }
     if (L.vec_epi) {
         float* reg = smem + wave * (32 * 64);           // [32 channels][64 pixels] of this wave; the K loop is done
         const int ch_l = lane >> 4;                     // channel row within a group of 4
@@ -531,6 +558,44 @@ static int launch_direct_small(const l2i_conv_params& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Split-K second pass: y = epilogue(sum_s ws[s]) over the output window of the launch, same fusion order as the conv epilogues.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const l2i_conv_params p, long long total) {
+    const size_t plane_o = (size_t)p.OHf * p.OWf;
+    const size_t per_split = (size_t)p.B * p.Cout * plane_o;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % p.OW);
+        const int oy = (int)((i / p.OW) % p.OH);
+        const long long bc = i / ((long long)p.OW * p.OH);
+        const int co = (int)(bc % p.Cout), bb = (int)(bc / p.Cout);
+        const size_t poff = (size_t)(oy * p.oy_step + p.oy_off) * p.OWf + ox * p.ox_step + p.ox_off;
+        const size_t oidx = ((size_t)bb * p.Cout + co) * plane_o + poff;
+        float v = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) v += p.ws[(size_t)s * per_split + oidx];
+        if (p.out_scale) v *= p.out_scale[(size_t)bb * p.Cout + co];
+        if (p.out_mask) v = (p.out_mask[oidx] > 0.f) ? v : 0.f;
+        if (p.noise) v += p.noise[(size_t)bb * plane_o + poff] * p.noise_w;
+        if (p.bias) v += p.bias[co];
+        if (p.residual) {
+            float rv = p.residual[oidx];
+            if (p.res_mask) rv = (p.res_mask[oidx] > 0.f) ? rv : 0.f;
+            v += rv;
+        }
+        if (p.act == L2I_ACT_LRELU) v = (v > 0.f ? v : v * p.act_slope) * p.act_gain;
+        else if (p.act == L2I_ACT_RELU) v = v > 0.f ? v : 0.f;
+        v *= p.out_gain;
+        if (p.accumulate) v += p.y[oidx];
+        p.y[oidx] = v;
+    }
+}
+
+int l2i_launch_splitk_epilogue(const l2i_conv_params& q, hipStream_t st) {
+    const long long total = (long long)q.B * q.Cout * q.OH * q.OW;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(l2i_grid_for(total, 256)), dim3(256), 0, st, q, total);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 static int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static unsigned magic_for(unsigned d) { return (unsigned)((0x100000000ULL + d - 1) / d); }    // exact while n*d < 2^32
 
@@ -593,6 +658,15 @@ static bool plan_tile(const l2i_conv_params& p, int wm, int wn, ConvLaunch& L, b
     if (ck < 2) return false;
     const int cin_even = (p.Cin + 1) & ~1;
     if (ck > cin_even) ck = cin_even;
+    L.ksplit = 1;
+    L.cin_per = p.Cin;
+    if (p.ksplit > 1 && p.ws) {                       // channel ranges must be whole chunks: the largest even CK that divides the range
+        const int per = p.Cin / p.ksplit;
+        if (per >= 2 && per * p.ksplit == p.Cin && (per % 2) == 0) {
+            while (ck > 2 && (per % ck) != 0) ck -= 2;
+            if ((per % ck) == 0) { L.ksplit = p.ksplit; L.cin_per = per; }
+        }
+    }
     L.CK = ck;
     L.in_elems = ck * in_per_c;
     L.w_vec = ck * KK * BM / 4;
@@ -604,7 +678,7 @@ static bool plan_tile(const l2i_conv_params& p, int wm, int wn, ConvLaunch& L, b
     L.vec_epi = (p.ox_step == 1 && p.oy_step == 1 && (p.OWf % 4) == 0 && (p.OW % 4) == 0 && (p.ox_off % 4) == 0 && L.tw_log2 >= 2 &&
                  al16(p.y) && al16(p.residual) && al16(p.res_mask) && al16(p.out_mask) && al16(p.noise)) ? 1 : 0;
     if (L.vec_epi && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);      // 8 KiB transpose strip per wave
-    grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks;
+    grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks * L.ksplit;
     return lds <= 64 * 1024 && grid > 0 && grid <= 0x7fffffffL;
 }
 
@@ -679,5 +753,10 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
         default: e = launch_cfg<2, 4>(p, Lbest, (int)gbest, lbest, vbest, st); break;
     }
     if (e != hipSuccess) return l2i_set_error(L2I_E_LAUNCH, hipGetErrorString(e));
+    if (Lbest.ksplit > 1) {
+        l2i_conv_params q = p;
+        q.ksplit = Lbest.ksplit;
+        return l2i_launch_splitk_epilogue(q, st);
+    }
     return L2I_OK;
 }

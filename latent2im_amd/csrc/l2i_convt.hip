@@ -25,6 +25,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct ConvTLaunch {
     int TW, TH, tb_log2;               // tile = 2^tb samples x TH rows x TW columns of positions (TW even; TW*TH*2^tb <= 128*WN slots)
     unsigned magic_tw, magic_th;
+    int ksplit, cin_per;               // split-K (small maps): channel ranges of cin_per (multiple of CK) channels, partial sums into p.ws
     int tiles_x, tiles_y, bgroups, mblocks;
     int CK, IH, IW, IWp, planeS, plane, rows_c;
     unsigned magic_iw, magic_rc, magic_ih;
@@ -58,8 +59,12 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p
     const int mblk = bid % L.mblocks; bid /= L.mblocks;
     const int tx = bid % L.tiles_x; bid /= L.tiles_x;
     const int ty = bid % L.tiles_y; bid /= L.tiles_y;
-    const int b0 = bid << L.tb_log2;
+    const int bgrp = bid % L.bgroups;
+    const int split = bid / L.bgroups;                           // 0 unless split-K
+    const int b0 = bgrp << L.tb_log2;
     const int m0 = mblk * BM;
+    const int c_begin = split * L.cin_per;
+    const int c_end = (c_begin + L.cin_per < p.Cin) ? c_begin + L.cin_per : p.Cin;
     const int ty0 = ty * TH, tx0 = tx * TW;                        // tile origin in input-resolution positions t
     const int iy0 = ty0 - P, ix0 = tx0 - P;                        // origin of the staged tile
 
@@ -156,11 +161,11 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p
         if (tid < TBCK) lds_sc[tid] = p.in_scale ? __uint_as_float(rsc) : 1.f;
     };
 
-    issue(0);
-    for (int c0 = 0; c0 < p.Cin; c0 += L.CK) {
+    issue(c_begin);
+    for (int c0 = c_begin; c0 < c_end; c0 += L.CK) {
         commit();
         __syncthreads();
-        if (c0 + L.CK < p.Cin) issue(c0 + L.CK);
+        if (c0 + L.CK < c_end) issue(c0 + L.CK);
         for (int cc = 0; cc < CKh; ++cc) {
             const float* wr = lds_w + wlane + cc * KK * BM;
             const float* ir = lds_in + cc * L.plane;
@@ -198,6 +203,32 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p
 
     // ---- epilogue: interleave the two x-parities through a per-wave LDS strip, write whole output rows ----
     const size_t plane_o = (size_t)p.OHf * p.OWf;
+    if (L.ksplit > 1) {
+        // split-K: raw partial sums of this channel range, laid out like y; splitk_epilogue_kernel (l2i_conv.hip) reduces and scales
+        float* wsp = p.ws + (size_t)split * p.B * p.Cout * plane_o;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int pi = (wave * WN + n) * 32 + j;
+            const int rowi = (int)fast_div_t((unsigned)pi, L.magic_tw);
+            const int tbi = (int)fast_div_t((unsigned)rowi, L.magic_th);
+            const int tcol = tx0 + (pi - rowi * TW), trow = ty0 + (rowi - tbi * TH);
+            const int bb = tbi < (1 << L.tb_log2) ? b0 + tbi : p.B;
+            if (bb < p.B) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oy = 2 * trow + (q >> 1), ox = 2 * tcol + (q & 1);
+                    if (oy < p.OHf && ox < p.OWf) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (co < p.Cout) wsp[((size_t)bb * p.Cout + co) * plane_o + (size_t)oy * p.OWf + ox] = acc[q][n][r];
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     float* strip = smem + wave * (32 * 64);                 // [32 channels][64 consecutive output pixels]
     const int ch_l = lane >> 4, q4 = lane & 15;
 #pragma unroll
@@ -303,6 +334,15 @@ static int launch_convt(const l2i_conv_params& p, hipStream_t st) {
     if (ck < 2) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: tile cannot be staged");
     const int cin_even = (p.Cin + 1) & ~1;
     if (ck > cin_even) ck = cin_even;
+    L.ksplit = 1;
+    L.cin_per = p.Cin;
+    if (p.ksplit > 1 && p.ws) {
+        const int per = p.Cin / p.ksplit;
+        if (per >= 2 && per * p.ksplit == p.Cin && (per % 2) == 0) {
+            while (ck > 2 && (per % ck) != 0) ck -= 2;
+            if ((per % ck) == 0) { L.ksplit = p.ksplit; L.cin_per = per; }
+        }
+    }
     L.CK = ck;
     L.in_elems = ck * L.rows_c * L.IW;
     L.w_vec = ck * KK * BM / 4;
@@ -311,11 +351,17 @@ static int launch_convt(const l2i_conv_params& p, hipStream_t st) {
     L.magic_ih = magic_of((unsigned)L.IH);
     size_t lds = per_c * ck + (size_t)(ck << L.tb_log2) * sizeof(float);
     if (lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
-    const long grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks;
+    const long grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks * L.ksplit;
     if (grid <= 0 || grid > 0x7fffffffL) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: grid too large");
     if (p.in_mask) hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, true>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
     else hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, false>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
     L2I_CHECK_LAUNCH();
+    if (L.ksplit > 1) {                                 // second pass: sum the partials, out_scale / out_gain (l2i_conv.hip)
+        l2i_conv_params q = p;
+        q.ksplit = L.ksplit;
+        q.OH = p.OHf; q.OW = p.OWf; q.oy_step = q.ox_step = 1; q.oy_off = q.ox_off = 0;
+        return l2i_launch_splitk_epilogue(q, st);
+    }
     return L2I_OK;
 }
 

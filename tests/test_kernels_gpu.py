@@ -82,7 +82,8 @@ def test_conv_prologue_epilogue_fusions():
 
 
 @pytest.mark.parametrize('cin,cout,k,pad,tr,h,w,b', [(24, 40, 3, 0, True, 17, 17, 2), (40, 24, 3, 1, False, 34, 30, 2), (3, 64, 7, 3, False, 64, 64, 1),
-                                                     (64, 3, 7, 3, False, 32, 32, 2), (512, 512, 3, 0, True, 4, 4, 3), (16, 32, 3, 0, False, 9, 9, 2)])
+                                                     (64, 3, 7, 3, False, 32, 32, 2), (512, 512, 3, 0, True, 4, 4, 3), (16, 32, 3, 0, False, 9, 9, 2),
+                                                     (512, 96, 3, 0, True, 8, 8, 8), (256, 64, 3, 0, True, 16, 16, 4), (64, 256, 3, 0, False, 17, 17, 8)])   # the last three: split-K
 def test_fused_transposed_conv_matches_per_parity_launches(cin, cout, k, pad, tr, h, w, b):
     """One-launch stride-2 transposed conv (l2i_conv_transpose2d_f32) == the four per-parity l2i_conv2d_f32 launches == torch."""
     rs = np.random.RandomState(cin + cout + h)
@@ -219,6 +220,42 @@ def test_gemm_1x1_conv(cin, cout, h, w, b):
         for got, want in ((y1, ref1), (y2, ref2)):
             err = float((got.double().cpu() - want).abs().max() / want.abs().max())
             assert err < 5e-6, (hint, err)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,h,b', [(512, 512, 3, 1, 4, 8), (256, 96, 3, 1, 8, 8), (512, 64, 3, 1, 16, 8), (512, 512, 3, 2, 9, 8), (384, 128, 3, 1, 6, 3)])
+def test_split_k_small_maps(cin, cout, k, stride, h, b):
+    """4x4 .. 16x16 maps: Cin is cut into ranges computed by separate blocks, a second pass reduces and applies the epilogue
+    (l2i.h: ksplit / ws).  Same results as the one-pass kernel and as a float64 reference, forward with the StyledConv fusions
+    and masked input-gradient."""
+    rs = np.random.RandomState(cin + cout + h)
+    pad = 1 if stride == 1 else 0
+    wt = T(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    x, s, d, bias = T(rs.randn(b, cin, h, h)), T(rs.rand(b, cin) + 0.5), T(rs.rand(b, cout) + 0.5), T(rs.randn(cout))
+    g = lambda t: t.to(DEV)
+    fc = conv.FrozenConv2d(wt, stride, pad, device=DEV)
+    oh = fc.out_hw(h, h)[0]
+    nz, res = T(rs.randn(b, 1, oh, oh)), T(rs.randn(b, cout, oh, oh))
+    D = lambda t: t.double()
+    ref = F.leaky_relu(F.conv2d(D(x) * D(s)[:, :, None, None], D(wt), stride=stride, padding=pad) * D(d)[:, :, None, None] + 0.3 * D(nz)
+                       + D(bias)[None, :, None, None] + D(res), 0.2) * 2 ** 0.5
+    outs = []
+    for on in (True, False):
+        conv.SPLIT_K = on
+        try:
+            outs.append(fc.forward(g(x), in_scale=g(s), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), residual=g(res),
+                                   act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5))
+        finally:
+            conv.SPLIT_K = True
+    for y in outs:
+        assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < 5e-6
+    if stride == 1:
+        gy, msk = T(rs.randn(b, cout, oh, oh)), T(rs.randn(b, cout, oh, oh))
+        xr = D(x).clone().requires_grad_(True)
+        gm = D(gy) * torch.where(msk > 0, torch.tensor(1.0, dtype=torch.float64), torch.tensor(0.2, dtype=torch.float64))
+        gref, = torch.autograd.grad(F.conv2d(xr, D(wt), padding=pad), xr, gm)
+        gx = fc.dgrad(g(gy), (h, h), in_mask=g(msk), mask=(1.0, 0.2)) if cout >= 256 else None
+        if gx is not None:
+            assert float((gx.double().cpu() - gref).abs().max() / gref.abs().max()) < 5e-6
 
 
 def test_fused_bias_act_golden(golden):

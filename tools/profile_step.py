@@ -35,7 +35,7 @@ for a, b, fl, d, _name in prof:
 tot = sum(v[1] for v in agg.values())
 print('step %.1f ms, conv %.1f ms in %d launches, %.1f TFLOP/s' % (e0.elapsed_time(e1), tot, len(prof), sum(v[2] for v in agg.values()) / tot / 1e9))
 print('%-74s %4s %9s %8s %6s' % ('(B,cin,cout,kh,kw,stride,H,W,OH,OW,step,mask,scale)', 'n', 'ms', 'TF/s', 'share'))
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("L2I_PROFILE_ROWS", "60"))]:
     print('%-74s %4d %9.3f %8.1f %5.1f%%' % (str(k), v[0], v[1], v[2] / v[1] / 1e9, 100 * v[1] / tot))
 
 
