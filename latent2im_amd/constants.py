@@ -17,3 +17,6 @@ SYNTH_SEED_G, SYNTH_SEED_D, SYNTH_SEED_R, SYNTH_SEED_V = 100, 200, 300, 400
 
 # run the discriminator / VGG / regressor loss branches on separate HIP streams (see graph.TransformGraph.get_w_loss)
 CONCURRENT_LOSS_BRANCHES = True
+
+# transform_base.py:290 hard-codes ``is_mlp = False`` ("TODO: Hard code"); True builds WalkMlpMultiW instead of WalkLinearMultiW
+WALK_IS_MLP = False

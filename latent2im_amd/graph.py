@@ -58,6 +58,66 @@ class WalkLinearMultiW(nn.Module):
 WalkLinearMultiW.__module__ = 'graphs.stylegan_v2_real.transform_base'
 
 
+class WalkMlpMultiW(nn.Module):
+    """Input-dependent MLP walk in W+ (transform_base.py:168-204; "an unused setting in the paper", built only when
+    ``is_mlp`` is switched on by hand): w_i + alpha[:, :1] * MLP(w_i), MLP = 512 -> 1024 -> 1024 -> 512 with LeakyReLU(0.2).
+    With ``layers`` given the reference calls ``self.linear(input[i], 1)``, which raises TypeError: kept."""
+
+    def __init__(self, dim_z, step, Nsliders, attrList):
+        super().__init__()
+        self.dim_z = dim_z
+        self.step = step
+        self.Nsliders = Nsliders
+        self.linear = nn.Sequential(nn.Linear(dim_z, 2 * dim_z), nn.LeakyReLU(0.2, True),
+                                    nn.Linear(2 * dim_z, 2 * dim_z), nn.LeakyReLU(0.2, True),
+                                    nn.Linear(2 * dim_z, dim_z))
+
+    def forward(self, input, alpha, layers=None, name=None, index_=None):
+        al = torch.unsqueeze(alpha[:, 0], 1).to(self.linear[0].weight.device)
+        if layers is None:
+            same = all(t is input[0] for t in input)               # get_w hands the SAME tensor n_latent times: one MLP pass
+            step0 = self.linear(input[0]) if same else None
+            return [input[i] + al * (step0 if same else self.linear(input[i])) for i in range(len(input))]
+        out = []
+        for i in range(len(input)):
+            out.append(input[i] + al * self.linear(input[i], 1) if i in layers else input[i])
+        return out
+
+
+class WalkNonLinearW(nn.Module):
+    """MLP walk conditioned on an embedding of alpha (transform_base.py:207-243), chosen by ``--walk_type NN*``:
+    e = Linear(10, 256)(alpha[:, :1] repeated 10x); d = MLP([e, w_i]); w_i + d / ||d|| (no normalisation when ``layers``
+    is given).  NOTE the argument order (input, name, alpha, index_, layers): the reference's get_w_new_tensor calls every
+    walk as ``walk(multi_ws, alpha=..., layers=...)`` (transform_base.py:380-386), so with this walk it raises TypeError
+    (missing ``name`` / ``index_``) — the same happens here; call the module directly to use it."""
+
+    def __init__(self, dim_z, step, Nsliders, attrList):
+        super().__init__()
+        self.dim_z = dim_z
+        self.step = step
+        self.Nsliders = Nsliders
+        self.embed = nn.Linear(10, dim_z // 2)
+        self.linear = nn.Sequential(nn.Linear(dim_z // 2 + dim_z, 2 * dim_z), nn.LeakyReLU(0.2, True),
+                                    nn.Linear(2 * dim_z, dim_z))
+
+    def forward(self, input, name, alpha, index_, layers=None):
+        al = torch.unsqueeze(alpha[:, 0], 1).to(self.embed.weight.device)
+        out = self.embed(al.repeat(1, 10))
+        w_transformed = []
+        for i in range(len(input)):
+            if layers is None:
+                out2 = self.linear(torch.cat([out, input[i]], 1))
+                w_transformed.append(input[i] + out2 / torch.norm(out2, dim=1, keepdim=True))
+            elif i in layers:
+                w_transformed.append(input[i] + self.linear(torch.cat([out, input[i]], 1)))
+            else:
+                w_transformed.append(input[i])
+        return w_transformed
+
+
+WalkMlpMultiW.__module__ = WalkNonLinearW.__module__ = 'graphs.stylegan_v2_real.transform_base'
+
+
 class ContentLoss(nn.Module):
     """transform_base.py:57-63."""
 
@@ -116,6 +176,15 @@ def load_networks(resolution, device, need_vgg=True, need_d=True):
     return netG, netD, reg, vgg, src
 
 
+def attribute_change_bucket(pred, org):
+    """Bucket index per sample (transform_base.py:722-738): 0 if |pred - org| <= 0.3, 1 if <= 0.6, 2 if <= 1, else 3
+    (dropped).  The comparison is made on the float32 difference against the float32 thresholds, which is what numpy does
+    for ``np.abs(float32 - float32) <= 0.3`` under NumPy >= 2 (a python float is a weak scalar; NumPy 1.x promoted the
+    scalar comparison to float64, which differs only for a difference that rounds exactly onto a threshold)."""
+    d = np.abs(np.asarray(pred, dtype=np.float32) - np.asarray(org, dtype=np.float32))
+    return np.where(d <= np.float32(0.3), 0, np.where(d <= np.float32(0.6), 1, np.where(d <= np.float32(1), 2, 3))).astype(np.int64)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # TransformGraph
 # ----------------------------------------------------------------------------------------------------------------
@@ -155,7 +224,7 @@ class TransformGraph:
         self.alpha = 1
         self.stylegan_opts = stylegan_opts
         self.layers = layers
-        self.is_mlp = False
+        self.is_mlp = constants.WALK_IS_MLP
 
         if walk_type == 'linear':
             if self.trainEmbed:
@@ -163,11 +232,12 @@ class TransformGraph:
             if stylegan_opts.latent == 'z':
                 raise NotImplementedError('Not implemented setting of linear transformation for z')
             elif stylegan_opts.latent == 'w':
-                self.walk = WalkLinearMultiW(self.dim_z, self.step, nsliders, self.attrList).to(self.device)
+                cls = WalkMlpMultiW if constants.WALK_IS_MLP else WalkLinearMultiW    # reference: is_mlp hard-coded False (:290)
+                self.walk = cls(self.dim_z, self.step, nsliders, self.attrList).to(self.device)
             else:
                 raise NotImplementedError('Not implemented latent walk type:' '{}'.format(stylegan_opts.latent))
         elif 'NN' in walk_type:
-            raise NotImplementedError('WalkNonLinearW (transform_base.py:207-243) is out of scope of this build')
+            self.walk = WalkNonLinearW(self.dim_z, self.step, nsliders, self.attrList).to(self.device)
         else:
             raise NotImplementedError('unknown walk_type %r' % (walk_type,))
 
@@ -346,6 +416,36 @@ class TransformGraph:
             Image.fromarray(strip).save(path)
             written.append(path)
         return written
+
+    def vis_multi_image_batch_alphas_compute_multi_attr(self, graph_inputs, filename, alphas_to_graph, alphas_to_target,
+                                                        batch_start, layers=None, name=None, wgt=False, wmask=False,
+                                                        trainEmbed=False, computeL2=False, given_w=None, index_=None):
+        """Attribute-preservation half of eval.py (transform_base.py:675-767): for every requested alpha edit the batch,
+        read all 40 regressor outputs of the edited and the original image, and sort every sample into one of three
+        buckets by how far the TARGET attribute moved: |d| <= 0.3, <= 0.6, <= 1 (samples that moved further are dropped).
+        Returns (multi_attr, attri_org, imgs, orgs): four lists of three lists (edited attrs [40], original attrs [40],
+        uint8 edited image [3,R,R], uint8 original image)."""
+        zs_batch = graph_inputs['z']
+        multi_attr, attri_org, imgs, orgs = [[], [], []], [[], [], []], [[], [], []], [[], [], []]
+        index_list = [index_] if type(index_) == int else index_
+        with torch.no_grad():
+            for ag1, at1 in zip(alphas_to_graph, alphas_to_target):
+                best_im_out, alpha_org, out_zs = self.apply_alpha({'z': torch.Tensor(zs_batch).to(self.device)}, ag1, name=name,
+                                                                  layers=layers, trainEmbed=trainEmbed, given_w=given_w,
+                                                                  index_=index_)
+                pred_attr = self.regressor(best_im_out).detach().cpu().numpy()       # [N, 40]
+                org = self.regressor(out_zs).detach().cpu().numpy()
+                best_im_out = self.clip_ims(best_im_out.detach().cpu().numpy())
+                out_zs = self.clip_ims(out_zs.cpu().numpy())
+                bucket = attribute_change_bucket(pred_attr[:, index_list[0]], org[:, index_list[0]])
+                for i in range(pred_attr.shape[0]):
+                    k = int(bucket[i])
+                    if k < 3:
+                        multi_attr[k].append(pred_attr[i])
+                        attri_org[k].append(org[i])
+                        imgs[k].append(best_im_out[i])
+                        orgs[k].append(out_zs[i])
+        return multi_attr, attri_org, imgs, orgs
 
     def vis_image_batch(self, graph_inputs, filename, batch_start, wgt=False, wmask=False, num_panels=7):
         raise NotImplementedError('Subclass should implement vis_image_batch')

@@ -92,3 +92,17 @@ def wino_conv(x, U, cout, pad):
     M = torch.einsum('cioj,nctuij->notuij', U.to(x.dtype)[:, :, :cout, :], V)
     Y = torch.einsum('ai,notuij,bj->notaub', At, M, At)               # [n, cout, ty, 2, tx, 2]
     return Y.reshape(n, cout, 2 * ty, 2 * tx)[:, :, :OH, :OW]
+
+
+def seeded_state(module, seed, scale=1.0):
+    """Same rule as tests/golden/make_golden.py::seeded_module_state: RandomState(seed).standard_normal per tensor in
+    state_dict order, matrices * scale / sqrt(fan_in), vectors * 0.1.  Loads the values into ``module`` and returns them."""
+    import numpy as np
+    import torch
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for k, v in module.state_dict().items():
+        a = rs.standard_normal(tuple(v.shape)).astype(np.float32)
+        sd[k] = (a * (scale / np.sqrt(v.shape[1])) if v.dim() == 2 else a * 0.1).astype(np.float32)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return sd

@@ -286,3 +286,111 @@ def test_train_cli_then_vis_cli_roundtrip(tmp_path):
 
 def test_smoke_entry():
     selfcheck.smoke()
+
+
+# ---- the rows next to the training step -------------------------------------------------------------------
+def _inference_graph(size, attrs, walk_seed, fc_scale=1.0, walk_scale=1.0):
+    import types
+    from latent2im_amd import constants, graph
+    constants.resolution, constants.BATCH_SIZE = size, 4
+    r_state = synth.resnet50_state(seed=300)
+    r_state['fc.weight'] = r_state['fc.weight'] * fc_scale
+    nets = (Generator(synth.generator_state(size, seed=100), size, device=DEV), None, ResNet50(r_state, device=DEV), None, {})
+    with open('dataset/attributes_celeba.txt') as f:
+        names = [l.strip() for l in f if l.strip()]
+    g = graph.faceGraph(lr=1e-3, walk_type='linear', loss='l2', trainEmbed=False, attrList=list(attrs),
+                        attrTable={n: i for i, n in enumerate(names)}, layers=None, stylegan_opts=types.SimpleNamespace(latent='w'), nets=nets)
+    with torch.no_grad():
+        g.walk.w.copy_(T(synth.walk_init(len(attrs), g.module.netG.n_latent, seed=walk_seed)) * walk_scale)
+    return g
+
+
+def test_eval_attribute_buckets_match_reference(golden):
+    """eval.py's attribute-preservation pass (vis_multi_image_batch_alphas_compute_multi_attr) on the GPU against the buckets
+    the reference's own method produced on the same seeds: identical membership (integer selection), regressor outputs within
+    the fp32 tolerance, and the same metric."""
+    import os
+    from latent2im_amd import constants, evaluate
+    os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    g = golden('next')
+    try:
+        gr = _inference_graph(64, ['Smiling', 'Young'], 9, float(g['fc_scale']), float(g['walk_scale']))
+        zs = synth.z_sample(4, seed=11)
+        idx = int(g['index_'])
+        x1, a0, x0 = gr.apply_alpha({'z': zs}, g['alphas'][3], index_=idx)
+        close(a0, g['apply.a0'])
+        close(x0.sum(3), g['apply.x0_rowsum'], 1e-3, 2e-3)
+        close(x1.sum(3), g['apply.x1_rowsum'], 1e-3, 2e-3)
+        ma, ao, im, og = gr.vis_multi_image_batch_alphas_compute_multi_attr({'z': zs}, '/tmp/unused', list(g['alphas']),
+                                                                           list(np.linspace(-0.5, 1.5, 5)), 0, index_=idx)
+        assert [len(m) for m in ma] == [6, 5, 6]
+        for k in range(3):
+            close(np.asarray(ma[k]), g['bucket%d.multi_attr' % k], 1e-3, 2e-3)
+            close(np.asarray(ao[k]), g['bucket%d.attri_org' % k], 1e-3, 2e-3)
+            assert all(i.dtype == np.uint8 and i.shape == (3, 64, 64) for i in im[k] + og[k])
+            s = np.asarray([int(i.astype(np.int64).sum()) for i in im[k]])
+            assert np.all(np.abs(s - g['bucket%d.img_sum' % k]) <= 64)
+        _, got = evaluate.attribute_preservation(ma, ao, idx)
+        _, want = evaluate.attribute_preservation([list(g['bucket%d.multi_attr' % k]) for k in range(3)],
+                                                  [list(g['bucket%d.attri_org' % k]) for k in range(3)], idx)
+        close(got, want, 1e-3, 1e-4)
+    finally:
+        constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
+def test_checkpoint_formats_round_trip(tmp_path):
+    """networks load from files in the reference's formats — StyleGAN2 ``{'g_ema': state_dict}``
+    (transform_base.py:544-547), regressor ``{'model': state_dict, 'optm': ...}`` (scene_regressor_256.py:167-170), torchvision
+    VGG ``features.N.*`` — and give the same outputs as the same weights handed over directly."""
+    from latent2im_amd import constants, graph
+    saved = (constants.g_path, constants.reg_path, constants.vgg_path, constants.resolution, constants.BATCH_SIZE)
+    try:
+        gs, rs_, vs = synth.generator_state(32, seed=5), synth.resnet50_state(seed=6), synth.vgg19_prefix_state(seed=7)
+        torch.save({'g_ema': {k: T(np.asarray(v)) for k, v in gs.items()}, 'g': {}, 'd': {}}, tmp_path / 'g.pt')
+        torch.save({'model': {k: T(np.asarray(v)) for k, v in rs_.items()}, 'optm': {}}, tmp_path / 'r.model')
+        torch.save({'features.' + k: T(np.asarray(v)) for k, v in vs.items()}, tmp_path / 'vgg.pth')
+        constants.g_path, constants.reg_path, constants.vgg_path = str(tmp_path / 'g.pt'), str(tmp_path / 'r.model'), str(tmp_path / 'vgg.pth')
+        constants.resolution, constants.BATCH_SIZE = 32, 4
+        netG, netD, reg, vgg, src = graph.load_networks(32, torch.device(DEV))
+        assert src['G'].endswith('g.pt') and src['R'].endswith('r.model') and src['V'].endswith('vgg.pth')
+        z = T(synth.z_sample(4, seed=2)).float().to(DEV)
+        w = netG.style(z).unsqueeze(1).repeat(1, netG.n_latent, 1)
+        x, _ = netG(w, input_is_latent=True)
+        G2 = Generator(gs, 32, device=DEV)
+        x2, _ = G2(G2.style(z).unsqueeze(1).repeat(1, G2.n_latent, 1), input_is_latent=True)
+        assert torch.equal(x, x2)
+        assert torch.equal(reg(x), ResNet50(rs_, device=DEV)(x))
+        l1 = vgg.content_losses(x, x * 0.9)
+        l2 = VGG19Prefix(vs, device=DEV).content_losses(x, x * 0.9)
+        close(l1, l2, 1e-5, 0)                                          # atomics in the squared-difference reduction
+        # missing files fall back to the seeded synthetic weights, and say so
+        constants.g_path = str(tmp_path / 'absent.pt')
+        assert graph.load_networks(32, torch.device(DEV), need_vgg=False, need_d=False)[4]['G'].startswith('synthetic')
+    finally:
+        constants.g_path, constants.reg_path, constants.vgg_path, constants.resolution, constants.BATCH_SIZE = saved
+
+
+def test_eval_cli_after_training(tmp_path):
+    """train.py (2 iterations at 32^2) then eval.py on its output: the metric dict comes back, bucket sizes add up to at most
+    samples x panels, and the printed line has the reference's wording."""
+    import os
+    from latent2im_amd import constants, evaluate, trainer
+    os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    models = str(tmp_path / 'models')
+    argv = ['--model', 'stylegan_v2_real', '--transform', 'face', '--num_samples', '8', '--learning_rate', '1e-3', '--latent', 'w',
+            '--walk_type', 'linear', '--loss', 'l2', '--attrList', 'Smiling', '--attrPath', './dataset/attributes_celeba.txt',
+            '--models_dir', models, '--overwrite_config', '--resolution', '32', '--batch_size', '4', '--n_epoch', '1', '--seed', '3',
+            '--model_save_freq', '1']
+    try:
+        trainer.main(multi_attr=False, argv=argv)
+        out = os.path.join(models, 'stylegan_v2_real_face_linear_lr0.001_l2_w')
+        ck = os.path.join(out, 'model_w_1_final_walk_module.ckpt')
+        r = evaluate.main([os.path.join(out, 'opt.yml'), '--save_path_w', ck, '--num_samples', '8', '--num_panels', '3',
+                           '--attrPath', './dataset/attributes_celeba.txt', '--target_attrList', 'Smiling'], all_batches=True)
+        assert r['index_'] == 31 and sum(r['bucket_sizes']) <= 8 * 3 and sum(r['bucket_sizes']) > 0
+        assert len(r['results_avg']) == sum(1 for b in r['bucket_sizes'] if b)
+        last = evaluate.main([os.path.join(out, 'opt.yml'), '--save_path_w', ck, '--num_samples', '8', '--num_panels', '3',
+                              '--attrPath', './dataset/attributes_celeba.txt', '--target_attrList', 'Smiling'])
+        assert sum(last['bucket_sizes']) <= 4 * 3                       # reference quirk: only the last batch is scored
+    finally:
+        constants.resolution, constants.BATCH_SIZE = 256, 4
