@@ -155,6 +155,24 @@ def main():
     value = global_b * a.steps / elapsed
     roof = None
     if prof:
+        # algorithmic HBM bytes of a conv call: input (+ its gradient mask) read once, output written once, every fused
+        # epilogue operand (residual, its mask, output mask, accumulate) read once; weights / per-sample vectors are noise
+        def call_bytes(q):
+            B, cin, cout, kh, kw, stride, H, W, OH, OW, step, in_mask = q[3][:12]
+            flags = q[3][13] if len(q[3]) > 13 else ''
+            extra = sum(1 for c in 'rmoa' if c in flags.rstrip('0123456789'))
+            return 4.0 * (B * cin * H * W * (2 if in_mask else 1) + B * cout * OH * OW * (1 + extra))
+        alg_bytes = sum(call_bytes(q) for q in prof) / len(prof)
+        traffic, traffic_note = None, 'no PMC summary for this workload under profiles/'
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_conv_hbm_traffic.json')
+        if (os.path.isfile(tp) and a.resolution == 1024 and a.batch == 8 and not a.reg_only and a.precision == 'f32' and not a.direct_3x3
+                and attrs == ['Smiling']):
+            tj = json.load(open(tp))
+            if abs(tj['conv_launches_per_step'] - len(prof) // a.steps) < 0.5:
+                traffic = round(tj['conv_bytes_per_launch'])
+                traffic_note = ('HBM bytes per conv launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command with --serial_streams '
+                                '(profiles/r01_conv_hbm_traffic.json, tools/hbm_traffic.py): KiB -> bytes, FETCH_SIZE doubled (gfx950), both factors '
+                                'checked on a kernel of known byte count in the same run; not re-measured live (counters need the profiler)')
         tot_ms = sum(q[0].elapsed_time(q[1]) for q in prof)
         tot_flop = sum(q[2] for q in prof)
         ach = tot_flop / (tot_ms * 1e-3) / 1e12
@@ -164,7 +182,8 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if a.precision == 'f32' else PEAK_BF16_MFMA_TFLOPS
         roof = dict(bound='mfma', kernel='conv_wino_kernel / conv_mfma_kernel + gemm1x1_kernel / convt_mfma_kernel (l2i_conv2d_wino_f32, l2i_conv2d_f32, l2i_conv_transpose2d_f32)' if a.precision == 'f32'
                     else 'conv_bf16x3_kernel + fp32 kernels for ineligible layers (algorithmic FLOPs; the split executes 3 MFMA FLOPs per algorithmic FLOP)',
-                    achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                    achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=traffic, traffic_unit='bytes per launch', traffic_note=traffic_note,
+                    algorithmic_bytes_per_launch=round(alg_bytes),
                     launches_per_step=len(prof) // a.steps, avg_launch_ms=round(tot_ms / len(prof), 4),
                     kernel_ms_per_step=round(tot_ms / a.steps, 2),
                     algorithmic_tflop_per_step=round(tot_flop / a.steps / 1e12, 3),

@@ -1,0 +1,70 @@
+"""Summarise two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — they do not fit one pass) of
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <dir_f> -o run --output-format csv -- python3 bench.py --serial_streams \
+        --steps 1 --warmup 1 --cpu_baseline_s 0 --no_alt_precision --no_kernel_events
+    (same with --pmc WRITE_SIZE -d <dir_w>)
+
+into profiles/<name>.json: HBM bytes per kernel family and per conv launch.  Corrections (MI355X_MICROARCH.md, "HBM"):
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read, so it is
+doubled; both factors are checked on the axpby_kernel launches of the same run (y = a + b over a known element count: 8 B read,
+4 B written per element: measured 2.00 and 1.00).
+
+    python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_conv_hbm_traffic.json
+"""
+import collections
+import csv
+import json
+import sys
+
+CONV = ('conv_wino_kernel', 'conv_mfma_kernel', 'gemm1x1_kernel', 'convt_mfma_kernel', 'conv_direct_small_kernel',
+        'conv16_kernel', 'splitk_epilogue_kernel')
+
+
+def load(d, name):
+    out = {}
+    for r in csv.DictReader(open('%s/run_counter_collection.csv' % d)):
+        if r['Counter_Name'] == name:
+            out[int(r['Dispatch_Id'])] = (r['Kernel_Name'].split('(')[0].replace('void ', ''), int(r['Grid_Size']), float(r['Counter_Value']) * 1024.0)
+    return out
+
+
+def main(df, dw, dst, steps=2, axpby_elems=8 * 64 * 1024 * 1024):
+    f, w = load(df, 'FETCH_SIZE'), load(dw, 'WRITE_SIZE')
+    fam = collections.defaultdict(lambda: dict(launches=0, fetch_raw=0.0, write_raw=0.0))
+    for i, (k, g, v) in f.items():
+        a = fam[k]
+        a['launches'] += 1
+        a['fetch_raw'] += v
+    for i, (k, g, v) in w.items():
+        fam[k]['write_raw'] += v
+    # calibration: axpby_kernel(y = a + b) runs once per step, on the VGG conv1_1 gradient [8, 64, 1024, 1024] of the default workload
+    cal_r = cal_w = None
+    ax = [(g, v, w[i][2]) for i, (k, g, v) in f.items() if k == 'axpby_kernel' and i in w and w[i][0] == k]
+    if ax:
+        n = axpby_elems * len(ax)
+        cal_r = 8.0 * n / sum(v for _, v, _ in ax)
+        cal_w = 4.0 * n / sum(x for _, _, x in ax)
+    fr, fw = 2.0, 1.0
+    rows = {}
+    conv = dict(launches=0, bytes=0.0)
+    for k, a in sorted(fam.items(), key=lambda kv: -(fr * kv[1]['fetch_raw'] + fw * kv[1]['write_raw'])):
+        b = fr * a['fetch_raw'] + fw * a['write_raw']
+        rows[k] = dict(launches_per_step=a['launches'] / steps, read_GB_per_step=round(fr * a['fetch_raw'] / steps / 1e9, 3),
+                       write_GB_per_step=round(fw * a['write_raw'] / steps / 1e9, 3))
+        if any(k.startswith(c) for c in CONV):
+            conv['launches'] += 0 if k.startswith('splitk_epilogue') else a['launches']      # the second pass of a split-K call is not a call
+            conv['bytes'] += b
+    out = dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --serial_streams, %d steps' % steps,
+               corrections=dict(unit='KiB -> bytes', fetch_factor=fr, write_factor=fw,
+                                calibration_axpby=dict(read_factor_measured=cal_r, write_factor_measured=cal_w,
+                                                       note='known bytes / reported bytes on axpby_kernel launches of the same run')),
+               conv_launches_per_step=conv['launches'] / steps, conv_bytes_per_step=conv['bytes'] / steps,
+               conv_bytes_per_launch=conv['bytes'] / max(conv['launches'], 1),
+               all_kernels_GB_per_step=round(sum(fr * a['fetch_raw'] + fw * a['write_raw'] for a in fam.values()) / steps / 1e9, 2),
+               per_kernel=rows)
+    json.dump(out, open(dst, 'w'), indent=1)
+    print(json.dumps({k: out[k] for k in ('corrections', 'conv_launches_per_step', 'conv_bytes_per_step', 'conv_bytes_per_launch', 'all_kernels_GB_per_step')}, indent=1))
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:4])
