@@ -214,6 +214,7 @@ def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), 
     p.mask_pos, p.mask_neg = mask
     p.out_scale = _lib.fptr(out_scale)
     p.act_gain, p.out_gain = 1.0, out_gain
+    p.tile_hint = tile_hint
     if in_mask is not None:
         assert in_mask.shape == x.shape
     _split_k(p, B * H * W, cin, y)
@@ -319,7 +320,7 @@ class FrozenConv2d:
             assert stride == 2
             self.fwd = transposed_plan(w, padding)
             self.bwd = correlation_plan(wt, 2, padding)           # dx[ci,i] = sum gy[co, 2i+k-pad] w[co,ci,k]
-            if fusable:
+            if fusable and self.cin % 4 == 0:            # the fused kernel walks input channels four at a time
                 self.fwd_fused = FusedTransposed(w, padding).to(device)
         else:
             self.fwd = correlation_plan(w, stride, padding)
@@ -328,7 +329,7 @@ class FrozenConv2d:
             else:
                 assert stride == 2
                 self.bwd = transposed_plan(wt, padding)           # dx[ci, 2o+k-pad] += gy[co,o] w[co,ci,k]
-                if fusable and self.cin > 4:          # <= 4 output channels: per-parity launches take the direct VALU kernel
+                if fusable and self.cin > 4 and self.cout % 4 == 0:          # <= 4 output channels: per-parity launches take the direct VALU kernel
                     self.bwd_fused = FusedTransposed(wt, padding).to(device)
         for L in self.fwd + self.bwd:
             if L is not None:

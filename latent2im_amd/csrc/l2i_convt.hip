@@ -12,7 +12,8 @@
 // are interleaved through a per-wave LDS transpose and stored 16 bytes per lane.
 //
 // Block = 256 threads = 4 waves along N; block tile = 32 output channels x (4*WN*32) INPUT-resolution positions t;
-// staging pipeline identical to l2i_conv.hip (buffer loads issued one chunk ahead, committed to LDS after the MFMAs).
+// staging: buffer loads issued two chunks ahead into registers, committed into the other of two LDS stages one chunk ahead,
+// one barrier per chunk.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,13 +46,13 @@ template <int K, int PAD> struct TrGeom {
 };
 
 template <int K, int PAD, int WN, bool MASK>
-__global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p, const ConvTLaunch L) {
+__global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const l2i_conv_params p, const ConvTLaunch L) {
     using G = TrGeom<K, PAD>;
-    constexpr int BM = 32, KK = K * K, NIN = 12, NWV = 4, P = G::P, Q = G::Q;
+    constexpr int BM = 32, KK = K * K, NIN = 12, P = G::P, Q = G::Q;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* lds_in = smem;
-    float* lds_w = smem + L.CK * L.plane;
-    float* lds_sc = lds_w + L.CK * KK * BM;
+    // two stages of [input tile | weights | input scales]: the chunk after the one being multiplied is committed into the other
+    // stage at the top of the iteration, so one barrier per chunk suffices
+    const int stage_f = L.CK * L.plane + L.CK * KK * BM + ((L.CK << L.tb_log2) + 3 & ~3);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const int TW = L.TW, TH = L.TH;
@@ -106,7 +107,6 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p
 
     unsigned rin[NIN], rmk[MASK ? NIN : 1], voff[NIN];
     int loff[NIN];
-    u32x4 rw[NWV];
     unsigned rsc = 0;
 #pragma unroll
     for (int u = 0; u < NIN; ++u) {
@@ -139,12 +139,26 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p
             rin[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff[u], so, 0);
             if constexpr (MASK) rmk[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_m, voff[u], so, 0);
         }
-        const unsigned sw = (unsigned)((size_t)c0 * KK * p.CoutP * sizeof(float));
-#pragma unroll
-        for (int u = 0; u < NWV; ++u) rw[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff, sw + u * wstep, 0);
         rsc = __builtin_amdgcn_raw_buffer_load_b32(rs_s, scoff, (unsigned)(c0 * sizeof(float)), 0);
     };
-    auto commit = [&]() {
+    // weights of a chunk: global -> LDS by DMA, 16 B per lane, a wave instruction fills 1 KiB of the [CK][KK][BM] tile in lane order
+    // (inline asm: through the builtin hipcc drains every outstanding load before the next ds_read); no registers, no commit
+    auto dma_w = [&](int c0, int st) {
+        const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + st * stage_f + L.CK * L.plane);
+        const unsigned sw = (unsigned)((size_t)c0 * KK * p.CoutP * sizeof(float));
+        for (int u = 0; u * 256 < L.w_vec; ++u) {
+            if (tid + u * 256 < L.w_vec) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(wvoff), "s"(rs_w), "s"(__builtin_amdgcn_readfirstlane(lds_w + (u * 256 + wave * 64) * 16)),
+                               "s"(sw + u * wstep) : "memory");
+            }
+        }
+    };
+    constexpr int NREG = NIN * (MASK ? 2 : 1) + 1;            // register loads of one issue(): younger than the DMA they follow
+    auto commit = [&](int st) {
+        float* lds_in = smem + st * stage_f;
+        float* lds_sc = lds_in + L.CK * L.plane + L.CK * KK * BM;
 #pragma unroll
         for (int u = 0; u < NIN; ++u) {
             if (loff[u] >= 0) {
@@ -153,51 +167,116 @@ __global__ __launch_bounds__(256) void convt_mfma_kernel(const l2i_conv_params p
                 lds_in[loff[u]] = v;
             }
         }
-#pragma unroll
-        for (int u = 0; u < NWV; ++u) {
-            const int idx = tid + u * 256;
-            if (idx < L.w_vec) reinterpret_cast<u32x4*>(lds_w)[idx] = rw[u];
-        }
         if (tid < TBCK) lds_sc[tid] = p.in_scale ? __uint_as_float(rsc) : 1.f;
     };
 
+    dma_w(c_begin, 0);
     issue(c_begin);
-    for (int c0 = c_begin; c0 < c_end; c0 += L.CK) {
-        commit();
-        __syncthreads();
-        if (c0 + L.CK < c_end) issue(c0 + L.CK);
+    commit(0);
+    if (c_begin + L.CK < c_end) issue(c_begin + L.CK);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREG) : "memory");      // the DMA (older than that issue) has landed
+    __syncthreads();
+    int st = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += L.CK, st ^= 1) {
+        const bool more = c0 + 2 * L.CK < c_end;
+        if (c0 + L.CK < c_end) {
+            commit(st ^ 1);                                  // loads issued one whole chunk ago
+            dma_w(c0 + L.CK, st ^ 1);
+            if (more) issue(c0 + 2 * L.CK);                  // in flight during the MFMAs below and the next chunk's
+        }
+        const float* lds_in = smem + st * stage_f;
+        const float* lds_w = lds_in + L.CK * L.plane;
+        const float* lds_sc = lds_w + L.CK * KK * BM;
+        if constexpr (K == 3) {
+            // 3x3: the fragments of channel pair cc + 1 are read from LDS while the 18 MFMAs of pair cc run (two register sets,
+            // loop unrolled by two) — left to itself the compiler issues each ds_read right before its MFMA and exposes the LDS latency
+            constexpr int NB = (P + Q + 1) * (P + Q + 1);
+            struct Frag { float a[KK]; float b[NB][WN]; float sv[WN]; };
+            auto load = [&](Frag& f, int cc) {
+                const float* wr = lds_w + wlane + cc * KK * BM;
+                const float* ir = lds_in + cc * L.plane;
+#pragma unroll
+                for (int t = 0; t < KK; ++t) f.a[t] = wr[t * BM];
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    f.sv[n] = lds_sc[sbase[n] + cc];
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) f.b[t][n] = ir[pixoff[n] + (t / (P + Q + 1)) * L.IWp + (t % (P + Q + 1))];
+                }
+            };
+            auto mfma = [&](const Frag& f) {
+                int slot = 0;
+#pragma unroll
+                for (int dy = -P; dy <= Q; ++dy) {
+#pragma unroll
+                    for (int dx = -P; dx <= Q; ++dx) {
+                        float bfr[WN];
+#pragma unroll
+                        for (int n = 0; n < WN; ++n) bfr[n] = f.b[(dy + P) * (P + Q + 1) + (dx + P)][n] * f.sv[n];
+#pragma unroll
+                        for (int py = 0; py < 2; ++py) {
+#pragma unroll
+                            for (int px = 0; px < 2; ++px) {
+                                const int ay = dy + G::pad(py), ax = dx + G::pad(px);
+                                if (ay >= 0 && ay < G::A(py) && ax >= 0 && ax < G::A(px)) {
+#pragma unroll
+                                    for (int n = 0; n < WN; ++n)
+                                        acc[py * 2 + px][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[slot], bfr[n], acc[py * 2 + px][n], 0, 0, 0);
+                                    ++slot;
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+            Frag f0, f1;
+            load(f0, 0);
+            for (int cc = 0; cc < CKh; cc += 2) {               // CK is a multiple of 4 for K == 3 (host): always whole pairs
+                load(f1, cc + 1);
+                __builtin_amdgcn_sched_barrier(0);              // keep the reads ahead of the MFMAs that do not need them
+                mfma(f0);
+                __builtin_amdgcn_sched_barrier(0);
+                load(f0, cc + 2 < CKh ? cc + 2 : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma(f1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         for (int cc = 0; cc < CKh; ++cc) {
-            const float* wr = lds_w + wlane + cc * KK * BM;
-            const float* ir = lds_in + cc * L.plane;
-            float sv[WN];
+                const float* wr = lds_w + wlane + cc * KK * BM;
+                const float* ir = lds_in + cc * L.plane;
+                float sv[WN];
 #pragma unroll
-            for (int n = 0; n < WN; ++n) sv[n] = lds_sc[sbase[n] + cc];
-            int slot = 0;                                   // compile-time after full unrolling
+                for (int n = 0; n < WN; ++n) sv[n] = lds_sc[sbase[n] + cc];
+                int slot = 0;                                   // compile-time after full unrolling
 #pragma unroll
-            for (int dy = -P; dy <= Q; ++dy) {
+                for (int dy = -P; dy <= Q; ++dy) {
 #pragma unroll
-                for (int dx = -P; dx <= Q; ++dx) {
-                    float bfr[WN];
-                    const int toff = (dy + P) * L.IWp + (dx + P);
+                    for (int dx = -P; dx <= Q; ++dx) {
+                        float bfr[WN];
+                        const int toff = (dy + P) * L.IWp + (dx + P);
 #pragma unroll
-                    for (int n = 0; n < WN; ++n) bfr[n] = ir[pixoff[n] + toff] * sv[n];
+                        for (int n = 0; n < WN; ++n) bfr[n] = ir[pixoff[n] + toff] * sv[n];
 #pragma unroll
-                    for (int py = 0; py < 2; ++py) {
+                        for (int py = 0; py < 2; ++py) {
 #pragma unroll
-                        for (int px = 0; px < 2; ++px) {
-                            const int ay = dy + G::pad(py), ax = dx + G::pad(px);
-                            if (ay >= 0 && ay < G::A(py) && ax >= 0 && ax < G::A(px)) {
-                                const float a = wr[slot * BM];
+                            for (int px = 0; px < 2; ++px) {
+                                const int ay = dy + G::pad(py), ax = dx + G::pad(px);
+                                if (ay >= 0 && ay < G::A(py) && ax >= 0 && ax < G::A(px)) {
+                                    const float a = wr[slot * BM];
 #pragma unroll
-                                for (int n = 0; n < WN; ++n)
-                                    acc[py * 2 + px][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr[n], acc[py * 2 + px][n], 0, 0, 0);
-                                ++slot;
+                                    for (int n = 0; n < WN; ++n)
+                                        acc[py * 2 + px][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr[n], acc[py * 2 + px][n], 0, 0, 0);
+                                    ++slot;
+                                }
                             }
                         }
                     }
                 }
             }
         }
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREG) : "memory");     // the next chunk's weights are in LDS; the register loads stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -325,21 +404,24 @@ static int launch_convt(const l2i_conv_params& p, hipStream_t st) {
     L.plane = (TB * L.planeS + 3) & ~3;
     L.rows_c = TB * L.IH;
     const size_t per_c = (size_t)(L.plane + KK * BM) * sizeof(float);
-    int ck = (int)((48 * 1024) / per_c);
+    int ck = (int)((36 * 1024) / per_c);                  // per stage; two stages, two blocks per CU
     const int ck_in = (12 * 256) / (L.rows_c * L.IW);
-    const int ck_w = (4 * 256) / (KK * BM / 4);
     if (ck > ck_in) ck = ck_in;
-    if (ck > ck_w) ck = ck_w;
-    ck &= ~1;
-    if (ck < 2) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: tile cannot be staged");
-    const int cin_even = (p.Cin + 1) & ~1;
-    if (ck > cin_even) ck = cin_even;
+    // channels per chunk: pairs (the two lane halves of an MFMA take one channel each); K == 3 walks two pairs per iteration.
+    // Chunks must tile Cin exactly: the per-chunk channel offset travels in the scalar offset of the buffer loads, which the
+    // hardware does not range-check.
+    constexpr int CKQ = (K == 3) ? 4 : 2;
+    if ((p.Cin % CKQ) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, K == 3 ? "conv_transpose2d: Cin must be a multiple of 4" : "conv_transpose2d: Cin must be even");
+    ck &= ~(CKQ - 1);
+    if (ck > p.Cin) ck = p.Cin;
+    while (ck > CKQ && (p.Cin % ck) != 0) ck -= CKQ;
+    if (ck < CKQ) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: tile cannot be staged");
     L.ksplit = 1;
     L.cin_per = p.Cin;
     if (p.ksplit > 1 && p.ws) {
         const int per = p.Cin / p.ksplit;
-        if (per >= 2 && per * p.ksplit == p.Cin && (per % 2) == 0) {
-            while (ck > 2 && (per % ck) != 0) ck -= 2;
+        if (per >= CKQ && per * p.ksplit == p.Cin && (per % CKQ) == 0) {
+            while (ck > CKQ && (per % ck) != 0) ck -= CKQ;
             if ((per % ck) == 0) { L.ksplit = p.ksplit; L.cin_per = per; }
         }
     }
@@ -349,7 +431,7 @@ static int launch_convt(const l2i_conv_params& p, hipStream_t st) {
     L.magic_iw = magic_of((unsigned)L.IW);
     L.magic_rc = magic_of((unsigned)L.rows_c);
     L.magic_ih = magic_of((unsigned)L.IH);
-    size_t lds = per_c * ck + (size_t)(ck << L.tb_log2) * sizeof(float);
+    size_t lds = 2 * (per_c * ck + (size_t)(((ck << L.tb_log2) + 3) & ~3) * sizeof(float));
     if (lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     const long grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks * L.ksplit;
     if (grid <= 0 || grid > 0x7fffffffL) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: grid too large");
@@ -380,8 +462,11 @@ extern "C" int l2i_conv_transpose2d_f32(const l2i_conv_params* pp, void* stream)
     if ((((uintptr_t)p.w) % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: packed weights must be 16-byte aligned");
     if ((size_t)p.Cin * p.KH * p.KW * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: weight pack >= 4 GiB");
     hipStream_t st = (hipStream_t)stream;
-    if (p.KH == 3 && p.pad_y == 0) return launch_convt<3, 0, 2>(p, st);
-    if (p.KH == 3 && p.pad_y == 1) return launch_convt<3, 1, 2>(p, st);
+    // 128 positions per block (three blocks per CU) on maps up to 33 positions wide, where 256-position tiles leave a CU with one
+    // or two blocks for most of the launch; 256 positions (two per CU, half the weight traffic per MFMA) above.  tile_hint 1 / 2 force.
+    const bool narrow = p.tile_hint == 1 || (p.tile_hint != 2 && (p.OWf + 1) / 2 <= 33);
+    if (p.KH == 3 && p.pad_y == 0) return narrow ? launch_convt<3, 0, 1>(p, st) : launch_convt<3, 0, 2>(p, st);
+    if (p.KH == 3 && p.pad_y == 1) return narrow ? launch_convt<3, 1, 1>(p, st) : launch_convt<3, 1, 2>(p, st);
     if (p.KH == 7 && p.pad_y == 3) return launch_convt<7, 3, 2>(p, st);
     return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: fused kernel built for (K,pad) in {(3,0),(3,1),(7,3)}");
 }

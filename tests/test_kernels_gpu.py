@@ -83,7 +83,8 @@ def test_conv_prologue_epilogue_fusions():
 
 @pytest.mark.parametrize('cin,cout,k,pad,tr,h,w,b', [(24, 40, 3, 0, True, 17, 17, 2), (40, 24, 3, 1, False, 34, 30, 2), (3, 64, 7, 3, False, 64, 64, 1),
                                                      (64, 3, 7, 3, False, 32, 32, 2), (512, 512, 3, 0, True, 4, 4, 3), (16, 32, 3, 0, False, 9, 9, 2),
-                                                     (512, 96, 3, 0, True, 8, 8, 8), (256, 64, 3, 0, True, 16, 16, 4), (64, 256, 3, 0, False, 17, 17, 8)])   # the last three: split-K
+                                                     (512, 96, 3, 0, True, 8, 8, 8), (256, 64, 3, 0, True, 16, 16, 4), (64, 256, 3, 0, False, 17, 17, 8),   # these three: split-K
+                                                     (20, 40, 3, 0, True, 33, 31, 2), (6, 40, 3, 0, True, 12, 12, 2), (136, 32, 3, 1, False, 40, 40, 1)])   # Cin % 8 != 0; Cin % 4 != 0 (not fused)
 def test_fused_transposed_conv_matches_per_parity_launches(cin, cout, k, pad, tr, h, w, b):
     """One-launch stride-2 transposed conv (l2i_conv_transpose2d_f32) == the four per-parity l2i_conv2d_f32 launches == torch."""
     rs = np.random.RandomState(cin + cout + h)
@@ -113,6 +114,10 @@ def test_fused_transposed_conv_matches_per_parity_launches(cin, cout, k, pad, tr
             conv.USE_FUSED_TRANSPOSED = True
     close(y1, ref, 1e-4, 2e-5)
     close(y0, ref, 1e-4, 2e-5)
+    if k == 3 and cin % 4 == 0 and (tr or cout % 4 == 0):          # both position-tile sizes of the fused kernel
+        for hint in (1, 2):
+            yh = fc.forward(g(x), in_scale=g(s), out_scale=g(d), tile_hint=hint) if tr else fc.dgrad(g(gy), (h, w), in_mask=g(y), mask=(1.0, 0.2), tile_hint=hint)
+            close(yh, ref, 1e-4, 2e-5)
 
 
 @pytest.mark.parametrize('cin,cout,k,h,w,b', [(64, 64, 3, 64, 64, 2), (32, 32, 3, 40, 96, 1), (128, 96, 1, 32, 64, 2), (16, 40, 3, 33, 37, 1),

@@ -32,6 +32,8 @@ SHAPES = [  # name, cin, cout, k, stride, pad, transposed, res, batch
     ('g_up64', 512, 512, 3, 2, 0, True, 32, 8),
     ('g_up64_p1', 512, 512, 3, 2, 1, True, 32, 8),
     ('g_up512_p1', 128, 64, 3, 2, 1, True, 256, 8),
+    ('g_up1024', 64, 32, 3, 2, 0, True, 512, 8),
+    ('g_up256', 256, 128, 3, 2, 0, True, 128, 8),
     ('r_256_1024', 256, 1024, 1, 1, 0, False, 64, 8),
     ('r_1024_256', 1024, 256, 1, 1, 0, False, 64, 8),
     ('r_2048_512', 2048, 512, 1, 1, 0, False, 32, 8),
@@ -46,7 +48,10 @@ def main():
     if len(sys.argv) > 3:
         conv.USE_WINOGRAD = sys.argv[3] != '0'
     rows = []
+    only = os.environ.get('L2I_BENCH_ONLY', '')
     for name, cin, cout, k, stride, pad, tr, res, b in SHAPES:
+        if only and only not in name:
+            continue
         w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
         fc = conv.FrozenConv2d(w, stride, pad, transposed=tr, device='cuda')
         x = torch.randn(b, cin, res, res, device='cuda')
