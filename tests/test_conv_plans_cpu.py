@@ -43,7 +43,7 @@ def test_forward_and_dgrad_plans(cin, cout, k, stride, pad, tr, h, w):
 
 @pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('cin,cout,k,pad,tr,h', [(6, 4, 3, 0, True, 5), (6, 6, 3, 1, False, 12), (6, 6, 3, 1, False, 11), (3, 8, 7, 3, False, 20),
-                                                 (5, 6, 3, 0, False, 9), (8, 5, 7, 3, False, 14)])
+                                                 (5, 6, 3, 0, False, 9), (8, 5, 7, 3, False, 14), (8, 4, 3, 0, True, 5), (6, 8, 3, 1, False, 12)])
 def test_fused_and_phase_transposed_agree(monkeypatch, fused, cin, cout, k, pad, tr, h):
     monkeypatch.setattr(conv, 'USE_FUSED_TRANSPOSED', fused)
     rs = np.random.RandomState(k + h)
@@ -55,7 +55,9 @@ def test_fused_and_phase_transposed_agree(monkeypatch, fused, cin, cout, k, pad,
     gref, = torch.autograd.grad(ref, x, gy)
     np.testing.assert_allclose(fc.forward(x.detach()).numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(fc.dgrad(gy, (h, h)).numpy(), gref.numpy(), rtol=1e-4, atol=1e-4)
-    assert (fc.fwd_fused is not None) == tr and (fc.bwd_fused is not None) == (not tr and cin > 4)
+    # the fused kernel walks its input channels four at a time (K = 3) and is not used for <= 4 output channels
+    assert (fc.fwd_fused is not None) == (tr and cin % 4 == 0)
+    assert (fc.bwd_fused is not None) == (not tr and cin > 4 and cout % 4 == 0)
 
 
 def test_pack_weight_layout():
