@@ -160,7 +160,7 @@ def main():
         def call_bytes(q):
             B, cin, cout, kh, kw, stride, H, W, OH, OW, step, in_mask = q[3][:12]
             flags = q[3][13] if len(q[3]) > 13 else ''
-            extra = sum(1 for c in 'rmoa' if c in flags.rstrip('0123456789'))
+            extra = sum(1 for c in 'rmoas' if c in flags.rstrip('0123456789'))
             return 4.0 * (B * cin * H * W * (2 if in_mask else 1) + B * cout * OH * OW * (1 + extra))
         alg_bytes = sum(call_bytes(q) for q in prof) / len(prof)
         traffic, traffic_note = None, 'no PMC summary for this workload under profiles/'

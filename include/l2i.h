@@ -49,7 +49,8 @@ extern "C" {
  *                                                       * w[ci][ky*KW+kx][co] )     for oy<OH, ox<OW
  *   pro(x) = x * in_scale[b,ci] * (in_mask ? (in_mask[same idx] > 0 ? mask_pos : mask_neg) : 1)
  *   epi(a) = act( a*out_scale[b,co] * (out_mask ? (out_mask[idx] > 0 ? 1 : 0) : 1) + noise[b,oyf,oxf]*noise_w + bias[co]
- *                 + residual[idx] * (res_mask ? (res_mask[idx] > 0 ? 1 : 0) : 1) ) * out_gain  (+ y[idx] if accumulate)
+ *                 + R * (res_mask ? (res_mask[idx] > 0 ? 1 : 0) : 1) ) * out_gain  (+ y[idx] if accumulate)
+ *   R = res_sub ? res_coef * res_coef_dev[0] * (residual[idx] - res_sub[idx]) : residual[idx]
  * Out-of-range input coordinates read as zero (that is the padding).  Transposed (stride-2) convolutions are issued
  * as one call per output phase with (oy_step, ox_step) = 2 and a per-phase packed sub-kernel. */
 typedef struct l2i_conv_params {
@@ -80,6 +81,9 @@ typedef struct l2i_conv_params {
     int32_t ksplit;         /* > 1: the input channels are cut into ksplit ranges computed by separate blocks (raw partial sums in ws),
                                then one reduction pass applies the epilogue: for 4x4..16x16 maps, whose whole K = Cin*KH*KW would
                                otherwise be walked serially by a dozen blocks.  0 / 1: off. */
+    const float* res_sub;   /* like y, or NULL.  Not NULL: the residual term becomes res_coef * res_coef_dev[0] * (residual - res_sub) — the */
+    float res_coef;         /* ContentLoss gradient 2/N * g * (feat - feat_org) of a VGG tap (transform_base.py:57-63) formed inside the     */
+    const float* res_coef_dev;  /* gradient conv that consumes it, instead of a separate pass.  res_coef_dev: 1 float on the device or NULL */
 } l2i_conv_params;
 
 int l2i_conv2d_f32(const l2i_conv_params* p, void* stream);
@@ -147,6 +151,11 @@ int l2i_maxpool2d_fwd_f32(float* y, uint8_t* idx, const float* x, int64_t planes
                           int OH, int OW, void* stream);
 int l2i_maxpool2d_bwd_f32(float* gx, const float* gy, const uint8_t* idx, int64_t planes, int H, int W, int k, int s,
                           int pad, int OH, int OW, void* stream);
+/* MaxPool2d(2, 2) backward fused with the ContentLoss gradient of the pooled layer's input (VGG conv1_2 tap,
+ * transform_base.py:57-63,440-452): gx = maxpool_bwd(gy) + coef * (coef_dev ? coef_dev[0] : 1) * (b - a), a / b / gx [planes, 2*OH, 2*OW].
+ * One pass over a and b instead of sqdiff-gradient + pool backward + add. */
+int l2i_maxpool2x2_bwd_add_diff_f32(float* gx, const float* gy, const uint8_t* idx, const float* a, const float* b, float coef,
+                                    const float* coef_dev, int64_t planes, int OH, int OW, void* stream);
 
 /* ContentLoss (transform_base.py:57-63): sum_out[0] += sum (a-b)^2 ; grad[i] = coef*(coef_dev ? coef_dev[0] : 1)*(b[i]-a[i])
  * (= d/d b of the scaled loss; coef_dev is a device scalar so that the upstream gradient needs no host sync).

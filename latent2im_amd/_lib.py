@@ -33,7 +33,7 @@ class ConvParams(ctypes.Structure):
         ('act', c_i), ('act_slope', c_f), ('act_gain', c_f), ('out_gain', c_f),
         ('accumulate', c_i), ('tile_hint', c_i),
         ('w_hi', c_p), ('w_lo', c_p),
-        ('ws', c_p), ('ksplit', c_i),
+        ('ws', c_p), ('ksplit', c_i), ('res_sub', c_p), ('res_coef', c_f), ('res_coef_dev', c_p),
     ]
 
 
@@ -50,6 +50,7 @@ _SIGNATURES = {
     'l2i_dot_reduce_f32': (c_i, [c_p, c_p, c_p, c_l, c_l, c_p]),
     'l2i_maxpool2d_fwd_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'l2i_maxpool2d_bwd_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'l2i_maxpool2x2_bwd_add_diff_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_l, c_i, c_i, c_p]),
     'l2i_sqdiff_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p]),
     'l2i_axpby_f32': (c_i, [c_p, c_p, c_p, c_f, c_f, c_l, c_p]),
     'l2i_relu_mask_f32': (c_i, [c_p, c_p, c_p, c_l, c_p]),

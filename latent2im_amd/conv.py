@@ -232,7 +232,7 @@ def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), 
 
 def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0), out_scale=None, noise=None,
                noise_w=0.0, bias=None, residual=None, res_mask=None, out_mask=None, act=ACT_NONE, slope=0.2, gain=1.0,
-               out_gain=1.0, accumulate=False, tile_hint=0):
+               out_gain=1.0, accumulate=False, tile_hint=0, res_sub=None, res_coef=1.0, res_coef_dev=None):
     """Enqueue one kernel call on the current stream.  ``y`` is the full output tensor [B, Cout, OHf, OWf]."""
     lib = _lib.load()
     B, cin, H, W = x.shape
@@ -257,6 +257,9 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
     p.mask_pos, p.mask_neg = mask
     p.out_scale, p.noise, p.noise_w, p.bias = _lib.fptr(out_scale), _lib.fptr(noise), float(noise_w), _lib.fptr(bias)
     p.residual, p.res_mask, p.out_mask = _lib.fptr(residual), _lib.fptr(res_mask), _lib.fptr(out_mask)
+    if res_sub is not None:                      # residual term = res_coef * res_coef_dev[0] * (residual - res_sub)
+        assert residual is not None and res_sub.shape == residual.shape
+        p.res_sub, p.res_coef, p.res_coef_dev = _lib.fptr(res_sub), float(res_coef), _lib.fptr(res_coef_dev)
     p.act, p.act_slope, p.act_gain, p.out_gain = act, slope, gain, out_gain
     p.accumulate, p.tile_hint = int(accumulate), tile_hint
     if in_mask is not None:
@@ -273,7 +276,7 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
         entry, name = lib.l2i_conv2d_bf16x3_f32, 'l2i_conv2d_bf16x3_f32'
     elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
-          and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise)):
+          and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise, res_sub)):
         p.w = _lib.fptr(L.wino_pack())
         entry, name = lib.l2i_conv2d_wino_f32, 'l2i_conv2d_wino_f32'
     if PROFILE is not None:
@@ -283,7 +286,7 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         e1.record()
         PROFILE.append((e0, e1, 2.0 * B * L.cout * cin * L.kh * L.kw * OH * OW,
                         (B, cin, L.cout, L.kh, L.kw, L.stride, H, W, OH, OW, L.step, in_mask is not None, in_scale is not None,
-                         ''.join(c for c, t in zip('dnbrmoa', (out_scale, noise, bias, residual, res_mask, out_mask, accumulate or None)) if t is not None) + str(act)),
+                         ''.join(c for c, t in zip('dnbrmoas', (out_scale, noise, bias, residual, res_mask, out_mask, accumulate or None, res_sub)) if t is not None) + str(act)),
                         name))
         return
     _lib.check(entry(p, _lib.stream_ptr()), name)

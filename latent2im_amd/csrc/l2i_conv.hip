@@ -312,6 +312,11 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
                         if (p.bias) { const float bv = p.bias[co]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
                         if (p.residual) {
                             float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
+                            if (p.res_sub) {                                   // residual term = res_coef * (residual - res_sub)
+                                const float4 sb = *reinterpret_cast<const float4*>(p.res_sub + oidx);
+                                const float rc = p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f);
+                                rv.x = rc * (rv.x - sb.x); rv.y = rc * (rv.y - sb.y); rv.z = rc * (rv.z - sb.z); rv.w = rc * (rv.w - sb.w);
+                            }
                             if (p.res_mask) {
                                 const float4 mk = *reinterpret_cast<const float4*>(p.res_mask + oidx);
                                 rv.x = mk.x > 0.f ? rv.x : 0.f; rv.y = mk.y > 0.f ? rv.y : 0.f; rv.z = mk.z > 0.f ? rv.z : 0.f; rv.w = mk.w > 0.f ? rv.w : 0.f;
@@ -367,6 +372,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
                     if (p.bias) v += p.bias[co];
                     if (p.residual) {
                         float rv = p.residual[oidx];
+                        if (p.res_sub) rv = p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) * (rv - p.res_sub[oidx]);
                         if (p.res_mask) rv = (p.res_mask[oidx] > 0.f) ? rv : 0.f;
                         v += rv;
                     }
@@ -577,6 +583,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const l2i_conv_par
         if (p.bias) v += p.bias[co];
         if (p.residual) {
             float rv = p.residual[oidx];
+            if (p.res_sub) rv = p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) * (rv - p.res_sub[oidx]);
             if (p.res_mask) rv = (p.res_mask[oidx] > 0.f) ? rv : 0.f;
             v += rv;
         }
@@ -676,7 +683,7 @@ static bool plan_tile(const l2i_conv_params& p, int wm, int wn, ConvLaunch& L, b
     lds = per_c * ck + (size_t)(ck << L.tb_log2) * sizeof(float);
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
     L.vec_epi = (p.ox_step == 1 && p.oy_step == 1 && (p.OWf % 4) == 0 && (p.OW % 4) == 0 && (p.ox_off % 4) == 0 && L.tw_log2 >= 2 &&
-                 al16(p.y) && al16(p.residual) && al16(p.res_mask) && al16(p.out_mask) && al16(p.noise)) ? 1 : 0;
+                 al16(p.y) && al16(p.residual) && al16(p.res_mask) && al16(p.res_sub) && al16(p.out_mask) && al16(p.noise)) ? 1 : 0;
     if (L.vec_epi && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);      // 8 KiB transpose strip per wave
     grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks * L.ksplit;
     return lds <= 64 * 1024 && grid > 0 && grid <= 0x7fffffffL;
@@ -691,6 +698,7 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
     if (p.KH <= 0 || p.KW <= 0 || p.KH > 16 || p.KW > 16 || (p.stride != 1 && p.stride != 2))
         return l2i_set_error(L2I_E_ARG, "conv2d: kernel size must be 1..16 and stride 1 or 2");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv2d: CoutP must be Cout rounded up to 32");
+    if (p.res_sub && !p.residual) return l2i_set_error(L2I_E_ARG, "conv2d: res_sub needs residual");
     if (p.oy_step <= 0 || p.ox_step <= 0 || (p.OH - 1) * p.oy_step + p.oy_off >= p.OHf || (p.OW - 1) * p.ox_step + p.ox_off >= p.OWf ||
         p.oy_off < 0 || p.ox_off < 0)
         return l2i_set_error(L2I_E_ARG, "conv2d: output window exceeds the output tensor");

@@ -257,6 +257,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const l2i_conv_para
                         if (p.bias) { const float bv = p.bias[co]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
                         if (p.residual) {
                             float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
+                            if (p.res_sub) {                                   // residual term = res_coef * (residual - res_sub)
+                                const float4 sb = *reinterpret_cast<const float4*>(p.res_sub + oidx);
+                                const float rc = p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f);
+                                rv.x = rc * (rv.x - sb.x); rv.y = rc * (rv.y - sb.y); rv.z = rc * (rv.z - sb.z); rv.w = rc * (rv.w - sb.w);
+                            }
                             if (p.res_mask) {
                                 const float4 mk = *reinterpret_cast<const float4*>(p.res_mask + oidx);
                                 rv.x = mk.x > 0.f ? rv.x : 0.f; rv.y = mk.y > 0.f ? rv.y : 0.f; rv.z = mk.z > 0.f ? rv.z : 0.f; rv.w = mk.w > 0.f ? rv.w : 0.f;
@@ -306,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const l2i_conv_para
                     if (p.bias) v += p.bias[co];
                     if (p.residual) {
                         float rv = p.residual[oidx];
+                        if (p.res_sub) rv = p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) * (rv - p.res_sub[oidx]);
                         if (p.res_mask) rv = (p.res_mask[oidx] > 0.f) ? rv : 0.f;
                         v += rv;
                     }
@@ -343,7 +349,7 @@ static int launch16(const l2i_conv_params& p, hipStream_t st) {
     size_t lds = (size_t)(2 * L.nitems + 2 * L.w_vec) * 16;
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
     L.vec_epi = (p.ox_step == 1 && p.oy_step == 1 && (p.OWf % 4) == 0 && (p.OW % 4) == 0 && (p.ox_off % 4) == 0 &&
-                 al16(p.y) && al16(p.residual) && al16(p.res_mask) && al16(p.out_mask) && al16(p.noise)) ? 1 : 0;
+                 al16(p.y) && al16(p.residual) && al16(p.res_mask) && al16(p.res_sub) && al16(p.out_mask) && al16(p.noise)) ? 1 : 0;
     if (L.vec_epi && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     if (lds > 64 * 1024) {
         static bool done = false;

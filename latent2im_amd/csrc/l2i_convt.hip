@@ -457,7 +457,7 @@ extern "C" int l2i_conv_transpose2d_f32(const l2i_conv_params* pp, void* stream)
     const int full_h = (p.H - 1) * 2 - 2 * p.pad_y + p.KH, full_w = (p.W - 1) * 2 - 2 * p.pad_x + p.KW;
     if (p.OHf < full_h || p.OWf < full_w || p.OHf > full_h + 1 || p.OWf > full_w + 1)
         return l2i_set_error(L2I_E_ARG, "conv_transpose2d: output must be the natural size (or one larger: output_padding)");
-    if (p.bias || p.noise || p.residual || p.res_mask || p.out_mask || p.act != L2I_ACT_NONE || p.accumulate)
+    if (p.bias || p.noise || p.residual || p.res_mask || p.res_sub || p.out_mask || p.act != L2I_ACT_NONE || p.accumulate)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: only in_scale / in_mask / out_scale / out_gain are fused here");
     if ((((uintptr_t)p.w) % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: packed weights must be 16-byte aligned");
     if ((size_t)p.Cin * p.KH * p.KW * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: weight pack >= 4 GiB");

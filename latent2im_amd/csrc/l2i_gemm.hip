@@ -147,6 +147,11 @@ __global__ __launch_bounds__(256, MASK ? 2 : 3) void gemm1x1_kernel(const l2i_co
                 if (p.bias) { const float bv = p.bias[co]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
                 if (p.residual) {
                     float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
+                    if (p.res_sub) {                                   // residual term = res_coef * (residual - res_sub)
+                        const float4 sb = *reinterpret_cast<const float4*>(p.res_sub + oidx);
+                        const float rc = p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f);
+                        rv.x = rc * (rv.x - sb.x); rv.y = rc * (rv.y - sb.y); rv.z = rc * (rv.z - sb.z); rv.w = rc * (rv.w - sb.w);
+                    }
                     if (p.res_mask) {
                         const float4 mk = *reinterpret_cast<const float4*>(p.res_mask + oidx);
                         rv.x = mk.x > 0.f ? rv.x : 0.f; rv.y = mk.y > 0.f ? rv.y : 0.f; rv.z = mk.z > 0.f ? rv.z : 0.f; rv.w = mk.w > 0.f ? rv.w : 0.f;
@@ -176,7 +181,7 @@ bool l2i_gemm1x1_eligible(const l2i_conv_params& p) {
     const size_t HW = (size_t)p.H * p.W;
     return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_y == 0 && p.pad_x == 0 && !p.in_scale && p.oy_step == 1 && p.ox_step == 1 &&
            p.oy_off == 0 && p.ox_off == 0 && p.OH == p.H && p.OW == p.W && p.OHf == p.H && p.OWf == p.W && (HW % gm::BN) == 0 && (p.Cin % gm::CK) == 0 &&
-           (p.CoutP % 64) == 0 && al16(p.x) && al16(p.in_mask) && al16(p.y) && al16(p.w) && al16(p.residual) && al16(p.res_mask) && al16(p.out_mask) && al16(p.noise) &&
+           (p.CoutP % 64) == 0 && al16(p.x) && al16(p.in_mask) && al16(p.y) && al16(p.w) && al16(p.residual) && al16(p.res_mask) && al16(p.res_sub) && al16(p.out_mask) && al16(p.noise) &&
            (size_t)p.Cin * HW * sizeof(float) < 0xFFFFFFF0ull;
 }
 

@@ -445,10 +445,12 @@ extern "C" int l2i_dot_reduce_f32(float* out, const float* a, const float* b, in
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ y, uint8_t* __restrict__ idx, const float* __restrict__ x,
                                                           long long planes, int H, int W, int k, int s, int pad, int OH, int OW) {
     const long long total = planes * OH * OW;
+    const unsigned OHW = (unsigned)OH * (unsigned)OW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ox = (int)(i % OW);
-        const int oy = (int)((i / OW) % OH);
-        const long long pl = i / ((long long)OW * OH);
+        const long long pl = i / OHW;                          // one 64-bit division; the rest is 32-bit
+        const unsigned rem = (unsigned)(i - pl * OHW);
+        const int oy = (int)(rem / (unsigned)OW);
+        const int ox = (int)(rem - (unsigned)oy * (unsigned)OW);
         const float* xp = x + pl * H * W;
         float best = -INFINITY;
         int bi = 0;
@@ -468,13 +470,18 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ y,
     }
 }
 
+// KT/ST/PT > 0: compile-time geometry (3,2,1 = the ResNet stem pool: the window arithmetic becomes shifts); 0: run-time k, s, pad
+template <int KT, int ST, int PT>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(float* __restrict__ gx, const float* __restrict__ gy, const uint8_t* __restrict__ idx,
-                                                          long long planes, int H, int W, int k, int s, int pad, int OH, int OW) {
+                                                          long long planes, int H, int W, int k_, int s_, int pad_, int OH, int OW) {
+    const int k = KT ? KT : k_, s = KT ? ST : s_, pad = KT ? PT : pad_;
     const long long total = planes * H * W;
+    const unsigned HW = (unsigned)H * (unsigned)W;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ix = (int)(i % W);
-        const int iy = (int)((i / W) % H);
-        const long long pl = i / ((long long)W * H);
+        const long long pl = i / HW;
+        const unsigned rem = (unsigned)(i - pl * HW);
+        const int iy = (int)(rem / (unsigned)W);
+        const int ix = (int)(rem - (unsigned)iy * (unsigned)W);
         float g = 0.f;
         // windows that contain (iy, ix): oy in [ceil((iy+pad-k+1)/s), floor((iy+pad)/s)]
         int oy_lo = iy + pad - k + 1; oy_lo = oy_lo <= 0 ? 0 : (oy_lo + s - 1) / s;
@@ -524,7 +531,48 @@ extern "C" int l2i_maxpool2d_bwd_f32(float* gx, const float* gy, const uint8_t* 
         L2I_CHECK_LAUNCH();
         return L2I_OK;
     }
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(l2i_grid_for(planes * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gx, gy, idx, (long long)planes, H, W, k, s, pad, OH, OW);
+    if ((long long)H * W >= 0x7fffffffLL) return l2i_set_error(L2I_E_ARG, "maxpool_bwd: plane too large");
+    if (k == 3 && s == 2 && pad == 1)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2, 1>), dim3(l2i_grid_for(planes * H * W, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, gx, gy, idx, (long long)planes, H, W, k, s, pad, OH, OW);
+    else
+        hipLaunchKernelGGL((maxpool_bwd_kernel<0, 0, 0>), dim3(l2i_grid_for(planes * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gx, gy, idx, (long long)planes, H, W, k, s, pad, OH, OW);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+// 2x2/2 pool backward + content-loss gradient of the pool's input in one pass: a thread owns two horizontally adjacent windows
+// = 4 consecutive pixels of two rows: 16-byte loads of a and b, 16-byte stores of gx.
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_add_diff_kernel(float* __restrict__ gx, const float* __restrict__ gy, const uint8_t* __restrict__ idx,
+                                                                      const float* __restrict__ a, const float* __restrict__ b, float coef,
+                                                                      const float* __restrict__ coef_dev, long long planes, int OH, int OW) {
+    if (coef_dev) coef *= coef_dev[0];
+    const int OW2 = OW >> 1, W = 2 * OW;
+    const long long total = planes * OH * OW2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox2 = (int)(i % OW2);
+        const long long row = i / OW2;                         // plane * OH + oy
+        const float2 g = *reinterpret_cast<const float2*>(gy + row * OW + 2 * ox2);
+        const int i0 = idx[row * OW + 2 * ox2], i1 = idx[row * OW + 2 * ox2 + 1];
+        const long long base = (2 * row) * (long long)W + 4 * ox2;       // rows 2*oy of plane: (plane*OH + oy) * 2 rows of width W
+        const float4 a0 = *reinterpret_cast<const float4*>(a + base), a1 = *reinterpret_cast<const float4*>(a + base + W);
+        const float4 b0 = *reinterpret_cast<const float4*>(b + base), b1 = *reinterpret_cast<const float4*>(b + base + W);
+        float4 r0, r1;
+        r0.x = coef * (b0.x - a0.x) + (i0 == 0 ? g.x : 0.f); r0.y = coef * (b0.y - a0.y) + (i0 == 1 ? g.x : 0.f);
+        r0.z = coef * (b0.z - a0.z) + (i1 == 0 ? g.y : 0.f); r0.w = coef * (b0.w - a0.w) + (i1 == 1 ? g.y : 0.f);
+        r1.x = coef * (b1.x - a1.x) + (i0 == 2 ? g.x : 0.f); r1.y = coef * (b1.y - a1.y) + (i0 == 3 ? g.x : 0.f);
+        r1.z = coef * (b1.z - a1.z) + (i1 == 2 ? g.y : 0.f); r1.w = coef * (b1.w - a1.w) + (i1 == 3 ? g.y : 0.f);
+        *reinterpret_cast<float4*>(gx + base) = r0;
+        *reinterpret_cast<float4*>(gx + base + W) = r1;
+    }
+}
+
+extern "C" int l2i_maxpool2x2_bwd_add_diff_f32(float* gx, const float* gy, const uint8_t* idx, const float* a, const float* b, float coef,
+                                               const float* coef_dev, int64_t planes, int OH, int OW, void* stream) {
+    if (!gx || !gy || !idx || !a || !b) return l2i_set_error(L2I_E_ARG, "maxpool2x2_bwd_add_diff: null tensor");
+    if (planes <= 0 || OH <= 0 || OW <= 0 || (OW & 1)) return l2i_set_error(L2I_E_ARG, "maxpool2x2_bwd_add_diff: OW must be even and positive");
+    if (((uintptr_t)gx | (uintptr_t)a | (uintptr_t)b) % 16 || ((uintptr_t)gy) % 8) return l2i_set_error(L2I_E_ARG, "maxpool2x2_bwd_add_diff: tensors must be 16-byte aligned");
+    hipLaunchKernelGGL(maxpool2x2_bwd_add_diff_kernel, dim3(l2i_grid_for(planes * OH * (OW / 2), 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream,
+                       gx, gy, idx, a, b, coef, coef_dev, (long long)planes, OH, OW);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }

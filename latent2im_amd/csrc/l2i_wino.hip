@@ -295,6 +295,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
             va = pk_add(va, pk_add(f32x2{nz.x, nz.y}, bvp)); vb = pk_add(vb, pk_add(f32x2{nz.z, nz.w}, bvp));
             if (p.residual) {
                 float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
+                if (p.res_sub) {                                   // residual term = res_coef * (residual - res_sub)
+                    const float4 sb = *reinterpret_cast<const float4*>(p.res_sub + oidx);
+                    const float rc = p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f);
+                    rv.x = rc * (rv.x - sb.x); rv.y = rc * (rv.y - sb.y); rv.z = rc * (rv.z - sb.z); rv.w = rc * (rv.w - sb.w);
+                }
                 if (p.res_mask) {
                     const float4 mk = *reinterpret_cast<const float4*>(p.res_mask + oidx);
                     rv.x = mk.x > 0.f ? rv.x : 0.f; rv.y = mk.y > 0.f ? rv.y : 0.f; rv.z = mk.z > 0.f ? rv.z : 0.f; rv.w = mk.w > 0.f ? rv.w : 0.f;
@@ -350,7 +355,7 @@ extern "C" int l2i_conv2d_wino_f32(const l2i_conv_params* pp, void* stream) {
     if (p.oy_off < 0 || p.ox_off < 0 || p.OH + p.oy_off > p.OHf || p.OW + p.ox_off > p.OWf)
         return l2i_set_error(L2I_E_ARG, "conv2d_wino: output window exceeds the output tensor");
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
-    if ((p.OWf % 4) != 0 || (p.OW % 4) != 0 || (p.ox_off % 4) != 0 || !al16(p.y) || !al16(p.residual) || !al16(p.res_mask) || !al16(p.out_mask) ||
+    if ((p.OWf % 4) != 0 || (p.OW % 4) != 0 || (p.ox_off % 4) != 0 || !al16(p.y) || !al16(p.residual) || !al16(p.res_mask) || !al16(p.res_sub) || !al16(p.out_mask) ||
         !al16(p.noise) || !al16(p.w))
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino: output rows must be 16-byte aligned multiples of 4 pixels");
     if ((size_t)p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull || (size_t)p.Cin * 16 * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull)

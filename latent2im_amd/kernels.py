@@ -113,6 +113,17 @@ def maxpool2d_bwd(gy, idx, in_hw, k, s, pad):
     return gx
 
 
+def maxpool2x2_bwd_add_diff(gy, idx, a, b, coef, coef_dev=None):
+    """maxpool(2,2) backward of ``gy`` plus coef*coef_dev*(b - a) on the pool's input, in one pass (VGG conv1_2 tap)."""
+    lib = _lib.load()
+    n, c, oh, ow = gy.shape
+    assert a.shape == b.shape == (n, c, 2 * oh, 2 * ow)
+    gx = torch.empty_like(b)
+    _lib.check(lib.l2i_maxpool2x2_bwd_add_diff_f32(_lib.fptr(gx), _lib.fptr(gy), _lib.ptr(idx), _lib.fptr(a), _lib.fptr(b), float(coef),
+                                                   _lib.fptr(coef_dev), n * c, oh, ow, _lib.stream_ptr()), 'l2i_maxpool2x2_bwd_add_diff_f32')
+    return gx
+
+
 def sqdiff(a, b, coef=0.0, want_grad=False, coef_dev=None, want_sum=True):
     """sum((b-a)^2) as a 1-element tensor, and optionally coef*coef_dev*(b-a) (coef_dev: 1-element device tensor)."""
     lib = _lib.load()

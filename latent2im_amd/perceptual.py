@@ -65,19 +65,21 @@ class _ContentFn(torch.autograd.Function):
         gl = [g_losses[k:k + 1].contiguous() for k in range(4)]   # device scalars: no host sync in the backward
         # direct term of every tap: d/d c_k [ mean (c_k - o_k)^2 ] = 2 (c_k - o_k) / N_k
         d4 = K.sqdiff(o4, c4, coef=2.0 / c4.numel(), coef_dev=gl[3], want_grad=True, want_sum=False)[1]
-        d3 = K.sqdiff(o3, c3, coef=2.0 / c3.numel(), coef_dev=gl[2], want_grad=True, want_sum=False)[1]
-        g3 = net.convs[3].dgrad(d4, (c3.shape[2], c3.shape[3]), out_mask=c3, residual=d3)
-        del d4, d3
+        # the direct term of tap 3 is formed inside the gradient conv's epilogue: + 2/N g (c3 - o3)
+        g3 = net.convs[3].dgrad(d4, (c3.shape[2], c3.shape[3]), out_mask=c3, residual=c3, res_sub=o3, res_coef=2.0 / c3.numel(), res_coef_dev=gl[2])
+        del d4
         gp = net.convs[2].dgrad(g3, (p.shape[2], p.shape[3]), out_mask=p)
         del g3
-        g2 = K.maxpool2d_bwd(gp, idx, (c2.shape[2], c2.shape[3]), 2, 2, 0)
+        if c2.shape[3] % 4 == 0 and c2.shape[2] % 2 == 0:      # pool backward + direct term of tap 2 in one pass
+            g2 = K.maxpool2x2_bwd_add_diff(gp, idx, o2, c2, 2.0 / c2.numel(), gl[1])
+        else:
+            g2 = K.maxpool2d_bwd(gp, idx, (c2.shape[2], c2.shape[3]), 2, 2, 0)
+            d2 = K.sqdiff(o2, c2, coef=2.0 / c2.numel(), coef_dev=gl[1], want_grad=True, want_sum=False)[1]
+            K.axpby(g2, d2, 1.0, 1.0, out=g2)
+            del d2
         del gp
-        d2 = K.sqdiff(o2, c2, coef=2.0 / c2.numel(), coef_dev=gl[1], want_grad=True, want_sum=False)[1]
-        K.axpby(g2, d2, 1.0, 1.0, out=g2)
-        del d2
-        d1 = K.sqdiff(o1, c1, coef=2.0 / c1.numel(), coef_dev=gl[0], want_grad=True, want_sum=False)[1]
-        g1 = net.convs[1].dgrad(g2, (c1.shape[2], c1.shape[3]), out_mask=c1, residual=d1)
-        del g2, d1
+        g1 = net.convs[1].dgrad(g2, (c1.shape[2], c1.shape[3]), out_mask=c1, residual=c1, res_sub=o1, res_coef=2.0 / c1.numel(), res_coef_dev=gl[0])
+        del g2
         g_img = net.convs[0].dgrad(g1, ctx.in_hw)
         ctx.acts = ctx.org = None
         return g_img, None, None

@@ -64,7 +64,7 @@ def smoke():
     nets = dict(G=ostep.to_torch(synth.generator_state(64, seed=100), dt), D=ostep.to_torch(synth.discriminator_state(64, seed=200), dt),
                 R=ostep.to_torch(synth.resnet50_state(seed=300), dt), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400), dt))
     o = ostep.train_step(nets, torch.from_numpy(synth.walk_init(1, 10, seed=7)).to(dt), torch.from_numpy(zs), torch.from_numpy(alpha), [31])
-    img_err = float((r['x1'].double().cpu() - o['x1']).abs().max())
+    img_err = float((r['x1'].detach().double().cpu() - o['x1']).abs().max())
     loss_err = abs(float(r['loss']) - float(o['loss']))
     gerr = float((r['grad'].double().cpu() - o['grad']).abs().max() / o['grad'].abs().max())
     print('smoke: loss %.6f (oracle %.6f)  max|dimg| %.2e  walk-grad rel-to-max err %.2e' % (float(r['loss']), float(o['loss']), img_err, gerr))

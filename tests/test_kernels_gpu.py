@@ -341,3 +341,47 @@ def test_maxpool(k, s, pad, h):
     gref, = torch.autograd.grad(ref, x, gy)
     gx = kernels.maxpool2d_bwd(gy.to(DEV), idx, (h, h), k, s, pad)
     close(gx, gref, 1e-6, 1e-6)
+
+
+@pytest.mark.parametrize('h,w', [(16, 16), (6, 40), (64, 4)])
+def test_maxpool2x2_backward_fused_with_content_gradient(h, w):
+    """gx = maxpool_bwd(gy) + coef * coef_dev * (b - a) in one pass == the three separate kernels (ties included)."""
+    rs = np.random.RandomState(h + w)
+    x = torch.relu(T(rs.randn(3, 5, h, w)))
+    o = T(rs.randn(3, 5, h, w))
+    y, idx = kernels.maxpool2d_fwd(x.to(DEV), 2, 2, 0)
+    gy = T(rs.randn(*y.shape)).to(DEV)
+    cd = torch.tensor([0.7], device=DEV)
+    want = kernels.maxpool2d_bwd(gy, idx, (h, w), 2, 2, 0) + kernels.sqdiff(o.to(DEV), x.to(DEV), coef=0.3, coef_dev=cd, want_grad=True, want_sum=False)[1]
+    got = kernels.maxpool2x2_bwd_add_diff(gy, idx, o.to(DEV), x.to(DEV), 0.3, cd)
+    close(got, want, 1e-6, 1e-6)
+    xr = x.clone().requires_grad_(True)
+    ref, = torch.autograd.grad(F.max_pool2d(xr, 2, 2), xr, gy.cpu())
+    close(got, ref + 0.3 * 0.7 * (x - o), 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize('cin,cout,k,h,w,b,precision', [(64, 64, 3, 64, 64, 2, 'f32'),      # Winograd kernel
+                                                         (16, 40, 3, 20, 24, 1, 'f32'),      # implicit-GEMM kernel, wide epilogue
+                                                         (16, 40, 3, 21, 23, 1, 'f32'),      # ... scalar epilogue (odd width)
+                                                         (64, 64, 1, 32, 32, 2, 'f32'),      # DMA-fed 1x1 GEMM
+                                                         (512, 64, 3, 8, 8, 2, 'f32'),       # split-K second pass
+                                                         (64, 64, 3, 64, 64, 1, 'bf16x3')])
+def test_conv_epilogue_difference_residual(cin, cout, k, h, w, b, precision):
+    """res_sub: the residual term becomes res_coef * res_coef_dev[0] * (residual - res_sub) (the ContentLoss gradient of a VGG
+    tap formed inside the gradient conv), in every kernel family's epilogue, with and without the residual mask."""
+    rs = np.random.RandomState(cin + cout + h + w)
+    wt = T(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    x, feat, org = T(rs.randn(b, cin, h, w)), T(rs.randn(b, cout, h, w)), T(rs.randn(b, cout, h, w))
+    cd = torch.tensor([1.7], device=DEV)
+    g = lambda t: t.to(DEV)
+    old, conv.PRECISION = conv.PRECISION, precision
+    try:
+        fc = conv.FrozenConv2d(wt, 1, k // 2, device=DEV)
+        y = fc.forward(g(x), out_mask=g(feat), residual=g(feat), res_sub=g(org), res_coef=0.25, res_coef_dev=cd)
+        ref = F.conv2d(x, wt, padding=k // 2) * (feat > 0) + 0.25 * 1.7 * (feat - org)
+        close(y, ref, 1e-4, 2e-5)
+        y = fc.forward(g(x), residual=g(feat), res_sub=g(org), res_coef=-2.0, res_mask=g(org), act=conv.ACT_RELU)
+        ref = torch.relu(F.conv2d(x, wt, padding=k // 2) - 2.0 * (feat - org) * (org > 0))
+        close(y, ref, 1e-4, 2e-5)
+    finally:
+        conv.PRECISION = old
