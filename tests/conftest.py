@@ -11,6 +11,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
 def pytest_configure(config):
+    # the CPU oracle: torch's CPU convolutions collapse beyond a few dozen threads (256 hardware threads on the GPU box: 5x slower)
+    import torch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'slow: takes more than a few seconds on CPU')
 

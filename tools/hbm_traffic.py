@@ -6,8 +6,8 @@
 
 into profiles/<name>.json: HBM bytes per kernel family and per conv launch.  Corrections (MI355X_MICROARCH.md, "HBM"):
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read, so it is
-doubled; both factors are checked on the axpby_kernel launches of the same run (y = a + b over a known element count: 8 B read,
-4 B written per element: measured 2.00 and 1.00).
+doubled; both factors are checked on a streaming kernel of known byte count in the same run (maxpool2x2_bwd_add_diff_kernel:
+9.25 B read, 4 B written per element; an earlier build's axpby_kernel gave 2.00 and 1.00).
 
     python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_conv_hbm_traffic.json
 """
@@ -28,7 +28,7 @@ def load(d, name):
     return out
 
 
-def main(df, dw, dst, steps=2, axpby_elems=8 * 64 * 1024 * 1024):
+def main(df, dw, dst, steps=2, cal_elems=8 * 64 * 1024 * 1024):
     f, w = load(df, 'FETCH_SIZE'), load(dw, 'WRITE_SIZE')
     fam = collections.defaultdict(lambda: dict(launches=0, fetch_raw=0.0, write_raw=0.0))
     for i, (k, g, v) in f.items():
@@ -37,12 +37,13 @@ def main(df, dw, dst, steps=2, axpby_elems=8 * 64 * 1024 * 1024):
         a['fetch_raw'] += v
     for i, (k, g, v) in w.items():
         fam[k]['write_raw'] += v
-    # calibration: axpby_kernel(y = a + b) runs once per step, on the VGG conv1_1 gradient [8, 64, 1024, 1024] of the default workload
+    # calibration on a kernel of known byte count in the same run: maxpool2x2_bwd_add_diff_kernel runs once per step on the VGG conv1_2 tap
+    # [8, 64, 1024, 1024] of the default workload: per output element 8 B read (a, b) + 5/4 B (pooled gradient, arg-max byte), 4 B written
     cal_r = cal_w = None
-    ax = [(g, v, w[i][2]) for i, (k, g, v) in f.items() if k == 'axpby_kernel' and i in w and w[i][0] == k]
+    ax = [(g, v, w[i][2]) for i, (k, g, v) in f.items() if k == 'maxpool2x2_bwd_add_diff_kernel' and i in w and w[i][0] == k]
     if ax:
-        n = axpby_elems * len(ax)
-        cal_r = 8.0 * n / sum(v for _, v, _ in ax)
+        n = cal_elems * len(ax)
+        cal_r = (8.0 + 1.25) * n / sum(v for _, v, _ in ax)
         cal_w = 4.0 * n / sum(x for _, _, x in ax)
     fr, fw = 2.0, 1.0
     rows = {}
@@ -56,8 +57,8 @@ def main(df, dw, dst, steps=2, axpby_elems=8 * 64 * 1024 * 1024):
             conv['bytes'] += b
     out = dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --serial_streams, %d steps' % steps,
                corrections=dict(unit='KiB -> bytes', fetch_factor=fr, write_factor=fw,
-                                calibration_axpby=dict(read_factor_measured=cal_r, write_factor_measured=cal_w,
-                                                       note='known bytes / reported bytes on axpby_kernel launches of the same run')),
+                                calibration=dict(kernel='maxpool2x2_bwd_add_diff_kernel', read_factor_measured=cal_r, write_factor_measured=cal_w,
+                                                       note='known bytes / reported bytes on that kernel in the same run')),
                conv_launches_per_step=conv['launches'] / steps, conv_bytes_per_step=conv['bytes'] / steps,
                conv_bytes_per_launch=conv['bytes'] / max(conv['launches'], 1),
                all_kernels_GB_per_step=round(sum(fr * a['fetch_raw'] + fw * a['write_raw'] for a in fam.values()) / steps / 1e9, 2),
