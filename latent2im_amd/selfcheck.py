@@ -54,6 +54,8 @@ def smoke():
     from . import synth
     from oracle import step as ostep                     # checker only
     assert torch.cuda.is_available(), 'smoke() needs the MI355X'
+    import os
+    torch.set_num_threads(min(32, os.cpu_count() or 1))          # the CPU checker: torch's CPU convs collapse at hundreds of threads
     torch.cuda.set_device(0)
     g = build_graph(64, ['Smiling'], 4)
     zs = synth.z_sample(4, seed=0)

@@ -240,10 +240,10 @@ def test_full_size_1024_forward_parity_and_consistency(precision):
         assert float((c.forward(a, tile_hint=hint) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize('size,batch,attrs,clamp', [(256, 8, ['Smiling'], False),
+@pytest.mark.parametrize('size,batch,attrs,clamp', [(256, 16, ['Smiling'], False),
                                                     (1024, 1, ['Smiling', 'Young', 'Male', 'Eyeglasses', 'Bangs'], True)])
 def test_full_size_training_step_vs_oracle(size, batch, attrs, clamp):
-    """BASELINE configs 2 (256^2, one attribute, train.py flow; batch 8 of its 16 to keep the CPU oracle under a minute) and 3/4 (1024^2, five attributes, train_multi_attr.py
+    """BASELINE configs 2 (256^2, batch 16, one attribute, train.py flow) and 3/4 (1024^2, five attributes, train_multi_attr.py
     clamp flow; one sample, which is what the CPU oracle finishes in under a minute): a whole training step — both generator
     passes, regressor, VGG content, discriminator, backward into the walk — against the float32 CPU oracle on the same z/seed.
     Images, alpha_org and every loss term within rtol 1e-3 / atol 1e-4 (the per-attribute regressor loss included); the walk
