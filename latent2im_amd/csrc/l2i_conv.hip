@@ -711,6 +711,7 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
         return launch_direct_small(p, (hipStream_t)stream);
 
     if (p.tile_hint == 0 && l2i_gemm1x1_eligible(p)) return l2i_launch_gemm1x1(p, (hipStream_t)stream);
+    if (p.tile_hint == 0 && l2i_cin3_eligible(p)) return l2i_launch_cin3(p, (hipStream_t)stream);
 
     // ---- tile selection: minimise a simple time model  waves(grid / resident blocks) x cycles per block  ----
     //      cycles per block = MFMA issue (64 cycles each) + per-chunk barrier/commit cost + epilogue stores (hidden by co-resident blocks);

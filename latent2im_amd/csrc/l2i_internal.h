@@ -8,6 +8,8 @@ int l2i_set_error(int code, const char* msg);   // records msg for l2i_last_erro
 struct l2i_conv_params;
 bool l2i_gemm1x1_eligible(const l2i_conv_params& p);              // l2i_gemm.hip: DMA-fed GEMM form of unmasked 1x1 stride-1 layers
 int l2i_launch_gemm1x1(const l2i_conv_params& p, hipStream_t st);
+bool l2i_cin3_eligible(const l2i_conv_params& p);                 // l2i_cin3.hip: 3x3 convs of <= 3-channel images as one 27-long contraction
+int l2i_launch_cin3(const l2i_conv_params& p, hipStream_t st);
 int l2i_launch_splitk_epilogue(const l2i_conv_params& q, hipStream_t st);     // l2i_conv.hip: y = epilogue(sum of q.ksplit partials in q.ws)
 
 #define L2I_CHECK_LAUNCH()                                                      \

@@ -385,3 +385,19 @@ def test_conv_epilogue_difference_residual(cin, cout, k, h, w, b, precision):
         close(y, ref, 1e-4, 2e-5)
     finally:
         conv.PRECISION = old
+
+
+@pytest.mark.parametrize('cin,cout,h,w,b', [(3, 64, 64, 128, 2), (3, 64, 20, 36, 1), (1, 96, 8, 8, 2), (2, 40, 33, 12, 1)])
+def test_small_cin_3x3_conv_as_one_contraction(cin, cout, h, w, b):
+    """<= 3 input channels, 3x3 stride 1 (VGG conv1_1 on the image): the 27-long im2col contraction kernel; bias / activation /
+    gain fused; tile_hint != 0 forces the generic kernel for comparison."""
+    rs = np.random.RandomState(cin + cout + h + w)
+    wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    x, bias = T(rs.randn(b, cin, h, w)), T(rs.randn(cout))
+    fc = conv.FrozenConv2d(wt, 1, 1, device=DEV)
+    g = lambda t: t.to(DEV)
+    ref = F.conv2d(x, wt, bias, padding=1)
+    close(fc.forward(g(x), bias=g(bias)), ref, 1e-4, 2e-5)
+    close(fc.forward(g(x), bias=g(bias), tile_hint=2), ref, 1e-4, 2e-5)
+    close(fc.forward(g(x), bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5, out_gain=0.5), F.leaky_relu(ref, 0.2) * 2 ** 0.5 * 0.5, 1e-4, 2e-5)
+    close(fc.forward(g(x), act=conv.ACT_RELU), torch.relu(F.conv2d(x, wt, padding=1)), 1e-4, 2e-5)
