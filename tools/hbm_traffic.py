@@ -17,7 +17,7 @@ import json
 import sys
 
 CONV = ('conv_wino_kernel', 'conv_mfma_kernel', 'gemm1x1_kernel', 'convt_mfma_kernel', 'conv_direct_small_kernel',
-        'conv16_kernel', 'splitk_epilogue_kernel')
+        'conv16_kernel', 'conv_cin3_kernel', 'splitk_epilogue_kernel')
 
 
 def load(d, name):
