@@ -118,7 +118,7 @@ def main():
     # roofline of the dominant kernel: the same steps again, now with a HIP event pair around every conv launch on the
     # launch stream.  Kept out of the timed region above because ~280 event pairs per step cost ~7 % wall on their own.
     prof, t_events = None, None
-    if not a.no_kernel_events and rk == 0:
+    if not a.no_kernel_events:            # every rank repeats the steps (the walk-gradient all-reduce is inside a step); rank 0 reports
         concurrent, constants.CONCURRENT_LOSS_BRANCHES = constants.CONCURRENT_LOSS_BRANCHES, False   # one stream: durations do not overlap
         conv.PROFILE = []
         torch.cuda.synchronize()

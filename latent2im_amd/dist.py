@@ -30,9 +30,10 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
+            backend = os.environ.get('L2I_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            # one GPU per rank; more ranks than GPUs only with L2I_DIST_BACKEND=gloo (control-flow rehearsal on a single-GPU box)
+            torch.cuda.set_device(local if backend == 'nccl' else local % torch.cuda.device_count())
         td.init_process_group(backend=backend, rank=rk, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
