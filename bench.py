@@ -150,6 +150,7 @@ def main():
                    note='same workload and steps with the matrix path switched (see DESIGN.md section 2); not the headline value')
 
     if rk != 0:
+        dist.shutdown()
         return
     ms_per_step = elapsed / a.steps * 1e3
     value = global_b * a.steps / elapsed
@@ -211,6 +212,7 @@ def main():
     else:
         out['cpu_baseline'] = None
     print(json.dumps(out), flush=True)
+    dist.shutdown()
 
 
 if __name__ == '__main__':

@@ -4,6 +4,7 @@ networks (0.33 GB fp32) and a slice of each batch; the only exchange per step is
 ([n_attr, n_latent, 512] fp32 = 28..184 KB -> latency-bound, a single small-message collective, nothing to bucket or
 overlap: it is the last op before Adam).  The reference has no distributed code at all (SURVEY §2 last rows)."""
 import os
+import tempfile
 
 import torch
 import torch.distributed as td
@@ -26,7 +27,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rk = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', str(rk)))
-    if world > 1 and not is_initialized():
+    if (world > 1 or os.environ.get('L2I_FORCE_PG')) and not is_initialized():      # L2I_FORCE_PG: build the group for one rank too (rehearsal)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -34,7 +35,15 @@ def init_from_env(backend=None):
         if torch.cuda.is_available():
             # one GPU per rank; more ranks than GPUs only with L2I_DIST_BACKEND=gloo (control-flow rehearsal on a single-GPU box)
             torch.cuda.set_device(local if backend == 'nccl' else local % torch.cuda.device_count())
-        td.init_process_group(backend=backend, rank=rk, world_size=world)
+        if backend == 'nccl':
+            # RCCL writes its NCCL_DEBUG output (the box exports NCCL_DEBUG=VERSION: a version banner, flushed at exit) to STDOUT,
+            # where a driver expects exactly one JSON line: send it to a file instead
+            os.environ.setdefault('NCCL_DEBUG_FILE', os.path.join(tempfile.gettempdir(), 'rccl_debug_%h_%p.log'))
+            if os.environ.get('NCCL_DEBUG', '').upper() == 'VERSION':      # the version banner ignores NCCL_DEBUG_FILE (measured)
+                del os.environ['NCCL_DEBUG']
+            td.init_process_group(backend=backend, rank=rk, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            td.init_process_group(backend=backend, rank=rk, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
     return rk, world, local
@@ -74,6 +83,11 @@ def average_gradients(params):
 def barrier():
     if is_initialized():
         td.barrier()
+
+
+def shutdown():
+    if is_initialized():
+        td.destroy_process_group()
 
 
 def max_over_ranks(value, device=None):
