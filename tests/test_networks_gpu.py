@@ -468,3 +468,27 @@ def test_eval_cli_after_training(tmp_path):
         assert sum(last['bucket_sizes']) <= 4 * 3                       # reference quirk: only the last batch is scored
     finally:
         constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
+def test_train_multi_attr_cli(tmp_path):
+    """train_multi_attr.py (BASELINE config 4 flow: five CelebA attributes, clamped targets, full loss) end to end at 32^2: the
+    walk tensor has one direction per attribute and moves; log and checkpoints are written under the reference's names."""
+    import os
+    from latent2im_amd import constants, trainer
+    os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    models = str(tmp_path / 'models')
+    argv = ['--model', 'stylegan_v2_real', '--transform', 'face', '--num_samples', '8', '--learning_rate', '1e-3', '--latent', 'w',
+            '--walk_type', 'linear', '--loss', 'l2', '--attrList', 'Smiling,Young,Male,Eyeglasses,Bangs',
+            '--attrPath', './dataset/attributes_celeba.txt', '--models_dir', models, '--overwrite_config', '--resolution', '32',
+            '--batch_size', '4', '--n_epoch', '1', '--seed', '3', '--model_save_freq', '1']
+    try:
+        trainer.main(multi_attr=True, argv=argv)
+        out = os.path.join(models, 'stylegan_v2_real_face_linear_lr0.001_l2_w')
+        first = torch.load(os.path.join(out, 'model_w_0_walk_module.ckpt'), map_location='cpu', weights_only=False)
+        last = torch.load(os.path.join(out, 'model_w_1_final_walk_module.ckpt'), map_location='cpu', weights_only=False)
+        assert tuple(last.w.shape) == (5, 8, 512) and torch.isfinite(last.w).all()
+        assert torch.equal(last.w.detach(), first.w.detach())                     # one epoch: the epoch-0 and the final checkpoint are the same state
+        assert float(last.w.detach().std()) > 0.01                               # N(0, 0.02) init, moved by two Adam steps
+        assert 'T, epc, bst, lss, alpha:' in open(os.path.join(out, 'log.txt')).read()
+    finally:
+        constants.resolution, constants.BATCH_SIZE = 256, 4
