@@ -7,7 +7,11 @@ resolution = 256
 useGPU = True
 NUM_CHANNELS = 3
 
-# checkpoint paths (reference placeholders '/path/...'); a missing file selects deterministic synthetic weights
+# checkpoint paths (reference placeholders '/path/...').  A configured path that does not exist is an ERROR (the reference
+# crashes in torch.load, transform_base.py:524-547) unless synthetic weights are requested explicitly: --synthetic_weights
+# on the drivers, L2I_SYNTHETIC_WEIGHTS=1 in the environment, or ALLOW_SYNTHETIC_WEIGHTS = True (bench.py, tests, smoke()).
+import os as _os
+ALLOW_SYNTHETIC_WEIGHTS = _os.environ.get('L2I_SYNTHETIC_WEIGHTS', '') == '1'
 reg_json = None
 reg_path = '/path/003_dict.model'
 g_path = '/path/550000.pt'

@@ -22,6 +22,21 @@ def world_size():
     return td.get_world_size() if is_initialized() else 1
 
 
+def select_gpu(gpu):
+    """``--gpu`` of the drivers (reference train.py:150 / vis_w.py: CUDA_VISIBLE_DEVICES set before the first CUDA call).  Must run
+    BEFORE anything initialises the HIP runtime: then the variable is exported (HIP honours both spellings); if the runtime is
+    already up (a caller built a graph earlier in the process) the first listed id becomes the current device instead.  Ignored
+    under torchrun (LOCAL_RANK picks the device) and when the launcher already pinned HIP_VISIBLE_DEVICES.  Never re-execs."""
+    if not gpu or int(os.environ.get('WORLD_SIZE', '1')) > 1 or 'HIP_VISIBLE_DEVICES' in os.environ:
+        return
+    gpu = str(gpu)
+    if torch.cuda.is_initialized():
+        torch.cuda.set_device(int(gpu.split(',')[0]))
+    else:
+        os.environ['CUDA_VISIBLE_DEVICES'] = gpu
+        os.environ['HIP_VISIBLE_DEVICES'] = gpu
+
+
 def init_from_env(backend=None):
     """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -44,7 +44,10 @@ def main(argv=None, all_batches=False):
     v.parser.add_argument('--trainEmbed', action='store_true')
     v.parser.add_argument('--updateGAN', action='store_true')
     opt, conf = v.parse(argv)
+    dist.select_gpu(opt.gpu)                         # before the first torch.cuda call (vis_w.py / eval.py set CUDA_VISIBLE_DEVICES)
     dist.init_from_env()
+    if getattr(conf, 'synthetic_weights', False):    # the training run's explicit choice travels in its opt.yml
+        constants.ALLOW_SYNTHETIC_WEIGHTS = True
     if getattr(conf, 'resolution', None):
         constants.resolution = conf.resolution
     if getattr(conf, 'batch_size', None):

@@ -141,17 +141,29 @@ def _to_numpy_state(sd):
     return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
 
 
+def _checkpoint_or_synthetic(what, path):
+    """True: load ``path``.  False: synthetic weights were requested explicitly.  Otherwise raise: a mistyped checkpoint path must
+    not train a walk against random frozen networks without anyone noticing."""
+    if path and os.path.isfile(path):
+        return True
+    if constants.ALLOW_SYNTHETIC_WEIGHTS:
+        return False
+    raise FileNotFoundError('%s checkpoint %r does not exist (graphs.stylegan_v2_real.constants); pass --synthetic_weights / set '
+                            'L2I_SYNTHETIC_WEIGHTS=1 to run on seeded random-init weights of the same architecture instead' % (what, path))
+
+
 def load_networks(resolution, device, need_vgg=True, need_d=True):
-    """Frozen nets from the checkpoint paths of ``constants`` (reference transform_base.py:522-549) or — when a path
-    does not exist — deterministic synthetic weights of the same architecture (latent2im_amd.synth)."""
+    """Frozen nets from the checkpoint paths of ``constants`` (reference transform_base.py:522-549).  Deterministic synthetic
+    weights of the same architecture (latent2im_amd.synth) are used only on explicit request (constants.ALLOW_SYNTHETIC_WEIGHTS);
+    the choice per network is returned as the last element and logged by the drivers."""
     src = {}
-    if constants.g_path and os.path.isfile(constants.g_path):
+    if _checkpoint_or_synthetic('generator (g_path)', constants.g_path):
         g_state = _to_numpy_state(torch.load(constants.g_path, map_location='cpu')['g_ema'])
         src['G'] = constants.g_path
     else:
         g_state = synth.generator_state(resolution, seed=constants.SYNTH_SEED_G)
         src['G'] = 'synthetic(seed=%d)' % constants.SYNTH_SEED_G
-    if constants.reg_path and os.path.isfile(constants.reg_path):
+    if _checkpoint_or_synthetic('regressor (reg_path)', constants.reg_path):
         r_state = _to_numpy_state(torch.load(constants.reg_path, map_location='cpu')['model'])
         src['R'] = constants.reg_path
     else:
@@ -161,7 +173,7 @@ def load_networks(resolution, device, need_vgg=True, need_d=True):
     reg = ResNet50(r_state, device=device)
     vgg = netD = None
     if need_vgg:
-        if constants.vgg_path and os.path.isfile(constants.vgg_path):
+        if _checkpoint_or_synthetic('VGG-19 (vgg_path; the reference downloads torchvision weights)', constants.vgg_path):
             v_state = _to_numpy_state(torch.load(constants.vgg_path, map_location='cpu'))
             v_state = {k.replace('features.', ''): v for k, v in v_state.items()}
             src['V'] = constants.vgg_path

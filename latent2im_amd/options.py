@@ -45,6 +45,9 @@ class TrainOptions:
         p.add_argument('--max_iters', type=int, default=None, help='stop each epoch after this many iterations')
         p.add_argument('--seed', type=int, default=None, help='seed numpy global RNG (walk init, alpha draws)')
         p.add_argument('--no_log_sync', action='store_true', help='do not read the loss back every step (train.py:110)')
+        p.add_argument('--synthetic_weights', action='store_true',
+                       help='run on seeded random-init G / regressor / VGG when the checkpoint paths of constants.py do not exist '
+                            '(default: a missing checkpoint is an error, as in the reference)')
         g = p.add_argument_group('nn', 'parameters used to specify NN walk')
         g.add_argument('--eps', type=float, help='step size of each NN block')
         g.add_argument('--num_steps', type=int, help='number of NN blocks')

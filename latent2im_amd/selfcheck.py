@@ -12,6 +12,7 @@ def build_graph(resolution, attr_names, batch_size, lr=1e-3, walk_seed=7, device
     from . import constants, graph, synth
     constants.resolution = resolution
     constants.BATCH_SIZE = batch_size
+    constants.ALLOW_SYNTHETIC_WEIGHTS = True              # explicit: this helper exists to build the seeded random-init networks
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, 'dataset', 'attributes_celeba.txt')) as f:

@@ -70,6 +70,7 @@ def train(graphs, graph_inputs, output_dir, attrList, layers=None, save_freq=100
     if is_main:
         os.makedirs(os.path.join(output_dir, 'results'), exist_ok=True)
         _configure_logging(os.path.join(output_dir, 'log.txt'), append=False)
+        logging.info('weight sources: {}'.format(getattr(graphs, 'weight_sources', None)))
     n_epoch = (opt.n_epoch if opt is not None and getattr(opt, 'n_epoch', None) else (3 if multi_attr else 10))
     batch_size = constants.BATCH_SIZE
     num_samples = graph_inputs['z'].shape[0]
@@ -111,10 +112,11 @@ def train(graphs, graph_inputs, output_dir, attrList, layers=None, save_freq=100
 def main(multi_attr=False, argv=None):
     from . import graph as graph_mod
     from .options import TrainOptions
+    opt = TrainOptions().parse(print_opt=(int(os.environ.get('RANK', '0')) == 0), argv=argv)
+    dist.select_gpu(opt.gpu)                         # train.py:150 — before the first torch.cuda call (init_from_env makes it)
     rk, world, local = dist.init_from_env()
-    opt = TrainOptions().parse(print_opt=(rk == 0), argv=argv)
-    if opt.gpu and world == 1 and 'HIP_VISIBLE_DEVICES' not in os.environ:
-        os.environ['CUDA_VISIBLE_DEVICES'] = opt.gpu                                          # train.py:150
+    if opt.synthetic_weights:
+        constants.ALLOW_SYNTHETIC_WEIGHTS = True
     if opt.resolution:
         constants.resolution = opt.resolution
     if opt.batch_size:
@@ -128,6 +130,16 @@ def main(multi_attr=False, argv=None):
     g = model(**graph_kwargs)
     if world > 1:                                    # one source of truth for the trainable state
         torch.distributed.broadcast(g.walk.w.data, src=0)
+    if rk == 0:                                      # which frozen weights this run trained against: stdout, opt.yml (and log.txt in train())
+        print('weight sources: ', g.weight_sources)
+        yml = os.path.join(opt.output_dir, 'opt.yml')
+        if os.path.isfile(yml):
+            import yaml
+            with open(yml) as f:
+                dump = yaml.load(f, Loader=yaml.FullLoader)
+            dump['weight_sources'] = dict(g.weight_sources)
+            with open(yml, 'wt') as f:
+                yaml.dump(dump, f, default_flow_style=False)
     graph_inputs = hostutil.graph_input(g, opt.num_samples, seed=0)
     attrList = graph_kwargs['attrList']
     print('attrlist: ', attrList)

@@ -323,7 +323,7 @@ def test_train_cli_then_vis_cli_roundtrip(tmp_path):
     argv = ['--model', 'stylegan_v2_real', '--transform', 'face', '--num_samples', '8', '--learning_rate', '1e-3', '--latent', 'w',
             '--walk_type', 'linear', '--loss', 'l2', '--attrList', 'Smiling', '--attrPath', './dataset/attributes_celeba.txt',
             '--models_dir', models, '--overwrite_config', '--resolution', '32', '--batch_size', '4', '--n_epoch', '1', '--seed', '3',
-            '--model_save_freq', '1']
+            '--model_save_freq', '1', '--synthetic_weights']
     import os
     os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     try:
@@ -437,11 +437,17 @@ def test_checkpoint_formats_round_trip(tmp_path):
         l1 = vgg.content_losses(x, x * 0.9)
         l2 = VGG19Prefix(vs, device=DEV).content_losses(x, x * 0.9)
         close(l1, l2, 1e-5, 0)                                          # atomics in the squared-difference reduction
-        # missing files fall back to the seeded synthetic weights, and say so
+        # a configured checkpoint that is missing is an error (the reference crashes in torch.load) ...
         constants.g_path = str(tmp_path / 'absent.pt')
+        constants.ALLOW_SYNTHETIC_WEIGHTS = False
+        with pytest.raises(FileNotFoundError, match='absent.pt'):
+            graph.load_networks(32, torch.device(DEV), need_vgg=False, need_d=False)
+        # ... unless seeded synthetic weights were asked for, and then the choice is reported
+        constants.ALLOW_SYNTHETIC_WEIGHTS = True
         assert graph.load_networks(32, torch.device(DEV), need_vgg=False, need_d=False)[4]['G'].startswith('synthetic')
     finally:
         constants.g_path, constants.reg_path, constants.vgg_path, constants.resolution, constants.BATCH_SIZE = saved
+        constants.ALLOW_SYNTHETIC_WEIGHTS = True
 
 
 def test_eval_cli_after_training(tmp_path):
@@ -454,7 +460,7 @@ def test_eval_cli_after_training(tmp_path):
     argv = ['--model', 'stylegan_v2_real', '--transform', 'face', '--num_samples', '8', '--learning_rate', '1e-3', '--latent', 'w',
             '--walk_type', 'linear', '--loss', 'l2', '--attrList', 'Smiling', '--attrPath', './dataset/attributes_celeba.txt',
             '--models_dir', models, '--overwrite_config', '--resolution', '32', '--batch_size', '4', '--n_epoch', '1', '--seed', '3',
-            '--model_save_freq', '1']
+            '--model_save_freq', '1', '--synthetic_weights']
     try:
         trainer.main(multi_attr=False, argv=argv)
         out = os.path.join(models, 'stylegan_v2_real_face_linear_lr0.001_l2_w')
@@ -480,7 +486,7 @@ def test_train_multi_attr_cli(tmp_path):
     argv = ['--model', 'stylegan_v2_real', '--transform', 'face', '--num_samples', '8', '--learning_rate', '1e-3', '--latent', 'w',
             '--walk_type', 'linear', '--loss', 'l2', '--attrList', 'Smiling,Young,Male,Eyeglasses,Bangs',
             '--attrPath', './dataset/attributes_celeba.txt', '--models_dir', models, '--overwrite_config', '--resolution', '32',
-            '--batch_size', '4', '--n_epoch', '1', '--seed', '3', '--model_save_freq', '1']
+            '--batch_size', '4', '--n_epoch', '1', '--seed', '3', '--model_save_freq', '1', '--synthetic_weights']
     try:
         trainer.main(multi_attr=True, argv=argv)
         out = os.path.join(models, 'stylegan_v2_real_face_linear_lr0.001_l2_w')

@@ -1,6 +1,8 @@
 """SURVEY 8(f) rows on the CPU: the oracle restatement of apply_alpha / eval buckets / non-linear walks against the
 fixture captured from the reference's own methods (tests/golden/next.npz), and the product's host-side pieces (bucket
 selection, attribute-preservation metric, walk modules — plain torch modules, they run anywhere) against both."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -95,3 +97,72 @@ def test_nonlinear_walks_match_reference(golden):
         nl(ws, alpha=al, layers=None)
     # pickles resolve under the reference's module path
     assert graph.WalkNonLinearW.__module__ == graph.WalkMlpMultiW.__module__ == 'graphs.stylegan_v2_real.transform_base'
+
+
+def test_walk_modules_pickle_round_trip(tmp_path):
+    """save_multi_models pickles the whole walk module (transform_base.py:492-499): every walk class must resolve under the
+    reference's module path, for torch.save and for torch.load in a process that only knows ``graphs.*``."""
+    import subprocess
+    import sys
+    import os
+    for cls in (graph.WalkLinearMultiW, graph.WalkMlpMultiW, graph.WalkNonLinearW):
+        m = cls(512, 6, 1, ['Smiling'])
+        path = str(tmp_path / (cls.__name__ + '.ckpt'))
+        torch.save(m, path)
+        back = torch.load(path, map_location='cpu', weights_only=False)
+        assert type(back) is cls and type(back).__module__ == 'graphs.stylegan_v2_real.transform_base'
+        for (k, a), (_, b) in zip(m.state_dict().items(), back.state_dict().items()):
+            assert torch.equal(a, b), k
+    # a fresh interpreter that never imported latent2im_amd.graph by name (the reference's vis_w.py does exactly this)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch, sys; sys.path.insert(0, %r); "
+            "[print(type(torch.load(p, map_location='cpu', weights_only=False)).__name__) for p in sys.argv[1:]]" % root)
+    out = subprocess.run([sys.executable, '-c', code] + [str(tmp_path / (n + '.ckpt')) for n in ('WalkLinearMultiW', 'WalkMlpMultiW', 'WalkNonLinearW')],
+                         capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ['WalkLinearMultiW', 'WalkMlpMultiW', 'WalkNonLinearW']
+
+
+def test_missing_checkpoint_is_an_error_unless_synthetic_weights_are_requested(tmp_path):
+    from latent2im_amd import constants
+    saved = constants.ALLOW_SYNTHETIC_WEIGHTS
+    try:
+        constants.ALLOW_SYNTHETIC_WEIGHTS = False
+        with pytest.raises(FileNotFoundError, match='synthetic_weights'):
+            graph._checkpoint_or_synthetic('generator', '/path/550000.pt')          # the reference's placeholder default
+        with pytest.raises(FileNotFoundError):
+            graph._checkpoint_or_synthetic('VGG-19', '')
+        real = tmp_path / 'g.pt'
+        real.write_bytes(b'x')
+        assert graph._checkpoint_or_synthetic('generator', str(real)) is True
+        constants.ALLOW_SYNTHETIC_WEIGHTS = True
+        assert graph._checkpoint_or_synthetic('generator', '/path/550000.pt') is False
+        assert graph._checkpoint_or_synthetic('generator', str(real)) is True
+    finally:
+        constants.ALLOW_SYNTHETIC_WEIGHTS = saved
+
+
+def test_gpu_flag_is_applied_before_the_runtime_starts(monkeypatch):
+    """--gpu (train.py:150): exported before the first torch.cuda call; ignored under torchrun and when the launcher pinned devices."""
+    from latent2im_amd import dist
+    for k in ('CUDA_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'WORLD_SIZE'):
+        monkeypatch.delenv(k, raising=False)
+    assert not torch.cuda.is_initialized()
+    dist.select_gpu('')
+    assert 'CUDA_VISIBLE_DEVICES' not in os.environ
+    dist.select_gpu('3')
+    assert os.environ['CUDA_VISIBLE_DEVICES'] == '3' and os.environ['HIP_VISIBLE_DEVICES'] == '3'
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '5')
+    dist.select_gpu('1')
+    assert os.environ['HIP_VISIBLE_DEVICES'] == '5'
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    monkeypatch.delenv('CUDA_VISIBLE_DEVICES')
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    dist.select_gpu('1')
+    assert 'CUDA_VISIBLE_DEVICES' not in os.environ
+    # trainer.main parses --gpu and calls select_gpu ahead of init_from_env
+    import inspect
+    from latent2im_amd import trainer, vis, evaluate
+    for mod in (trainer, vis, evaluate):
+        src = inspect.getsource(mod.main)
+        assert 0 < src.index('dist.select_gpu(') < src.index('dist.init_from_env()'), mod.__name__
