@@ -76,14 +76,24 @@ def main():
     a = ap.parse_args()
 
     from latent2im_amd import constants, conv, dist, selfcheck, synth
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL over xGMI) BEFORE anything
+        # in this process touches the GPU, relay rank 0's JSON line, fail if any rank failed.  (Under torch.distributed.run the
+        # environment already carries WORLD_SIZE and this branch is skipped.)
+        codes, out0 = dist.spawn_local(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        lines = [l for l in out0.splitlines() if l.startswith('{')]
+        if any(codes) or len(lines) != 1:
+            sys.stderr.write('bench.py: rank exit codes %s, rank 0 printed %d JSON line(s)\n%s\n' % (codes, len(lines), out0[-2000:]))
+            raise SystemExit(1)
+        print(lines[0], flush=True)
+        return
     if a.serial_streams:
         constants.CONCURRENT_LOSS_BRANCHES = False
     conv.PRECISION = a.precision
     conv.USE_WINOGRAD = not a.direct_3x3
     rk, world, local = dist.init_from_env()
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus))
+        raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     assert torch.cuda.is_available(), 'bench.py needs the MI355X'
     dev = torch.device('cuda', torch.cuda.current_device())
     attrs = a.attrs.split(',')

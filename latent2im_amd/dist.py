@@ -65,13 +65,49 @@ def init_from_env(backend=None):
 
 
 def shard(n, rk=None, world=None):
-    """Contiguous slice of ``range(n)`` owned by this rank (equal shards: mean of shard means == global mean)."""
+    """Rows of a global batch of ``n`` samples owned by this rank: every ``world``-th sample starting at ``rank`` (SURVEY 8e allows
+    ``r::world`` or contiguous).  Equal shards, so the mean of the shard means is the global mean for every loss term — and the
+    STRIDED choice also keeps the discriminator's minibatch-stddev statistics (networks.py:630-638: sample b belongs to subgroup
+    b mod (B/4)) identical to a single process on the global batch: with a per-rank batch that is a multiple of 4, two samples of a
+    rank share a local subgroup exactly when they share a global one (world * (B_local/4) = B/4), so the GAN term needs no
+    cross-rank exchange and data parallelism stays one all-reduce of the walk gradient."""
     rk = rank() if rk is None else rk
     world = world_size() if world is None else world
     if n % world != 0:
         raise ValueError('global batch %d is not divisible by world size %d' % (n, world))
-    per = n // world
-    return slice(rk * per, (rk + 1) * per)
+    return slice(rk, n, world)
+
+
+def spawn_local(n, argv, env=None, timeout=None):
+    """Start ``n`` FRESH child processes ``argv`` on this node, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+    MASTER_PORT set; each child calls ``init_from_env``), wait for all of them and return (exit codes, rank 0's stdout).  The other
+    ranks' stdout and every stderr go to this process's stderr.  The caller must not have initialised the GPU if it wants to keep
+    using this process afterwards for GPU work of its own; nothing here touches the GPU, and no process image is replaced."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0 = b''
+    codes = []
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        for p in procs:
+            codes.append(p.wait(timeout=timeout))
+    except subprocess.TimeoutExpired:
+        for p in procs:                       # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+        codes = [p.wait() for p in procs]
+    return codes, out0.decode(errors='replace')
 
 
 def average_gradients(params):

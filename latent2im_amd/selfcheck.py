@@ -22,8 +22,9 @@ def build_graph(resolution, attr_names, batch_size, lr=1e-3, walk_seed=7, device
     g = graph.faceGraph(lr=lr, walk_type='linear', loss='l2', trainEmbed=False, attrList=list(attr_names), attrTable=table,
                         layers=None, stylegan_opts=types.SimpleNamespace(latent='w'))
     np.random.set_state(state)
-    with torch.no_grad():
-        g.walk.w.copy_(torch.from_numpy(synth.walk_init(len(attr_names), g.module.netG.n_latent, seed=walk_seed)))
+    if hasattr(g.walk, 'w'):                               # the linear walk; the MLP walks keep torch's own (seeded by the caller) init
+        with torch.no_grad():
+            g.walk.w.copy_(torch.from_numpy(synth.walk_init(len(attr_names), g.module.netG.n_latent, seed=walk_seed)))
     return g
 
 

@@ -147,3 +147,76 @@ def train_step(nets_state, walk_w, z, alpha_for_graph, attr_idx, layers=None, no
     return dict(x0=x0.detach(), x1=x1.detach(), alpha_org=a0.detach(), eps=eps.detach(), target=target.detach(),
                 reg=reg.detach(), cont=cont.detach(), cont_terms=[c.detach() for c in cont_terms],
                 gan=gan.detach(), loss=loss.detach(), grad=grad.detach())
+
+
+def stddev_subgroups(batch, group=4):
+    """Index sets that the discriminator's minibatch-stddev layer (networks.py:630-638) reduces over: ``view(group, B/group, ...)``
+    puts sample b into subgroup b mod (B/group), group = min(B, 4).  Samples of different subgroups never interact anywhere in
+    the step, so a batch can be evaluated one subgroup at a time."""
+    g = min(batch, group)
+    assert batch % g == 0, 'the reference view() needs batch %% min(batch, 4) == 0'
+    n = batch // g
+    return [list(range(j, batch, n)) for j in range(n)]
+
+
+def train_step_bounded(nets_state, walk_w, z, alpha_for_graph, attr_idx, layers=None, no_content_loss=False, no_gan_loss=False,
+                       clamp_variant=False):
+    """Same function as ``train_step`` evaluated with bounded memory, for the BASELINE-size checks (1024^2, batch 8: the
+    autograd graph of the whole batch is > 100 GB in float32): one minibatch-stddev subgroup at a time (every loss term is a
+    mean over samples and the subgroups are equal-sized, so the batch value is the mean of the subgroup values), and inside a
+    subgroup one loss branch at a time — each branch is back-propagated to the edited image, its graph is freed, and the summed
+    image gradient goes through the generator once.  Same arithmetic per sample; only summation order of the final means
+    differs from ``train_step`` (checked against it in tests/test_oracle_golden.py)."""
+    PG, PR, PV, PD = nets_state['G'], nets_state['R'], nets_state.get('V'), nets_state.get('D')
+    B = z.shape[0]
+    n_latent = walk_w.shape[1]
+    groups = stddev_subgroups(B)
+    out = dict(x0=[None] * B, x1=[None] * B, alpha_org=[None] * B, eps=[None] * B, target=[None] * B)
+    acc = dict(reg=0.0, cont=0.0, gan=0.0, grad=0.0, cont_terms=None)
+    for idx in groups:
+        ww = walk_w.detach().clone().requires_grad_(True)
+        zc, ac = z[idx], alpha_for_graph[idx]
+        with torch.no_grad():
+            ws = get_w(PG, zc, n_latent)
+            x0 = get_logits(PG, ws, None)
+            a0 = get_reg_preds(PR, x0, attr_idx)
+        if clamp_variant:
+            target, eps = get_alphas_clamp(a0, ac)
+        else:
+            target, eps = ac, get_alphas(a0, ac)
+        w1 = walk_linear_multi_w(ws, eps, ww, layers)
+        x1 = get_logits(PG, w1, None)
+        gx = torch.zeros_like(x1)
+        terms = {}
+        for name in ('reg', 'cont', 'gan'):
+            if (name == 'cont' and no_content_loss) or (name == 'gan' and no_gan_loss):
+                terms[name] = torch.zeros((), dtype=x1.dtype)
+                continue
+            xl = x1.detach().requires_grad_(True)
+            if name == 'reg':
+                t = reg_loss(PR, xl, target, attr_idx)
+                wgt = 1.0 if (no_content_loss and no_gan_loss) else 10.0
+            elif name == 'cont':
+                t, cts = content_loss(PV, x0, xl)
+                acc['cont_terms'] = [c.detach() / len(groups) + (a if acc['cont_terms'] else 0.0)
+                                     for c, a in zip(cts, acc['cont_terms'] or [0.0] * len(cts))]
+                wgt = 0.05
+            else:
+                t = gan_loss(PD, xl)
+                wgt = 0.05
+            g, = torch.autograd.grad(t * wgt, xl)
+            gx += g.to(gx.dtype)
+            terms[name] = t.detach()
+            del t, g, xl
+        grad, = torch.autograd.grad(x1, ww, gx)
+        for k, i in enumerate(idx):
+            out['x0'][i], out['x1'][i] = x0[k], x1[k].detach()
+            out['alpha_org'][i], out['eps'][i], out['target'][i] = a0[k], eps[k].detach(), target[k].detach()
+        for name in ('reg', 'cont', 'gan'):
+            acc[name] = acc[name] + terms[name] / len(groups)
+        acc['grad'] = acc['grad'] + grad.detach() / len(groups)
+        del x1, gx, grad
+    res = {k: torch.stack(v) for k, v in out.items()}
+    res.update(reg=acc['reg'], cont=acc['cont'], gan=acc['gan'], cont_terms=acc['cont_terms'] or [],
+               loss=total_loss(acc['reg'], acc['cont'], acc['gan'], no_content_loss, no_gan_loss), grad=acc['grad'])
+    return res

@@ -81,9 +81,20 @@ def test_dp_matches_single_process(world):
     np.testing.assert_allclose(got, walk.detach().numpy(), rtol=1e-4, atol=1e-6)
 
 
-def test_shard_is_contiguous_and_checks_divisibility():
+def test_shard_is_strided_and_checks_divisibility():
     from latent2im_amd import dist
-    assert dist.shard(8, 1, 4) == slice(2, 4)
+    from oracle import step as ostep
+    assert list(range(8))[dist.shard(8, 1, 4)] == [1, 5]
+    # every rank's local minibatch-stddev subgroups are whole global subgroups (so DP == single process, GAN term included)
+    for n, world in ((8, 2), (32, 4), (64, 8), (16, 1), (8, 1)):
+        glob = [set(g) for g in ostep.stddev_subgroups(n)]
+        seen = []
+        for r in range(world):
+            mine = list(range(n))[dist.shard(n, r, world)]
+            for g in ostep.stddev_subgroups(len(mine)):
+                assert {mine[i] for i in g} in glob
+                seen.append({mine[i] for i in g})
+        assert sorted(map(sorted, seen)) == sorted(map(sorted, glob))
     with pytest.raises(ValueError):
         dist.shard(6, 0, 4)
     assert dist.world_size() == 1 and dist.rank() == 0

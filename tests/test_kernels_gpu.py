@@ -401,3 +401,78 @@ def test_small_cin_3x3_conv_as_one_contraction(cin, cout, h, w, b):
     close(fc.forward(g(x), bias=g(bias), tile_hint=2), ref, 1e-4, 2e-5)
     close(fc.forward(g(x), bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5, out_gain=0.5), F.leaky_relu(ref, 0.2) * 2 ** 0.5 * 0.5, 1e-4, 2e-5)
     close(fc.forward(g(x), act=conv.ACT_RELU), torch.relu(F.conv2d(x, wt, padding=1)), 1e-4, 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the drop-in autograd wrappers (latent2im_amd.op == the reference's graphs/stylegan_v2_real/op package)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_op_fused_leaky_relu_autograd_and_double_backward(golden):
+    """latent2im_amd.op.fused_leaky_relu / FusedLeakyReLU through autograd (op/fused_act.py:17-86): forward == y_30, the
+    backward Function == the reference's act=3, grad=1 table entry (y_31) with grad_bias = its sum over all dims but 1, and the
+    double backward (gradgrad_input + gradgrad_bias through the same mask) against torch's own double backward of
+    leaky_relu(x + b) * sqrt(2) on the CPU."""
+    from latent2im_amd import op
+    from latent2im_amd.op import fused_act
+    gd = golden('fused_bias_act')
+    x, b, ref = (T(gd[k]) for k in ('x', 'b', 'ref'))
+    xd, bd = x.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = op.fused_leaky_relu(xd, bd)
+    close(y, T(gd['y_30']), 1e-6, 1e-7)
+    # the backward Function on the reference's own vectors: input plays grad_output, ref plays the saved output
+    gi, gb = fused_act._FusedLeakyReLUBackward.apply(x.to(DEV), ref.to(DEV), 0.2, 2 ** 0.5)
+    close(gi, T(gd['y_31']), 1e-6, 1e-7)
+    close(gb, T(gd['y_31']).sum((0, 2, 3)), 1e-5, 1e-6)
+    # autograd end to end, first and second order, against torch on the CPU
+    rs = np.random.RandomState(3)
+    gy, vx, vb = T(rs.randn(*x.shape)), T(rs.randn(*x.shape)), T(rs.randn(*b.shape))
+    xc, bc, gyc = x.clone().requires_grad_(True), b.clone().requires_grad_(True), gy.clone().requires_grad_(True)
+    yc = F.leaky_relu(xc + bc.view(1, -1, 1, 1), 0.2) * 2 ** 0.5
+    gxc, gbc = torch.autograd.grad(yc, (xc, bc), gyc, create_graph=True)
+    ggc, = torch.autograd.grad((gxc * vx).sum() + (gbc * vb).sum(), gyc)
+    gyd = gy.to(DEV).requires_grad_(True)
+    gxd, gbd = torch.autograd.grad(y, (xd, bd), gyd, create_graph=True)
+    close(gxd, gxc, 1e-6, 1e-7)
+    close(gbd, gbc, 1e-5, 1e-6)
+    ggd, = torch.autograd.grad((gxd * vx.to(DEV)).sum() + (gbd * vb.to(DEV)).sum(), gyd)
+    close(ggd, ggc, 1e-5, 1e-6)
+    # the module form: bias parameter of the right shape, gradient reaches it; 2-D inputs (the mapping network's use, networks.py:151)
+    m = op.FusedLeakyReLU(5).to(DEV)
+    with torch.no_grad():
+        m.bias.copy_(b.to(DEV))
+    ym = m(x.to(DEV))
+    close(ym, T(gd['y_30']), 1e-6, 1e-7)
+    ym.backward(gy.to(DEV))
+    close(m.bias.grad, gbc, 1e-5, 1e-6)
+    x2, b2 = T(gd['x2']).to(DEV).requires_grad_(True), T(gd['b2']).to(DEV).requires_grad_(True)
+    y2 = op.fused_leaky_relu(x2, b2)
+    close(y2, T(gd['y2_30']), 1e-6, 1e-7)
+    g2 = T(rs.randn(3, 7))
+    y2.backward(g2.to(DEV))
+    x2c, b2c = T(gd['x2']).requires_grad_(True), T(gd['b2']).requires_grad_(True)
+    (F.leaky_relu(x2c + b2c, 0.2) * 2 ** 0.5).backward(g2)
+    close(x2.grad, x2c.grad, 1e-6, 1e-7)
+    close(b2.grad, b2c.grad, 1e-5, 1e-6)
+
+
+def test_op_upfirdn2d_autograd_and_double_backward(golden):
+    """latent2im_amd.op.upfirdn2d through autograd (op/upfirdn2d.py:17-149) on every case of the reference fixture: forward == y_i,
+    x.grad for the fixture's gy_i == gx_i (the reference's own backward: flipped FIR, up <-> down, the g_pad algebra of :110-115),
+    and the double backward (= the forward op applied to the cotangent, :63-84) against the op itself and the CPU oracle."""
+    from latent2im_amd import op
+    gd = golden('upfirdn2d')
+    rs = np.random.RandomState(4)
+    for i, (n, c, h, w, up, down, p0, p1, gain) in enumerate(gd['cases']):
+        up, down, p0, p1 = int(up), int(down), int(p0), int(p1)
+        x = T(np.random.RandomState(20 + i).randn(int(n), int(c), int(h), int(w)).astype(np.float32))
+        k = T(synth.fir_kernel(gain=gain))
+        xd = x.to(DEV).requires_grad_(True)
+        y = op.upfirdn2d(xd, k.to(DEV), up=up, down=down, pad=(p0, p1))
+        close(y, T(gd['y_%d' % i]), 1e-5, 1e-6)
+        gy = T(gd['gy_%d' % i]).to(DEV).requires_grad_(True)
+        gx, = torch.autograd.grad(y, xd, gy, create_graph=True)
+        assert gx.shape == x.shape
+        close(gx, T(gd['gx_%d' % i]), 1e-5, 1e-6)
+        v = T(rs.randn(*x.shape))
+        gg, = torch.autograd.grad((gx * v.to(DEV)).sum(), gy)
+        close(gg, sg2.upfirdn2d(v, k, up=up, down=down, pad=(p0, p1)), 1e-5, 1e-6)
+        close(gg, kernels.upfirdn2d(v.to(DEV), k.to(DEV), (up, up), (down, down), (p0, p1, p0, p1)), 1e-6, 1e-7)

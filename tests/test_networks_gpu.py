@@ -284,6 +284,81 @@ def test_full_size_training_step_vs_oracle(size, batch, attrs, clamp):
         constants.resolution, constants.BATCH_SIZE = 256, 4
 
 
+def _oracle_nets(size, dt=torch.float32):
+    return dict(G=ostep.to_torch(synth.generator_state(size, seed=100), dt), D=ostep.to_torch(synth.discriminator_state(size, seed=200), dt),
+                R=ostep.to_torch(synth.resnet50_state(seed=300), dt), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400), dt))
+
+
+def test_config3_whole_step_1024_batch8_vs_oracle():
+    """BASELINE config 3 at its own batch: one whole training step at 1024^2, batch 8, one attribute, full loss (both generator
+    passes, regressor, VGG content, discriminator WITH its group-of-4 minibatch stddev over {0,2,4,6} / {1,3,5,7}, backward into the
+    walk) against the float32 CPU oracle on the same z / seed.  The oracle is evaluated with bounded memory
+    (oracle.step.train_step_bounded: same function, tests/test_oracle_golden.py).  Images, alpha, every loss term: rtol 1e-3 / atol 1e-4."""
+    from latent2im_amd import constants
+    try:
+        size, batch, attrs = 1024, 8, ['Smiling']
+        gr = selfcheck.build_graph(size, attrs, batch, lr=1e-3)
+        zs = synth.z_sample(batch, seed=11)
+        alpha = np.ones((batch, 1)) * 0.62
+        r = selfcheck.run_step(gr, zs, alpha, optimize=False)
+        torch.cuda.synchronize()
+        nets = _oracle_nets(size)
+        o = ostep.train_step_bounded(nets, T(synth.walk_init(1, gr.module.netG.n_latent, seed=7)), T(zs).float(), T(alpha).float(), gr.attrIdx)
+        close(r['x0'], o['x0'])
+        close(r['a0'], o['alpha_org'])
+        close(r['eps'], o['eps'])
+        close(r['x1'], o['x1'])
+        close(r['terms']['reg'], o['reg'], 1e-3, 1e-5)
+        close(r['terms']['cont'], o['cont'], 1e-3, 1e-6)
+        close(r['terms']['gan'], o['gan'], 1e-3, 1e-5)
+        close(r['loss'], o['loss'], 1e-3, 1e-4)
+        assert r['loss'].dtype == torch.float64
+        pg = gr.regressor(r['x1'])[:, gr.attrIdx].double().cpu()
+        po = onets.resnet50_forward(nets['R'], o['x1'])[:, gr.attrIdx].double()
+        tgt = o['target'].double()
+        per_attr = lambda p: -(tgt * p.clamp(min=1e-12).log() + (1 - tgt) * (1 - p).clamp(min=1e-12).log()).mean(0)
+        close(per_attr(pg), per_attr(po), 1e-3, 1e-5)
+        # float32 against float32 through ~60 piecewise-linear layers: coarse here, the float64 bound is the next test
+        e = relmax(r['grad'], o['grad'])
+        print('1024^2 batch-8 walk gradient, HIP vs float32 oracle, relative to the largest entry: %.3e' % e)
+        assert e < 3e-2, e
+    finally:
+        constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
+def test_walk_gradient_1024_vs_float64_oracle():
+    """The walk gradient of a full-loss step at 1024^2 (one sample) against the oracle evaluated in FLOAT64 — the same bar as
+    test_walk_gradient_256_vs_float64_oracle at the bench resolution: no further from the exact value than twice the oracle's own
+    float32 run, or 5e-3 of the largest entry."""
+    from latent2im_amd import constants
+    try:
+        size, batch = 1024, 1
+        gr = selfcheck.build_graph(size, ['Smiling'], batch, lr=1e-3)
+        zs = synth.z_sample(batch, seed=12)
+        alpha = np.ones((batch, 1)) * 0.41
+        r = selfcheck.run_step(gr, zs, alpha, optimize=False)
+        torch.cuda.synchronize()
+        errs = {}
+        o64 = None
+        for dt in (torch.float64, torch.float32):
+            o = ostep.train_step_bounded(_oracle_nets(size, dt), T(synth.walk_init(1, gr.module.netG.n_latent, seed=7)).to(dt), T(zs).to(dt),
+                                         T(alpha).to(dt), gr.attrIdx)
+            if dt == torch.float64:
+                o64 = o
+                errs['hip'] = relmax(r['grad'], o64['grad'])
+                close(r['x1'], o64['x1'])
+                close(r['loss'], o64['loss'], 1e-3, 1e-4)
+                close(r['terms']['reg'], o64['reg'], 1e-3, 1e-5)
+                close(r['terms']['cont'], o64['cont'], 1e-3, 1e-6)
+                close(r['terms']['gan'], o64['gan'], 1e-3, 1e-5)
+            else:
+                errs['oracle32'] = relmax(o['grad'], o64['grad'])
+        print('1024^2 walk gradient vs float64 oracle, relative to the largest entry:', errs)
+        assert errs['hip'] < max(2 * errs['oracle32'], 5e-3), errs
+    finally:
+        constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
 def test_walk_gradient_256_vs_float64_oracle():
     """Walk gradient of a full-loss step at 256^2 (batch 4) against the oracle evaluated in float64 — the value the arithmetic
     has without rounding.  The HIP path must be no further from it than twice the oracle's own float32 run (or 5e-3 of the
@@ -498,3 +573,82 @@ def test_train_multi_attr_cli(tmp_path):
         assert 'T, epc, bst, lss, alpha:' in open(os.path.join(out, 'log.txt')).read()
     finally:
         constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
+def test_nonlinear_walks_on_device_match_reference(golden):
+    """WalkMlpMultiW / WalkNonLinearW (transform_base.py:168-243) built on the GPU like the graph builds them
+    (.to(device)), against the outputs of the reference's own modules (tests/golden/next.npz), and a training step of the product
+    graph with the MLP walk switched on (constants.WALK_IS_MLP: the reference's hand-edited ``is_mlp``): the gradient reaches every
+    MLP parameter and one Adam step changes them."""
+    from latent2im_amd import constants, graph
+    from tests import emu
+    g = golden('next')
+    ws = [T(synth.z_sample(4, seed=21 + i)).float().to(DEV) for i in range(3)]
+    al = T(np.asarray([[0.3], [-0.7], [1.2], [0.0]], dtype=np.float32)).to(DEV)
+    mlp = graph.WalkMlpMultiW(512, 6, 1, ['Smiling'])
+    emu.seeded_state(mlp, 31)
+    mlp = mlp.to(DEV)
+    close(torch.stack(mlp(ws, al)), g['mlp.out'], 1e-4, 1e-5)
+    with pytest.raises(TypeError):
+        mlp(ws, al, layers=[0])
+    nl = graph.WalkNonLinearW(512, 6, 1, ['Smiling'])
+    emu.seeded_state(nl, 32)
+    nl = nl.to(DEV)
+    close(torch.stack(nl(ws, None, al, None)), g['nonlinear.out'], 1e-4, 1e-5)
+    close(torch.stack(nl(ws, None, al, None, layers=[1])), g['nonlinear.out_layers1'], 1e-4, 1e-5)
+    with pytest.raises(TypeError):
+        nl(ws, alpha=al, layers=None)
+    # the product graph with the MLP walk: one real step (regressor-only loss at 32^2)
+    try:
+        constants.WALK_IS_MLP = True
+        gr = selfcheck.build_graph(32, ['Smiling'], 4, lr=1e-3)
+        assert type(gr.walk).__name__ == 'WalkMlpMultiW' and next(gr.walk.parameters()).is_cuda
+        before = [p.detach().clone() for p in gr.walk.parameters()]
+        zs = synth.z_sample(4, seed=2)
+        z = T(zs).float().to(DEV)
+        w = gr.get_w(z)
+        x0 = gr.get_logits({'w': w})
+        a0 = gr.get_reg_preds(x0)
+        ag = torch.full((4, 1), 0.8, device=DEV)
+        w1 = gr.get_w_new_tensor(w, gr.get_alphas(a0, ag))
+        x1 = gr.get_logits({'w': w1})
+        loss = gr.optimizeParametersAll({'w': w1, 'org': x0, 'logit': x1, 'alpha': ag}, False, False, no_content_loss=True, no_gan_loss=True)
+        assert torch.isfinite(loss)
+        for p, b in zip(gr.walk.parameters(), before):
+            assert p.grad is not None and float(p.grad.abs().max()) > 0
+            assert not torch.equal(p.detach(), b)
+    finally:
+        constants.WALK_IS_MLP = False
+        constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
+@pytest.mark.parametrize('no_gan', [True, False])
+def test_data_parallel_product_graph_matches_single_process(tmp_path, no_gan):
+    """SURVEY 8(e) on the product graph: two fresh rank processes (sharing this box's one GPU, process group over gloo —
+    L2I_DIST_BACKEND=gloo; on a multi-GPU node the same code runs one rank per GPU over RCCL) run the real faceGraph for two
+    optimizeParametersAll steps on their strided shards of a global batch of 8, with the single all-reduce of the walk gradient
+    inside the step; a single process runs the same steps on the global batch.  The all-reduced gradient, every (mean) loss term and
+    the walk after two Adam steps must agree — with the GAN term too: the strided shards keep the discriminator's minibatch-stddev
+    subgroups {0,2,4,6} / {1,3,5,7} intact (dist.shard)."""
+    import os
+    import subprocess
+    import sys
+    from latent2im_amd import dist
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dp_worker.py')
+    args = ['64', '8', '2', '1' if no_gan else '0']
+    env = dict(os.environ, L2I_DIST_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    single, multi = str(tmp_path / 'single.npz'), str(tmp_path / 'dp2.npz')
+    r = subprocess.run([sys.executable, worker, single] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    codes, _ = dist.spawn_local(2, [sys.executable, worker, multi] + args, env=env, timeout=600)
+    assert codes == [0, 0], codes
+    a, b = np.load(single), np.load(multi)
+    assert int(a['world']) == 1 and int(b['world']) == 2
+    close(b['losses'], a['losses'], 1e-4, 1e-6)                       # total, reg, content (, gan): mean of shard means == global mean
+    for s in range(2):
+        grad_ok(T(b['grads'][s]), T(a['grads'][s]))                   # same samples, different tile shapes: a few flipped masks at most
+        assert relmax(T(b['grads'][s]), T(a['grads'][s])) < 2e-2
+    step = np.abs(a['walk'] - synth.walk_init(2, 10, seed=7)).max()
+    assert step > 1e-4                                                # Adam moved the walk ...
+    assert np.abs(b['walk'] - a['walk']).max() < 0.05 * step          # ... and both runs moved it the same way

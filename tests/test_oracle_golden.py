@@ -200,3 +200,23 @@ def test_adam_restatement_matches_torch_optim():
         ref.step()
         mine.step(gr)
         close(mine.p, p.detach().numpy(), 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize('batch,attrs,clamp,flags', [(8, 1, False, {}), (4, 2, True, {}), (8, 1, False, dict(no_content_loss=True, no_gan_loss=True))])
+def test_bounded_memory_step_is_the_same_function(batch, attrs, clamp, flags):
+    """oracle.step.train_step_bounded (one minibatch-stddev subgroup and one loss branch at a time: what the 1024^2 batch-8 GPU
+    parity test can afford) against the plain train_step on a batch that has two subgroups."""
+    size = 32
+    nets = dict(G=ostep.to_torch(synth.generator_state(size, seed=100)), D=ostep.to_torch(synth.discriminator_state(size, seed=200)),
+                R=ostep.to_torch(synth.resnet50_state(seed=300)), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400)))
+    assert ostep.stddev_subgroups(8) == [[0, 2, 4, 6], [1, 3, 5, 7]] and ostep.stddev_subgroups(2) == [[0, 1]]
+    assert ostep.stddev_subgroups(16)[1] == [1, 5, 9, 13]
+    walk = T(synth.walk_init(attrs, 8, seed=7))
+    zs = T(synth.z_sample(batch, seed=5)).float()
+    alpha = torch.full((batch, attrs), 0.3) * torch.arange(1, attrs + 1)
+    idx = [31, 39][:attrs]
+    a = ostep.train_step(nets, walk, zs, alpha, idx, clamp_variant=clamp, **flags)
+    b = ostep.train_step_bounded(nets, walk, zs, alpha, idx, clamp_variant=clamp, **flags)
+    for k in ('x0', 'x1', 'alpha_org', 'eps', 'target', 'reg', 'cont', 'gan', 'loss', 'grad'):
+        assert a[k].dtype == b[k].dtype, k
+        np.testing.assert_allclose(b[k].numpy(), a[k].numpy(), rtol=1e-5, atol=1e-6 * float(a[k].abs().max()), err_msg=k)
