@@ -651,4 +651,9 @@ def test_data_parallel_product_graph_matches_single_process(tmp_path, no_gan):
         assert relmax(T(b['grads'][s]), T(a['grads'][s])) < 2e-2
     step = np.abs(a['walk'] - synth.walk_init(2, 10, seed=7)).max()
     assert step > 1e-4                                                # Adam moved the walk ...
-    assert np.abs(b['walk'] - a['walk']).max() < 0.05 * step          # ... and both runs moved it the same way
+    # ... and both runs moved it the same way.  Adam's first updates are ~ lr * sign(g): entries whose gradient is within rounding
+    # of zero may legitimately step the other way, so the comparison is made where the gradient is well away from zero
+    clear = np.abs(a['grads']).min(0) > 0.02 * np.abs(a['grads']).max()
+    assert clear.mean() > 0.1
+    assert np.abs(b['walk'] - a['walk'])[clear].max() < 0.05 * step
+    assert np.median(np.abs(b['walk'] - a['walk'])) < 0.01 * step
