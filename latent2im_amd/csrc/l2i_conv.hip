@@ -200,7 +200,11 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
             const int idx = tid + u * 256;
             if (idx < L.w_vec) reinterpret_cast<u32x4*>(lds_w)[idx] = rw[u];
         }
-        if (tid < TBCK) lds_sc[tid] = p.in_scale ? __uint_as_float(rsc) : 1.f;
+        // one scale per (sample of the tile, channel of the chunk).  With a style scale the host caps CK so that the table fits one
+        // entry per thread (TB * CK <= 256); without one the table is all ones and may be longer than the block (tiny maps pack up to
+        // 128 samples into a tile: ResNet-50's tail at small inputs)
+        if (p.in_scale) { if (tid < TBCK) lds_sc[tid] = __uint_as_float(rsc); }
+        else for (int i = tid; i < TBCK; i += 256) lds_sc[i] = 1.f;
     };
 
     int sbase[WN];               // per N tile: index of this lane's (sample, first channel) in the scale table
@@ -661,6 +665,7 @@ static bool plan_tile(const l2i_conv_params& p, int wm, int wn, ConvLaunch& L, b
     const int ck_w = (nwv * 256) / (KK * BM / 4);
     if (ck > ck_in) ck = ck_in;
     if (ck > ck_w) ck = ck_w;
+    if (p.in_scale && ck > (256 >> L.tb_log2)) ck = 256 >> L.tb_log2;      // the per-(sample, channel) scale table is filled one entry per thread
     ck &= ~1;
     if (ck < 2) return false;
     const int cin_even = (p.Cin + 1) & ~1;

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
                 lds_in[loff[u]] = v;
             }
         }
-        if (tid < TBCK) lds_sc[tid] = p.in_scale ? __uint_as_float(rsc) : 1.f;
+        if (p.in_scale) { if (tid < TBCK) lds_sc[tid] = __uint_as_float(rsc); }       // host: TB * CK <= 256 when a style scale is present
+        else for (int i = tid; i < TBCK; i += 256) lds_sc[i] = 1.f;
     };
 
     dma_w(c_begin, 0);
@@ -407,6 +408,7 @@ static int launch_convt(const l2i_conv_params& p, hipStream_t st) {
     int ck = (int)((36 * 1024) / per_c);                  // per stage; two stages, two blocks per CU
     const int ck_in = (12 * 256) / (L.rows_c * L.IW);
     if (ck > ck_in) ck = ck_in;
+    if (p.in_scale && ck > (256 >> L.tb_log2)) ck = 256 >> L.tb_log2;      // one scale-table entry per thread
     // channels per chunk: pairs (the two lane halves of an MFMA take one channel each); K == 3 walks two pairs per iteration.
     // Chunks must tile Cin exactly: the per-chunk channel offset travels in the scalar offset of the buffer loads, which the
     // hardware does not range-check.

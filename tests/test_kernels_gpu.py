@@ -28,6 +28,10 @@ CONV_CASES = [  # cin, cout, k, stride, pad, transposed, h, w, batch
     # tiny maps (ResNet-50 tail at small inputs): several samples per tile, 1-pixel rows
     (256, 512, 1, 2, 0, False, 2, 2, 4), (2048, 512, 1, 1, 0, False, 1, 1, 4), (512, 2048, 1, 1, 0, False, 1, 1, 3), (64, 64, 3, 1, 1, False, 1, 1, 5),
     (128, 128, 3, 2, 1, False, 3, 3, 2),
+    # tiny maps at batch >= 8: a tile packs 8..128 samples, the per-(sample, channel) scale table is longer than the block (round-2 bug:
+    # ResNet-50's tail was wrong for batch >= 8 on <= 4x4 maps)
+    (128, 512, 1, 1, 0, False, 4, 4, 8), (512, 128, 1, 1, 0, False, 4, 4, 16), (1024, 256, 1, 1, 0, False, 2, 2, 16),
+    (2048, 512, 1, 1, 0, False, 1, 1, 16), (256, 512, 1, 2, 0, False, 8, 8, 8), (512, 512, 3, 1, 1, False, 2, 2, 16),
 ]
 
 

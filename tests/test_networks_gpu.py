@@ -657,3 +657,24 @@ def test_data_parallel_product_graph_matches_single_process(tmp_path, no_gan):
     assert clear.mean() > 0.1
     assert np.abs(b['walk'] - a['walk'])[clear].max() < 0.05 * step
     assert np.median(np.abs(b['walk'] - a['walk'])) < 0.01 * step
+
+
+@pytest.mark.parametrize('size,batch', [(32, 8), (64, 16), (128, 8)])
+def test_networks_small_maps_large_batch_vs_oracle(size, batch):
+    """Every frozen network where a kernel tile packs many samples (<= 4x4 maps at batch >= 8: ResNet-50's tail at small inputs, the
+    first generator / last discriminator blocks) against the CPU oracle.  Regression test of a round-2 finding (the scale table of
+    the implicit-GEMM kernel was only filled for the first 256 (sample, channel) pairs of a tile)."""
+    stG, stR, stV, stD = (synth.generator_state(size, seed=100), synth.resnet50_state(seed=300), synth.vgg19_prefix_state(seed=400),
+                          synth.discriminator_state(size, seed=200))
+    G = Generator(stG, size, device=DEV)
+    z = T(synth.z_sample(batch, seed=3)).float()
+    w = G.style(z.to(DEV))
+    img = G.synthesis(torch.stack([w] * G.n_latent, 1).contiguous())
+    PG = ostep.to_torch(stG)
+    img_o = sg2.generator_synthesis(PG, torch.stack([sg2.style_mlp(PG, z)] * G.n_latent, 1), None)
+    close(img, img_o)
+    close(ResNet50(stR, device=DEV)(img_o.to(DEV)), onets.resnet50_forward(ostep.to_torch(stR), img_o))
+    close(Discriminator(stD, size, device=DEV)(img_o.to(DEV)), sg2.discriminator_forward(ostep.to_torch(stD), img_o))
+    other = torch.roll(img_o, 3, 3)
+    _, lo = ostep.content_loss(ostep.to_torch(stV), other, img_o)
+    close(VGG19Prefix(stV, device=DEV).content_losses(other.to(DEV), img_o.to(DEV)), torch.stack(lo), 1e-3, 1e-6)
