@@ -1,16 +1,25 @@
 """Benchmark of the walk-training hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c5]
 
 One "step" = one full iteration of the reference's training loop (train.py:48-110) over one batch of synthetic z:
 sample z -> style MLP -> StyleGAN2 synthesis (original) -> ResNet-50 regressor -> linear W+ walk -> synthesis (edited)
 -> discriminator + VGG-19 content + regressor BCE losses -> backward into the walk -> [all-reduce] -> Adam.
-Workload = BASELINE.json configs[2]: StyleGAN2 FFHQ-shaped 1024^2 generator, ResNet-50 regressor, 1 attribute
-(Smiling), batch 8 per GPU, full loss (the reference's default flags), fp32 on the matrix cores.  Weak scaling: the
-per-GPU batch is fixed; ranks draw identical z / alpha and take their slice; the only collective is one all-reduce of
-the walk gradient per step.  Prints ONE JSON line on rank 0.
+
+--config c3 (default, the headline): BASELINE.json configs[2] — StyleGAN2 FFHQ-shaped 1024^2 generator, ResNet-50 regressor,
+  1 attribute (Smiling), batch 8 per GPU, full loss (the reference's default flags), train.py flow, fp32 on the matrix cores
+  (the reference's arithmetic type), eager launches on three loss-branch streams.
+--config c5: BASELINE.json configs[4] per-GPU shape — the same networks on the transient-scene attribute table (SceneGraph,
+  dataset/attributes_scene.txt, 5 attributes, train_multi_attr.py clamp flow), batch 8 per GPU, every contraction on the 16-bit
+  matrix cores (3-term bf16 split, fp32 accumulation: fp32-class results), forward+backward replayed from ONE hipGraph.
+
+N > 1: one rank process per GPU (RCCL over xGMI).  `python bench.py --gpus N` starts the ranks itself; under
+torch.distributed.run (WORLD_SIZE set) it is one of them.  Weak scaling: the per-GPU batch is fixed; ranks draw identical z /
+alpha and take every N-th sample; the only collective is one all-reduce of the walk gradient per step.  Prints ONE JSON line
+on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,12 +32,12 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: v_mfma_f32_32x32x16_bf16, dense
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6300 achievable)
+NOISE_STRENGTH = 0.05               # per-layer NoiseInjection weights of the benchmarked generator ("pretrained-like": non-zero)
+SCENE_ATTRS = ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk']
 
 
-def cpu_baseline(resolution, attrs, budget_s, full_loss=True):
+def cpu_baseline(resolution, n_attr, budget_s, full_loss=True, clamp=False):
     """The CPU oracle (plain torch on the host cores) on a bounded sample of the same workload: whole training steps at
     the benchmark resolution with batch 1 (per-image work is identical; D's stddev group is min(B,4))."""
     from latent2im_amd import synth
@@ -40,14 +49,13 @@ def cpu_baseline(resolution, attrs, budget_s, full_loss=True):
     nets = dict(G=ostep.to_torch(synth.generator_state(resolution, seed=100)), D=ostep.to_torch(synth.discriminator_state(resolution, seed=200)),
                 R=ostep.to_torch(synth.resnet50_state(seed=300)), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400)))
     n_latent = 2 * int(np.log2(resolution)) - 2
-    walk = torch.from_numpy(synth.walk_init(len(attrs), n_latent, seed=7))
-    idx = list(range(len(attrs)))
+    walk = torch.from_numpy(synth.walk_init(n_attr, n_latent, seed=7))
     done, t_total = 0, 0.0
     while True:
         z = torch.from_numpy(synth.z_sample(1, seed=done)).float()
         t0 = time.time()
-        ostep.train_step(nets, walk, z, torch.full((1, len(attrs)), 0.3), [31 + i for i in idx],
-                         no_content_loss=not full_loss, no_gan_loss=not full_loss)
+        ostep.train_step(nets, walk, z, torch.full((1, n_attr), 0.3), list(range(n_attr)),
+                         no_content_loss=not full_loss, no_gan_loss=not full_loss, clamp_variant=clamp)
         t_total += time.time() - t0
         done += 1
         if t_total >= budget_s or done >= 4:
@@ -57,22 +65,65 @@ def cpu_baseline(resolution, attrs, budget_s, full_loss=True):
                        % (done, resolution, t_total, torch.__version__))
 
 
+def lib_hash():
+    from latent2im_amd import _lib
+    with open(_lib.LIB_PATH, 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def call_bytes(q):
+    """Algorithmic HBM bytes of a conv call: input (+ its gradient mask) read once, output written once, every fused epilogue
+    operand (residual, its mask, output mask, accumulate, res_sub) read once; weights / per-sample vectors are noise."""
+    B, cin, cout, kh, kw, stride, H, W, OH, OW, step, in_mask = q[3][:12]
+    flags = q[3][13] if len(q[3]) > 13 else ''
+    extra = sum(1 for c in 'rmoas' if c in flags.rstrip('0123456789'))
+    return 4.0 * (B * cin * H * W * (2 if in_mask else 1) + B * cout * OH * OW * (1 + extra))
+
+
+def family_table(prof, steps):
+    """Per kernel family: launches, HIP-event time, algorithmic and executed TFLOP/s, fraction of the peak of the MFMA instruction
+    the family runs on.  executed = what the matrix cores actually multiply (Winograd F(2x2,3x3): 16/36 of the dense form; the
+    bf16 split: 3 bf16 products per fp32 product)."""
+    from latent2im_amd import conv
+    fam = {}
+    for q in prof:
+        f = fam.setdefault(q[5], dict(n=0, ms=0.0, flop=0.0, bytes=0.0))
+        f['n'] += 1
+        f['ms'] += q[0].elapsed_time(q[1])
+        f['flop'] += q[2]
+        f['bytes'] += call_bytes(q)
+    rows = []
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]['ms']):
+        kern, exe_ratio, peak = conv.FAMILY_INFO[name]
+        alg = f['flop'] / (f['ms'] * 1e-3) / 1e12
+        rows.append(dict(family=name, kernel=kern, launches_per_step=round(f['n'] / steps, 1), ms_per_step=round(f['ms'] / steps, 3),
+                         avg_launch_ms=round(f['ms'] / f['n'], 4), algorithmic_tflops=round(alg, 2), executed_tflops=round(alg * exe_ratio, 2),
+                         peak_tflops=peak, frac=round(alg * exe_ratio / peak, 4),
+                         algorithmic_bytes_per_launch=round(f['bytes'] / f['n']), algorithmic_flop_per_launch=round(f['flop'] / f['n']),
+                         hbm_GBs_algorithmic=round(f['bytes'] / (f['ms'] * 1e-3) / 1e9, 1)))
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', default='c3', choices=['c3', 'c5'], help='BASELINE.json configs[2] (headline) or configs[4] per-GPU shape')
     ap.add_argument('--resolution', type=int, default=1024)
     ap.add_argument('--batch', type=int, default=8, help='per-GPU batch')
-    ap.add_argument('--attrs', type=str, default='Smiling')
+    ap.add_argument('--attrs', type=str, default=None)
     ap.add_argument('--reg_only', action='store_true', help='--no_content_loss --no_gan_loss')
     ap.add_argument('--cpu_baseline_s', type=float, default=12.0, help='CPU-oracle time budget (0 = skip)')
     ap.add_argument('--no_kernel_events', action='store_true', help='do not bracket conv launches with events')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x3'],
-                    help="matrix path: exact fp32 MFMA (default) or the opt-in 3-term bf16 split (fp32-class accuracy)")
+    ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3'],
+                    help="matrix path: exact fp32 MFMA (c3 default) or the 3-term bf16 split with fp32 accumulation (c5 default)")
+    ap.add_argument('--hip_graph', type=int, default=None, help='1: replay forward+backward from one hipGraph (c5 default), 0: eager launches')
     ap.add_argument('--no_alt_precision', action='store_true', help='skip the extra timing of the other matrix path')
     ap.add_argument('--direct_3x3', action='store_true', help='run 3x3 stride-1 layers on the direct implicit-GEMM kernel instead of Winograd F(2x2,3x3)')
-    ap.add_argument('--serial_streams', action='store_true', help='run the three loss branches on one stream (profiling aid: with\n                    concurrent streams the per-kernel durations rocprof reports include time shared with other kernels)')
+    ap.add_argument('--serial_streams', action='store_true', help='run the three loss branches on one stream (profiling aid: with '
+                    'concurrent streams the per-kernel durations rocprof reports include time shared with other kernels)')
+    ap.add_argument('--noise_strength', type=float, default=NOISE_STRENGTH, help='generator NoiseInjection weights (0: no noise drawn)')
     a = ap.parse_args()
 
     from latent2im_amd import constants, conv, dist, selfcheck, synth
@@ -87,18 +138,24 @@ def main():
             raise SystemExit(1)
         print(lines[0], flush=True)
         return
+    c5 = a.config == 'c5'
+    precision = a.precision or ('bf16x3' if c5 else 'f32')
+    use_graph = bool(a.hip_graph) if a.hip_graph is not None else c5
+    transform = 'scene' if c5 else 'face'
+    attrs = a.attrs.split(',') if a.attrs else (SCENE_ATTRS if c5 else ['Smiling'])
+    clamp = c5                                              # train_multi_attr.py:113 flow for the multi-attribute configs
     if a.serial_streams:
         constants.CONCURRENT_LOSS_BRANCHES = False
-    conv.PRECISION = a.precision
+    constants.SYNTH_NOISE_STRENGTH = a.noise_strength
+    conv.PRECISION = precision
     conv.USE_WINOGRAD = not a.direct_3x3
     rk, world, local = dist.init_from_env()
     if a.gpus != world:
         raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     assert torch.cuda.is_available(), 'bench.py needs the MI355X'
     dev = torch.device('cuda', torch.cuda.current_device())
-    attrs = a.attrs.split(',')
     np.random.seed(1234)
-    g = selfcheck.build_graph(a.resolution, attrs, a.batch * world, lr=1e-4)
+    g = selfcheck.build_graph(a.resolution, attrs, a.batch * world, lr=1e-4, transform=transform)
     if world > 1:
         torch.distributed.broadcast(g.walk.w.data, src=0)
     flags = dict(no_content_loss=a.reg_only, no_gan_loss=a.reg_only)
@@ -106,11 +163,24 @@ def main():
     zs_all = synth.z_sample(global_b * (a.steps + a.warmup), seed=0)
     sl = dist.shard(global_b)
 
+    def draw_alpha():                                       # Face/SceneTransform.get_train_alpha: one draw per step, shared by the batch
+        lo = -1.0 if c5 else 0.0
+        return np.ones((a.batch, len(attrs))) * np.random.uniform(lo, 1, len(attrs))
+
+    captured = None
+
     def one_step(i):
         zs = zs_all[i * global_b:(i + 1) * global_b][sl]
-        alpha = np.ones((a.batch, len(attrs))) * np.random.uniform(0, 1, len(attrs))      # FaceTransform.get_train_alpha
-        return selfcheck.run_step(g, zs, alpha, **flags)
+        if captured is not None:
+            return captured(zs, draw_alpha())
+        return selfcheck.run_step(g, zs, draw_alpha(), clamp=clamp, **flags)
 
+    def make_captured():
+        from latent2im_amd import capture
+        return capture.CapturedStep(g, a.batch, len(attrs), clamp=clamp, **flags)
+
+    if use_graph:
+        captured = make_captured()
     for i in range(a.warmup):
         one_step(i)
     torch.cuda.synchronize()
@@ -124,11 +194,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = dist.max_over_ranks(elapsed, dev)
+    loss_value = float(r['loss'])
 
-    # roofline of the dominant kernel: the same steps again, now with a HIP event pair around every conv launch on the
-    # launch stream.  Kept out of the timed region above because ~280 event pairs per step cost ~7 % wall on their own.
+    # roofline of the conv kernels: the same steps again, eager, with a HIP event pair around every conv launch on the launch
+    # stream.  Kept out of the timed region above because ~280 event pairs per step cost ~7 % wall on their own.
     prof, t_events = None, None
     if not a.no_kernel_events:            # every rank repeats the steps (the walk-gradient all-reduce is inside a step); rank 0 reports
+        keep_captured, captured = captured, None
         concurrent, constants.CONCURRENT_LOSS_BRANCHES = constants.CONCURRENT_LOSS_BRANCHES, False   # one stream: durations do not overlap
         conv.PROFILE = []
         torch.cuda.synchronize()
@@ -139,13 +211,20 @@ def main():
         t_events = (time.perf_counter() - t1) / a.steps * 1e3
         prof, conv.PROFILE = conv.PROFILE, None
         constants.CONCURRENT_LOSS_BRANCHES = concurrent
+        captured = keep_captured
     dist.barrier()
 
     # the other matrix path, same steps, for the record (all ranks: the all-reduce is inside the step)
     alt = None
     if not a.no_alt_precision:
-        other = 'bf16x3' if a.precision == 'f32' else 'f32'
+        other = 'bf16x3' if precision == 'f32' else 'f32'
         conv.PRECISION = other
+        if use_graph:                                       # a graph holds the kernels of the precision it was captured with; its memory
+            import gc                                       # pool (every activation of a step) is released before the next one is built
+            captured = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            captured = make_captured()
         one_step(0)
         torch.cuda.synchronize()
         dist.barrier()
@@ -155,7 +234,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t_alt = dist.max_over_ranks(time.perf_counter() - t2, dev)
-        conv.PRECISION = a.precision
+        conv.PRECISION = precision
         alt = dict(precision=other, value=round(global_b * a.steps / t_alt, 3), unit='images/s', ms_per_step=round(t_alt / a.steps * 1e3, 2),
                    note='same workload and steps with the matrix path switched (see DESIGN.md section 2); not the headline value')
 
@@ -166,59 +245,63 @@ def main():
     value = global_b * a.steps / elapsed
     roof = None
     if prof:
-        # algorithmic HBM bytes of a conv call: input (+ its gradient mask) read once, output written once, every fused
-        # epilogue operand (residual, its mask, output mask, accumulate) read once; weights / per-sample vectors are noise
-        def call_bytes(q):
-            B, cin, cout, kh, kw, stride, H, W, OH, OW, step, in_mask = q[3][:12]
-            flags = q[3][13] if len(q[3]) > 13 else ''
-            extra = sum(1 for c in 'rmoas' if c in flags.rstrip('0123456789'))
-            return 4.0 * (B * cin * H * W * (2 if in_mask else 1) + B * cout * OH * OW * (1 + extra))
-        alg_bytes = sum(call_bytes(q) for q in prof) / len(prof)
-        traffic, traffic_note = None, 'no PMC summary for this workload under profiles/'
-        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_conv_hbm_traffic.json')
-        if (os.path.isfile(tp) and a.resolution == 1024 and a.batch == 8 and not a.reg_only and a.precision == 'f32' and not a.direct_3x3
-                and attrs == ['Smiling']):
-            tj = json.load(open(tp))
-            if abs(tj['conv_launches_per_step'] - len(prof) // a.steps) < 0.5:
-                traffic = round(tj['conv_bytes_per_launch'])
-                traffic_note = ('HBM bytes per conv launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command with --serial_streams '
-                                '(profiles/r01_conv_hbm_traffic.json, tools/hbm_traffic.py): KiB -> bytes, FETCH_SIZE doubled (gfx950), both factors '
-                                'checked on a kernel of known byte count in the same run; not re-measured live (counters need the profiler)')
+        fams = family_table(prof, a.steps)
+        dom = fams[0]                                       # the family with the most GPU time per step
         tot_ms = sum(q[0].elapsed_time(q[1]) for q in prof)
         tot_flop = sum(q[2] for q in prof)
-        ach = tot_flop / (tot_ms * 1e-3) / 1e12
-        wino = [q for q in prof if q[4] == 'l2i_conv2d_wino_f32']
-        exe_flop = tot_flop - sum(q[2] for q in wino) * (1.0 - 16.0 / 36.0)      # F(2x2,3x3): 16 multiplies per 2x2 tile instead of 36
-        exe = exe_flop / (tot_ms * 1e-3) / 1e12
-        peak = PEAK_F32_MFMA_TFLOPS if a.precision == 'f32' else PEAK_BF16_MFMA_TFLOPS
-        roof = dict(bound='mfma', kernel='conv_wino_kernel / conv_mfma_kernel + gemm1x1_kernel / convt_mfma_kernel (l2i_conv2d_wino_f32, l2i_conv2d_f32, l2i_conv_transpose2d_f32)' if a.precision == 'f32'
-                    else 'conv_bf16x3_kernel + fp32 kernels for ineligible layers (algorithmic FLOPs; the split executes 3 MFMA FLOPs per algorithmic FLOP)',
-                    achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=traffic, traffic_unit='bytes per launch', traffic_note=traffic_note,
-                    algorithmic_bytes_per_launch=round(alg_bytes),
-                    launches_per_step=len(prof) // a.steps, avg_launch_ms=round(tot_ms / len(prof), 4),
-                    kernel_ms_per_step=round(tot_ms / a.steps, 2),
-                    algorithmic_tflop_per_step=round(tot_flop / a.steps / 1e12, 3),
-                    executed_mfma_tflops=round(exe, 2), executed_frac=round(exe / peak, 4),
-                    winograd_launches_per_step=len(wino) // a.steps, winograd_ms_per_step=round(sum(q[0].elapsed_time(q[1]) for q in wino) / a.steps, 2),
-                    ms_per_step_with_events=round(t_events, 2),
-                    note='achieved = sum over conv launches (l2i_conv2d_wino_f32 + l2i_conv2d_f32 + l2i_conv_transpose2d_f32) of 2*MAC of the dense '
-                         'correlation / sum of their HIP-event durations, over a repeat of the timed steps on ONE stream with an event pair '
-                         'per launch (the timed region itself runs the three loss branches on separate streams, without events); algorithmic TFLOP per image = algorithmic_tflop_per_step / batch. '
-                         '3x3 stride-1 layers run as Winograd F(2x2,3x3) (fp32 products, 16/36 of the direct multiplies): executed_mfma_tflops counts what the matrix cores '
-                         'actually execute, achieved counts the algorithmic FLOPs of the dense correlation as the contract asks')
+        exe_flop = sum(q[2] * conv.FAMILY_INFO[q[5]][1] for q in prof)
+        peak_all = max(f['peak_tflops'] for f in fams)
+        # HBM bytes of the dominant kernel from the PMC summary that was taken with THIS build of the library (else null)
+        traffic, traffic_note = None, 'no PMC summary under profiles/ for this build of libl2i_hip.so and this workload'
+        tag = 'c5' if c5 else 'c3'
+        tp = os.path.join(ROOT, 'profiles', 'r02_%s_hbm_traffic.json' % tag)
+        if os.path.isfile(tp):
+            tj = json.load(open(tp))
+            ent = tj.get('per_family', {}).get(dom['family'])
+            if tj.get('lib_sha256_16') == lib_hash() and tj.get('workload') == [a.resolution, a.batch, attrs, precision, bool(a.reg_only)] and ent \
+                    and abs(ent['launches_per_step'] - dom['launches_per_step']) < 0.5:
+                traffic = round(ent['bytes_per_launch'])
+                traffic_note = ('HBM bytes per launch of %s from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate) over this command with '
+                                '--serial_streams (profiles/%s, tools/hbm_traffic.py): KiB -> bytes, FETCH_SIZE doubled (gfx950), both factors checked on '
+                                'a kernel of known byte count in the same run; the summary carries the sha256 of the library it was taken with and is '
+                                'dropped when it differs' % (dom['kernel'], os.path.basename(tp)))
+            else:
+                traffic_note = 'profiles/%s was taken with another build / workload (library %s now): dropped' % (os.path.basename(tp), lib_hash())
+        roof = dict(bound='mfma', kernel=dom['kernel'], family=dom['family'],
+                    achieved=dom['executed_tflops'], peak=dom['peak_tflops'], unit='TFLOP/s', frac=dom['frac'],
+                    traffic=traffic, traffic_unit='bytes per launch', traffic_note=traffic_note,
+                    algorithmic_tflops=dom['algorithmic_tflops'], algorithmic_flop_per_launch=dom['algorithmic_flop_per_launch'],
+                    algorithmic_bytes_per_launch=dom['algorithmic_bytes_per_launch'], avg_launch_ms=dom['avg_launch_ms'],
+                    launches_per_step=dom['launches_per_step'], kernel_ms_per_step=dom['ms_per_step'],
+                    hbm_bound=dict(peak_GBs=HBM_PEAK_GBS, achieved_GBs_algorithmic=dom['hbm_GBs_algorithmic'],
+                                   frac=round(dom['hbm_GBs_algorithmic'] / HBM_PEAK_GBS, 4)),
+                    families=fams,
+                    all_conv=dict(launches_per_step=len(prof) // a.steps, ms_per_step=round(tot_ms / a.steps, 2),
+                                  algorithmic_tflop_per_step=round(tot_flop / a.steps / 1e12, 3),
+                                  algorithmic_tflops=round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
+                                  executed_tflops=round(exe_flop / (tot_ms * 1e-3) / 1e12, 2),
+                                  executed_frac_of_fastest_instruction_peak=round(exe_flop / (tot_ms * 1e-3) / 1e12 / peak_all, 4)),
+                    ms_per_step_with_events=round(t_events, 2), library_sha256_16=lib_hash(),
+                    note='dominant kernel family = most GPU time per step.  achieved / frac = FLOPs the matrix cores EXECUTE in that family '
+                         '(Winograd F(2x2,3x3): 16/36 of the dense correlation; 3-term bf16 split: 3 products per fp32 product) / its HIP-event time '
+                         '/ the dense peak of the MFMA instruction it runs on; algorithmic_tflops = 2*MAC of the dense correlation / the same time. '
+                         'Events: an eager repeat of the timed steps on ONE stream with an event pair per conv launch (the timed region has none). '
+                         'families: the same figures for every conv kernel family of the step; all_conv: their sum')
+    wl = ('StyleGAN2 FFHQ-shaped %d^2 generator (random-init, noise weights ~ %g: per-layer noise drawn every pass), ResNet-50 regressor, '
+          '%d %s attr (%s flow), %s, batch %d per GPU, linear W+ walk, %s launches'
+          % (a.resolution, a.noise_strength, len(attrs), 'transient-scene' if c5 else 'CelebA', 'train_multi_attr.py clamp' if clamp else 'train.py',
+             'reg-only loss' if a.reg_only else 'full loss (reg+content+GAN)', a.batch, 'hipGraph-replayed' if use_graph else 'eager'))
     out = dict(metric='edited images/sec', value=round(value, 3), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
-               ms_per_step=round(ms_per_step, 2), higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.precision,
+               ms_per_step=round(ms_per_step, 2), higher_is_better=True, scaling='weak', vs_baseline=None, dtype=precision,
                data='synthetic',
-               config=dict(workload='StyleGAN2 FFHQ-shaped %d^2 generator (random-init), ResNet-50 regressor, %d attr, %s, '
-                                    'batch %d per GPU, linear W+ walk' % (a.resolution, len(attrs),
-                                                                          'reg-only loss' if a.reg_only else 'full loss (reg+content+GAN)', a.batch),
+               config=dict(workload=wl, baseline_config='configs[4] per-GPU shape' if c5 else 'configs[2]',
                            resolution=a.resolution, global_batch=global_b, per_gpu_batch=a.batch, attrs=attrs,
                            losses='reg' if a.reg_only else 'reg+content+gan', parallelism='dp%d' % world,
-                           loss_branch_streams=3 if constants.CONCURRENT_LOSS_BRANCHES else 1,
-                           loss=float(r['loss'])),
+                           loss_branch_streams=3 if constants.CONCURRENT_LOSS_BRANCHES else 1, hip_graph=use_graph,
+                           noise_strength=a.noise_strength, loss=loss_value),
                roofline=roof, alt_precision=alt)
     if world == 1 and a.cpu_baseline_s > 0:
-        out['cpu_baseline'] = cpu_baseline(a.resolution, attrs, a.cpu_baseline_s, full_loss=not a.reg_only)
+        out['cpu_baseline'] = cpu_baseline(a.resolution, len(attrs), a.cpu_baseline_s, full_loss=not a.reg_only, clamp=clamp)
     else:
         out['cpu_baseline'] = None
     print(json.dumps(out), flush=True)

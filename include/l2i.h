@@ -88,6 +88,14 @@ typedef struct l2i_conv_params {
 
 int l2i_conv2d_f32(const l2i_conv_params* p, void* stream);
 
+/* Which kernel family l2i_conv2d_f32 runs `p` on (no launch; pure function of the parameters): the measurement code uses it to
+ * price every launch against the roofline of the kernel that actually ran. */
+#define L2I_FAMILY_IMPLICIT_GEMM 0  /* conv_mfma_kernel: LDS-staged halo tile, v_mfma_f32_32x32x2_f32 */
+#define L2I_FAMILY_GEMM1X1 1        /* gemm1x1_kernel: DMA-fed plain GEMM of unscaled 1x1 stride-1 layers */
+#define L2I_FAMILY_CIN3 2           /* conv_cin3_kernel: 3x3 convs of <= 3-channel images */
+#define L2I_FAMILY_DIRECT_SMALL 3   /* conv_direct_small_kernel: <= 4 output channels, VALU */
+int l2i_conv2d_family(const l2i_conv_params* p);
+
 /* Stride-2 TRANSPOSED convolution, all four output parities in one launch:
  *   y[b,co,2*iy+ky-pad,2*ix+kx-pad] += x[b,ci,iy,ix] * w[co,ci,ky,kx]          (F.conv_transpose2d(stride=2) of the up
  *   layers, networks.py:246-255, and the input-gradient of every stride-2 conv of the path).

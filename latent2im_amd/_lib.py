@@ -39,6 +39,7 @@ class ConvParams(ctypes.Structure):
 
 _SIGNATURES = {
     'l2i_conv2d_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
+    'l2i_conv2d_family': (c_i, [ctypes.POINTER(ConvParams)]),
     'l2i_conv_transpose2d_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_bf16x3_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_wino_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),

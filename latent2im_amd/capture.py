@@ -1,0 +1,93 @@
+"""The walk-training step as a hipGraph (BASELINE config 5: "hipGraph-captured step").
+
+Everything between "z and alpha are on the device" and "the walk gradient is complete" is static-shaped GPU work issued from
+Python one launch at a time (~300 conv launches + ~500 small kernels per step).  ``CapturedStep`` records that region ONCE with
+``torch.cuda.graph`` (HIP stream capture -> hipGraphInstantiate) and replays it with a single ``hipGraphLaunch`` per step:
+
+    z, alpha (static device buffers, refilled by an async copy before each replay)
+      -> style MLP -> synthesis (x0) -> regressor -> epsilon (device-side: no ``.item()``, no host read of alpha_org)
+      -> walk -> synthesis (x1) -> D / VGG / regressor losses on their three streams (forked from and joined to the captured
+         stream) -> backward into ``walk.grad``
+
+The all-reduce of the walk gradient (RCCL) and the Adam update stay OUTSIDE the graph, in the order optimizeParametersAll runs
+them: a handful of tiny launches, and the captured region holds no collective, so the same graph serves 1 and N ranks.
+Per-layer generator noise (networks.py:281-286) is drawn inside the graph from torch's graph-safe Philox stream (fresh values every
+replay).  Reference: train.py:56-110 is the region; the reference itself is eager PyTorch.
+"""
+import numpy as np
+import torch
+
+from . import dist
+
+
+def forward(g, z, alpha_for_graph, clamp=False, layers=None):
+    """train.py:56-101 on DEVICE inputs: both generator passes, the regressor on the original, epsilon and the walk; no host
+    synchronisation.  Returns (feed_dict for optimizeParametersAll, dict of device tensors)."""
+    w = g.get_w(z)
+    x0 = g.get_logits({'w': w})
+    a0 = g.get_reg_preds(x0)
+    if clamp:
+        target, eps = g.get_alphas_clamped(a0, alpha_for_graph)
+    else:
+        target, eps = alpha_for_graph, g.get_alphas(a0, alpha_for_graph)
+    w1 = g.get_w_new_tensor(w, eps, layers=layers)
+    x1 = g.get_logits({'w': w1})
+    return {'w': w1, 'org': x0, 'logit': x1, 'alpha': target}, dict(x0=x0, x1=x1, a0=a0, eps=eps)
+
+
+def forward_backward(g, z, alpha_for_graph, no_content_loss=False, no_gan_loss=False, clamp=False, layers=None):
+    """``forward`` + the loss and backward of optimizeParametersAll (transform_base.py:459-488), without its all-reduce / Adam tail.
+    Leaves d loss / d walk in ``walk.grad``."""
+    feed, r = forward(g, z, alpha_for_graph, clamp=clamp, layers=layers)
+    g.optimizers.zero_grad()
+    loss = g.get_w_loss(feed, no_content_loss, no_gan_loss)
+    loss.backward()
+    r.update(loss=loss.detach(), terms=g.last_terms)
+    return r
+
+
+class CapturedStep:
+    """``step(zs, alpha)`` == selfcheck.run_step(g, zs, alpha, ...) with the forward+backward replayed from one hipGraph."""
+
+    def __init__(self, g, batch, n_attr, no_content_loss=False, no_gan_loss=False, clamp=False, layers=None, warmup=2):
+        self.g = g
+        dev = g.device
+        self.z = torch.zeros(batch, g.dim_z, device=dev)
+        self.alpha = torch.zeros(batch, n_attr, device=dev)
+        self._stage_z = torch.zeros(batch, g.dim_z).pin_memory()
+        self._stage_a = torch.zeros(batch, n_attr).pin_memory()
+        kw = dict(no_content_loss=no_content_loss, no_gan_loss=no_gan_loss, clamp=clamp, layers=layers)
+        # warm-up on a side stream (allocator pools, split-K workspaces, lazily packed weights), as stream capture requires
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(max(warmup, 1)):
+                forward_backward(g, self.z, self.alpha, **kw)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g.optimizers.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = forward_backward(g, self.z, self.alpha, **kw)
+        self.grads = [p.grad for p in g.walk.parameters()]          # static tensors inside the graph's pool, rewritten by every replay
+        self.launches = None
+
+    def load(self, zs, alpha):
+        """Host -> the graph's static inputs (pinned staging, asynchronous on the current stream)."""
+        self._stage_z.copy_(torch.as_tensor(np.asarray(zs), dtype=torch.float32))
+        self._stage_a.copy_(torch.as_tensor(np.asarray(alpha), dtype=torch.float32))
+        self.z.copy_(self._stage_z, non_blocking=True)
+        self.alpha.copy_(self._stage_a, non_blocking=True)
+
+    def __call__(self, zs=None, alpha=None, optimize=True):
+        if zs is not None:
+            self.load(zs, alpha)
+        self.graph.replay()
+        for p, gr in zip(self.g.walk.parameters(), self.grads):      # Adam reads p.grad: the graph's static gradient tensors
+            p.grad = gr
+        if optimize:
+            dist.average_gradients(self.g.walk.parameters())         # one RCCL all-reduce of <= 184 KB, outside the graph
+            self.g.optimizers.step()
+        o = dict(self.out)
+        o['grad'] = self.grads[0]
+        return o

@@ -18,6 +18,9 @@ g_path = '/path/550000.pt'
 vgg_path = ''
 
 SYNTH_SEED_G, SYNTH_SEED_D, SYNTH_SEED_R, SYNTH_SEED_V = 100, 200, 300, 400
+# per-layer NoiseInjection weights of the synthetic generator: 0 like a fresh reference Generator (networks.py:279; parity tests), > 0
+# like a trained one (bench.py: the per-layer N(0,1) draw of networks.py:281-286 is then inside the timed region)
+SYNTH_NOISE_STRENGTH = 0.0
 
 # run the discriminator / VGG / regressor loss branches on separate HIP streams (see graph.TransformGraph.get_w_loss)
 CONCURRENT_LOSS_BRANCHES = True

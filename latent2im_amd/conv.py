@@ -22,7 +22,18 @@ USE_WINOGRAD = _os.environ.get('L2I_WINOGRAD', '1') != '0'    # 3x3 stride-1 lay
 SPLIT_K = _os.environ.get('L2I_SPLIT_K', '1') != '0'    # 4x4 .. 16x16 maps: cut Cin into ranges computed by separate blocks (l2i.h: ksplit / ws)
 _WS = {}            # split-K workspaces, one per (device, stream)
 USE_FUSED_TRANSPOSED = True     # False: issue stride-2 transposed convs as four per-parity launches
-PROFILE = None      # bench.py sets this to a list: every launch then appends (start_event, end_event, algorithmic_flops, shape, entry point)
+PROFILE = None      # bench.py sets this to a list: every launch then appends (start_event, end_event, algorithmic_flops, shape, entry point, kernel family)
+FAMILIES = ('implicit_gemm_f32', 'gemm1x1_f32', 'cin3_f32', 'direct_small_valu')      # l2i.h: L2I_FAMILY_* of l2i_conv2d_f32
+# kernel family -> (kernel name in rocprof, MFMA FLOPs executed per algorithmic FLOP, peak TFLOP/s of the instruction it runs on)
+FAMILY_INFO = {
+    'winograd_f32': ('conv_wino_kernel', 16.0 / 36.0, 157.3),
+    'implicit_gemm_f32': ('conv_mfma_kernel', 1.0, 157.3),
+    'gemm1x1_f32': ('gemm1x1_kernel', 1.0, 157.3),
+    'transposed_f32': ('convt_mfma_kernel', 1.0, 157.3),
+    'cin3_f32': ('conv_cin3_kernel', 28.0 / 27.0, 157.3),
+    'direct_small_valu': ('conv_direct_small_kernel', 1.0, 157.3),
+    'implicit_gemm_bf16x3': ('conv_bf16x3_kernel', 3.0, 2500.0),
+}
 
 
 def pack_weight(w):
@@ -224,7 +235,8 @@ def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), 
         _lib.check(lib.l2i_conv_transpose2d_f32(p, _lib.stream_ptr()), 'l2i_conv_transpose2d_f32')
         e1.record()
         PROFILE.append((e0, e1, 2.0 * B * F.cout * cin * F.k * F.k * H * W,
-                        (B, cin, F.cout, F.k, F.k, 2, H, W, int(p.OHf), int(p.OWf), 2, in_mask is not None, in_scale is not None), 'l2i_conv_transpose2d_f32'))
+                        (B, cin, F.cout, F.k, F.k, 2, H, W, int(p.OHf), int(p.OWf), 2, in_mask is not None, in_scale is not None), 'l2i_conv_transpose2d_f32',
+                        'transposed_f32'))
         return y
     _lib.check(lib.l2i_conv_transpose2d_f32(p, _lib.stream_ptr()), 'l2i_conv_transpose2d_f32')
     return y
@@ -280,6 +292,9 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         p.w = _lib.fptr(L.wino_pack())
         entry, name = lib.l2i_conv2d_wino_f32, 'l2i_conv2d_wino_f32'
     if PROFILE is not None:
+        family = {'l2i_conv2d_wino_f32': 'winograd_f32', 'l2i_conv2d_bf16x3_f32': 'implicit_gemm_bf16x3'}.get(name)
+        if family is None:
+            family = FAMILIES[lib.l2i_conv2d_family(p)]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _lib.check(entry(p, _lib.stream_ptr()), name)
@@ -287,7 +302,7 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         PROFILE.append((e0, e1, 2.0 * B * L.cout * cin * L.kh * L.kw * OH * OW,
                         (B, cin, L.cout, L.kh, L.kw, L.stride, H, W, OH, OW, L.step, in_mask is not None, in_scale is not None,
                          ''.join(c for c, t in zip('dnbrmoas', (out_scale, noise, bias, residual, res_mask, out_mask, accumulate or None, res_sub)) if t is not None) + str(act)),
-                        name))
+                        name, family))
         return
     _lib.check(entry(p, _lib.stream_ptr()), name)
 

@@ -694,6 +694,17 @@ static bool plan_tile(const l2i_conv_params& p, int wm, int wn, ConvLaunch& L, b
     return lds <= 64 * 1024 && grid > 0 && grid <= 0x7fffffffL;
 }
 
+extern "C" int l2i_conv2d_family(const l2i_conv_params* pp) {
+    if (!pp) return L2I_E_ARG;
+    const l2i_conv_params& p = *pp;
+    if (p.Cout <= 4 && p.stride == 1 && p.KH <= 16 && p.tile_hint == 0 && !p.out_scale && !p.noise && !p.bias && !p.residual && !p.out_mask &&
+        p.act == L2I_ACT_NONE)
+        return L2I_FAMILY_DIRECT_SMALL;
+    if (p.tile_hint == 0 && l2i_gemm1x1_eligible(p)) return L2I_FAMILY_GEMM1X1;
+    if (p.tile_hint == 0 && l2i_cin3_eligible(p)) return L2I_FAMILY_CIN3;
+    return L2I_FAMILY_IMPLICIT_GEMM;
+}
+
 extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
     if (!pp) return l2i_set_error(L2I_E_ARG, "conv2d: null params");
     const l2i_conv_params& p = *pp;
@@ -711,12 +722,10 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
     if ((size_t)p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull || (size_t)p.Cin * p.KH * p.KW * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d: one sample / the weight pack must stay below 4 GiB (32-bit buffer offsets)");
 
-    if (p.Cout <= 4 && p.stride == 1 && p.KH <= 16 && p.tile_hint == 0 && !p.out_scale && !p.noise && !p.bias && !p.residual && !p.out_mask &&
-        p.act == L2I_ACT_NONE)
-        return launch_direct_small(p, (hipStream_t)stream);
-
-    if (p.tile_hint == 0 && l2i_gemm1x1_eligible(p)) return l2i_launch_gemm1x1(p, (hipStream_t)stream);
-    if (p.tile_hint == 0 && l2i_cin3_eligible(p)) return l2i_launch_cin3(p, (hipStream_t)stream);
+    const int family = l2i_conv2d_family(pp);
+    if (family == L2I_FAMILY_DIRECT_SMALL) return launch_direct_small(p, (hipStream_t)stream);
+    if (family == L2I_FAMILY_GEMM1X1) return l2i_launch_gemm1x1(p, (hipStream_t)stream);
+    if (family == L2I_FAMILY_CIN3) return l2i_launch_cin3(p, (hipStream_t)stream);
 
     // ---- tile selection: minimise a simple time model  waves(grid / resident blocks) x cycles per block  ----
     //      cycles per block = MFMA issue (64 cycles each) + per-chunk barrier/commit cost + epilogue stores (hidden by co-resident blocks);

@@ -161,8 +161,8 @@ def load_networks(resolution, device, need_vgg=True, need_d=True):
         g_state = _to_numpy_state(torch.load(constants.g_path, map_location='cpu')['g_ema'])
         src['G'] = constants.g_path
     else:
-        g_state = synth.generator_state(resolution, seed=constants.SYNTH_SEED_G)
-        src['G'] = 'synthetic(seed=%d)' % constants.SYNTH_SEED_G
+        g_state = synth.generator_state(resolution, seed=constants.SYNTH_SEED_G, noise_strength=constants.SYNTH_NOISE_STRENGTH)
+        src['G'] = 'synthetic(seed=%d%s)' % (constants.SYNTH_SEED_G, ', noise_strength=%g' % constants.SYNTH_NOISE_STRENGTH if constants.SYNTH_NOISE_STRENGTH else '')
     if _checkpoint_or_synthetic('regressor (reg_path)', constants.reg_path):
         r_state = _to_numpy_state(torch.load(constants.reg_path, map_location='cpu')['model'])
         src['R'] = constants.reg_path

@@ -45,6 +45,10 @@ class TrainOptions:
         p.add_argument('--max_iters', type=int, default=None, help='stop each epoch after this many iterations')
         p.add_argument('--seed', type=int, default=None, help='seed numpy global RNG (walk init, alpha draws)')
         p.add_argument('--no_log_sync', action='store_true', help='do not read the loss back every step (train.py:110)')
+        p.add_argument('--hip_graph', action='store_true',
+                       help='record forward+backward of the step once and replay it from one hipGraph per iteration (static batch size)')
+        p.add_argument('--precision', type=str, default=None, choices=['f32', 'bf16x3'],
+                       help='matrix path of the frozen convolutions: exact fp32 MFMA (default) or the 3-term bf16 split (fp32 accumulation)')
         p.add_argument('--synthetic_weights', action='store_true',
                        help='run on seeded random-init G / regressor / VGG when the checkpoint paths of constants.py do not exist '
                             '(default: a missing checkpoint is an error, as in the reference)')

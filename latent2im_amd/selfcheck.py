@@ -7,20 +7,22 @@ import numpy as np
 import torch
 
 
-def build_graph(resolution, attr_names, batch_size, lr=1e-3, walk_seed=7, device=None):
-    """A faceGraph on synthetic weights without touching the CLI (used by smoke(), bench.py and the tests)."""
+def build_graph(resolution, attr_names, batch_size, lr=1e-3, walk_seed=7, device=None, transform='face'):
+    """A faceGraph (CelebA attribute table) or SceneGraph (transient-scene table) on synthetic weights without touching the CLI
+    (used by smoke(), bench.py and the tests)."""
     from . import constants, graph, synth
     constants.resolution = resolution
     constants.BATCH_SIZE = batch_size
     constants.ALLOW_SYNTHETIC_WEIGHTS = True              # explicit: this helper exists to build the seeded random-init networks
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, 'dataset', 'attributes_celeba.txt')) as f:
+    with open(os.path.join(root, 'dataset', 'attributes_celeba.txt' if transform == 'face' else 'attributes_scene.txt')) as f:
         names = [l.strip() for l in f if l.strip()]
     table = {n: i for i, n in enumerate(names)}
     state = np.random.get_state()
-    g = graph.faceGraph(lr=lr, walk_type='linear', loss='l2', trainEmbed=False, attrList=list(attr_names), attrTable=table,
-                        layers=None, stylegan_opts=types.SimpleNamespace(latent='w'))
+    cls = {'face': graph.faceGraph, 'scene': graph.SceneGraph}[transform]      # (find_model_using_name prints; bench.py owns stdout)
+    g = cls(lr=lr, walk_type='linear', loss='l2', trainEmbed=False, attrList=list(attr_names), attrTable=table,
+            layers=None, stylegan_opts=types.SimpleNamespace(latent='w'))
     np.random.set_state(state)
     if hasattr(g.walk, 'w'):                               # the linear walk; the MLP walks keep torch's own (seeded by the caller) init
         with torch.no_grad():
@@ -30,26 +32,18 @@ def build_graph(resolution, attr_names, batch_size, lr=1e-3, walk_seed=7, device
 
 def run_step(g, zs, alpha, no_content_loss=False, no_gan_loss=False, clamp=False, layers=None, optimize=True):
     """train.py:56-110 with an explicit alpha instead of the global-RNG draw.  Returns dict of device tensors."""
+    from . import capture
     dev = g.device
     z = torch.Tensor(zs).to(dev)
-    w = g.get_w(z)
-    x0 = g.get_logits({'w': w})
-    a0 = g.get_reg_preds(x0)
     ag = torch.tensor(alpha).float().to(dev)
-    if clamp:
-        target, eps = g.get_alphas_clamped(a0, ag)
-    else:
-        target, eps = ag, g.get_alphas(a0, ag)
-    w1 = g.get_w_new_tensor(w, eps, layers=layers)
-    x1 = g.get_logits({'w': w1})
-    feed = {'w': w1, 'org': x0, 'logit': x1, 'alpha': target}
     if optimize:
+        feed, r = capture.forward(g, z, ag, clamp=clamp, layers=layers)
         loss = g.optimizeParametersAll(feed, False, False, no_content_loss=no_content_loss, no_gan_loss=no_gan_loss)
+        r.update(loss=loss.detach(), terms=g.last_terms)
     else:
-        g.optimizers.zero_grad()
-        loss = g.get_w_loss(feed, no_content_loss, no_gan_loss)
-        loss.backward()
-    return dict(x0=x0, x1=x1, a0=a0, eps=eps, loss=loss.detach(), grad=g.walk.w.grad.detach().clone(), terms=g.last_terms)
+        r = capture.forward_backward(g, z, ag, no_content_loss=no_content_loss, no_gan_loss=no_gan_loss, clamp=clamp, layers=layers)
+    r['grad'] = g.walk.w.grad.detach().clone() if hasattr(g.walk, 'w') else None
+    return r
 
 
 def smoke():

@@ -45,6 +45,11 @@ def make_samples(img_tensor, output_dir, epoch, optim_iter, batch_size, pre_path
 def train_step(graphs, zs_batch, attrList, layers=None, trainEmbed=False, updateGAN=False, opt=None, multi_attr=False):
     """One iteration of the hot loop.  ``zs_batch``: this rank's [B_local, 512] numpy slice.  Returns
     (loss tensor, alpha_for_target, out_zs, transformed_output)."""
+    if opt is not None and getattr(opt, 'hip_graph', False) and not trainEmbed and zs_batch.shape[0] == _captured_batch(graphs, zs_batch):
+        # --hip_graph: the same calls, recorded once (capture.CapturedStep) and replayed; alpha is still drawn on the host
+        alpha_for_graph, alpha_for_target, _ = graphs.get_train_alpha(zs_batch, N_attr=len(attrList), trainEmbed=trainEmbed)
+        r = graphs._captured_step(zs_batch, alpha_for_graph)
+        return r['loss'], alpha_for_target, r['x0'], r['x1']
     z_global = torch.Tensor(zs_batch).to(graphs.device)                       # train.py:56
     w_global = graphs.get_w(z_global)                                          # :62
     out_zs = graphs.get_logits({'z': z_global, 'w': w_global})                 # :66
@@ -64,6 +69,17 @@ def train_step(graphs, zs_batch, attrList, layers=None, trainEmbed=False, update
     return loss, alpha_for_target, out_zs, transformed_output
 
 
+def _captured_batch(graphs, zs_batch):
+    """Build the hipGraph of the step on first use (the local batch size is static from then on; a ragged last batch runs eagerly)."""
+    st = getattr(graphs, '_captured_step', None)
+    if st is None:
+        from . import capture
+        o = graphs._captured_opts
+        st = graphs._captured_step = capture.CapturedStep(graphs, zs_batch.shape[0], len(o['attrList']), clamp=o['multi_attr'], layers=o['layers'],
+                                                          no_content_loss=o['no_content_loss'], no_gan_loss=o['no_gan_loss'])
+    return st.z.shape[0]
+
+
 def train(graphs, graph_inputs, output_dir, attrList, layers=None, save_freq=100, trainEmbed=False, updateGAN=False,
           opt=None, multi_attr=False):
     is_main = dist.rank() == 0
@@ -71,6 +87,8 @@ def train(graphs, graph_inputs, output_dir, attrList, layers=None, save_freq=100
         os.makedirs(os.path.join(output_dir, 'results'), exist_ok=True)
         _configure_logging(os.path.join(output_dir, 'log.txt'), append=False)
         logging.info('weight sources: {}'.format(getattr(graphs, 'weight_sources', None)))
+    graphs._captured_opts = dict(attrList=attrList, multi_attr=multi_attr, layers=None if layers is None else [int(l) for l in layers],
+                                 no_content_loss=bool(opt and opt.no_content_loss), no_gan_loss=bool(opt and opt.no_gan_loss))
     n_epoch = (opt.n_epoch if opt is not None and getattr(opt, 'n_epoch', None) else (3 if multi_attr else 10))
     batch_size = constants.BATCH_SIZE
     num_samples = graph_inputs['z'].shape[0]
@@ -117,6 +135,9 @@ def main(multi_attr=False, argv=None):
     rk, world, local = dist.init_from_env()
     if opt.synthetic_weights:
         constants.ALLOW_SYNTHETIC_WEIGHTS = True
+    if opt.precision:
+        from . import conv
+        conv.PRECISION = opt.precision
     if opt.resolution:
         constants.resolution = opt.resolution
     if opt.batch_size:

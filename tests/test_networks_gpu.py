@@ -678,3 +678,38 @@ def test_networks_small_maps_large_batch_vs_oracle(size, batch):
     other = torch.roll(img_o, 3, 3)
     _, lo = ostep.content_loss(ostep.to_torch(stV), other, img_o)
     close(VGG19Prefix(stV, device=DEV).content_losses(other.to(DEV), img_o.to(DEV)), torch.stack(lo), 1e-3, 1e-6)
+
+
+def test_hipgraph_captured_step_matches_eager(precision):
+    """BASELINE config 5's step shape at test size: SceneGraph on the transient-scene attribute table, five attributes, the
+    train_multi_attr.py clamp flow, forward+backward replayed from ONE hipGraph (latent2im_amd.capture.CapturedStep: static device
+    inputs, device-side epsilon, the three loss-branch streams captured as forks) — against the same steps launched eagerly and
+    against the CPU oracle.  Three optimiser steps: the replayed graph must follow the walk as Adam moves it."""
+    from latent2im_amd import capture, constants
+    try:
+        attrs = ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk']
+        size, batch = 64, 4
+        rs = np.random.RandomState(3)
+        zs = [synth.z_sample(batch, seed=40 + i) for i in range(3)]
+        al = [np.ones((batch, 5)) * rs.uniform(-1, 1, 5) for _ in range(3)]          # SceneTransform.get_train_alpha
+        ge = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform='scene')
+        assert type(ge).__name__ == 'SceneGraph' and ge.attrIdx == [0, 1, 2, 3, 4]
+        eager = [selfcheck.run_step(ge, zs[i], al[i], clamp=True) for i in range(3)]
+        gc = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform='scene')
+        step = capture.CapturedStep(gc, batch, 5, clamp=True)
+        for i in range(3):
+            r = step(zs[i], al[i])
+            torch.cuda.synchronize()
+            close(r['x1'], eager[i]['x1'], 1e-4, 1e-5)
+            close(r['eps'], eager[i]['eps'], 1e-4, 1e-6)
+            close(r['loss'], eager[i]['loss'], 1e-5, 1e-6)
+            assert relmax(r['grad'], eager[i]['grad']) < 1e-3
+        assert relmax(gc.walk.w, ge.walk.w) < 1e-3 and not torch.equal(gc.walk.w.detach().cpu(), T(synth.walk_init(5, 10, seed=7)))
+        # the first step against the oracle (scene attribute indices 0..4, clamp flow)
+        o = ostep.train_step(_oracle_nets(size), T(synth.walk_init(5, 10, seed=7)), T(zs[0]).float(), T(al[0]).float(), [0, 1, 2, 3, 4], clamp_variant=True)
+        close(eager[0]['x1'], o['x1'])
+        close(eager[0]['eps'], o['eps'])
+        close(eager[0]['loss'], o['loss'], 1e-3, 1e-4)
+        assert relmax(eager[0]['grad'], o['grad']) < 2e-2
+    finally:
+        constants.resolution, constants.BATCH_SIZE = 256, 4
