@@ -286,8 +286,16 @@ class TransformGraph:
             layers = [int(l) for l in layers]                 # the reference passes strings through
         return self.walk(multi_ws, alpha=alpha, layers=layers)
 
+    def _attr_columns(self):
+        """attrIdx as a device index tensor, built once: indexing with the python list would copy it host -> device on every call
+        (a synchronous copy, and not permitted while the step is being captured into a hipGraph)."""
+        t = getattr(self, '_attr_index', None)
+        if t is None or t.numel() != len(self.attrIdx) or t.device != self.device:
+            t = self._attr_index = torch.tensor(list(self.attrIdx), dtype=torch.long, device=self.device)
+        return t
+
     def get_reg_preds(self, logit):
-        preds = self.regressor(logit)[:, self.attrIdx]        # integer column select: bit-exact
+        preds = self.regressor(logit).index_select(1, self._attr_columns())        # integer column select: bit-exact
         if len(preds.size()) == 1:
             preds = preds.unsqueeze(1)
         return preds
@@ -307,7 +315,7 @@ class TransformGraph:
     def get_reg_loss(self, feed_dict):
         logit = feed_dict['logit']
         alpha_gt = feed_dict['alpha'].to(torch.double)
-        preds = self.regressor(logit)[:, self.attrIdx]
+        preds = self.regressor(logit).index_select(1, self._attr_columns())
         return self.get_bce_loss(preds, alpha_gt).mean()
 
     def get_content_loss(self, org_img, shifted_img):
