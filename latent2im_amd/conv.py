@@ -47,8 +47,9 @@ def pack_weight(w):
 
 
 def pack_weight_bf16x3(w):
-    """[Cout, Cin, KH, KW] fp32 -> (hi, lo) bf16 planes laid out [Cin/16][KH*KW][CoutP][2][8] (as int16 tensors):
-    hi = bf16(w) (round to nearest even), lo = bf16(w - hi)."""
+    """[Cout, Cin, KH, KW] fp32 -> (hi, lo) bf16 planes laid out [Cin/16][KH*KW][2 (8-channel half)][CoutP][8] (as int16 tensors):
+    hi = bf16(w) (round to nearest even), lo = bf16(w - hi).  This is the LDS image order of csrc/l2i_conv16.hip: the rows of a
+    (16-channel group, tap, half) are CoutP consecutive 16-byte slots, so a block's slice goes global -> LDS by DMA."""
     w = torch.as_tensor(w, dtype=torch.float32)
     cout, cin, kh, kw = w.shape
     assert cin % 16 == 0
@@ -58,8 +59,8 @@ def pack_weight_bf16x3(w):
     hi = full.to(torch.bfloat16)
     lo = (full - hi.float()).to(torch.bfloat16)
 
-    def lay(t):          # [CoutP, Cin, KH, KW] -> [Cin/16, KH*KW, CoutP, 2, 8]
-        t = t.reshape(coutp, cin // 16, 2, 8, kh * kw).permute(1, 4, 0, 2, 3).contiguous()
+    def lay(t):          # [CoutP, Cin, KH, KW] -> [Cin/16, KH*KW, 2, CoutP, 8]
+        t = t.reshape(coutp, cin // 16, 2, 8, kh * kw).permute(1, 4, 2, 0, 3).contiguous()
         return t.view(torch.int16)
     return lay(hi), lay(lo)
 
@@ -92,7 +93,7 @@ class Launch:
         self.step, self.off_y, self.off_x = step, off_y, off_x
         self.w16 = None                                        # (hi, lo) planes, built on first bf16x3 use
         self.wino = None                                       # Winograd pack, built on first use
-        self.w_src = torch.as_tensor(w_oihw, dtype=torch.float32) if (stride == 1 and self.cin % 8 == 0 and self.kh <= 3 and self.kw <= 3) else None
+        self.w_src = torch.as_tensor(w_oihw, dtype=torch.float32) if (self.cin % 8 == 0 and self.kh <= 3 and self.kw <= 3) else None
 
     def bf16x3_planes(self):
         if self.w16 is None and self.w_src is not None:
@@ -281,12 +282,14 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
     if out_mask is not None:
         assert out_mask.shape == y.shape
     entry, name = lib.l2i_conv2d_f32, 'l2i_conv2d_f32'
-    if L.kh * L.kw > 1 and L.cout > 4:
-        _split_k(p, B * OH * OW, cin, y)
-    if PRECISION == 'bf16x3' and L.step == 1 and OW >= 32 and L.w_src is not None and L.cin % 16 == 0 and L.cout > 4 and L.kh * L.kw > 1:     # 1x1 layers are HBM-bound
+    if PRECISION == 'bf16x3' and tile_hint == 0 and _bf16x3_eligible(L, x, in_mask, OW):
         planes = L.bf16x3_planes()
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
         entry, name = lib.l2i_conv2d_bf16x3_f32, 'l2i_conv2d_bf16x3_f32'
+    elif L.kh * L.kw > 1 and L.cout > 4:
+        _split_k(p, B * OH * OW, cin, y)
+    if name != 'l2i_conv2d_f32':
+        pass
     elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
           and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise, res_sub)):
         p.w = _lib.fptr(L.wino_pack())
@@ -305,6 +308,16 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
                         name, family))
         return
     _lib.check(entry(p, _lib.stream_ptr()), name)
+
+
+def _bf16x3_eligible(L, x, in_mask, OW):
+    """Mirror of l2i_bf16x3_pipe_eligible (csrc/l2i_conv16.hip): 1x1 (pad 0) / 3x3 (pad 1; stride 2 also pad 0) layers with a dense output
+    window on maps >= 32 wide, whole 16-channel (1x1: 32-channel) groups, aligned 4-pixel row vectors.  <= 4 output channels stay on
+    the direct VALU kernel, everything else that is not eligible on the fp32 matrix kernels."""
+    k1 = L.kh == 1 and L.kw == 1 and L.pad_y == 0 and L.pad_x == 0
+    k3 = L.kh == 3 and L.kw == 3 and L.pad_y == L.pad_x and (L.pad_x == 1 or (L.pad_x == 0 and L.stride == 2))
+    return ((k1 or k3) and L.step == 1 and L.w_src is not None and L.cin % (32 if k1 else 16) == 0 and L.cout > 4 and OW >= 32
+            and x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and (in_mask is None or in_mask.data_ptr() % 16 == 0))
 
 
 def _wino_aligned(*tensors):

@@ -1,83 +1,212 @@
-// l2i_conv16.hip — stride-1 2-D correlation on the bf16 matrix cores with a 3-term operand split (gfx950).
+// l2i_conv16.hip — stride-1 / stride-2 1x1 and 3x3 correlations on the bf16 matrix cores with the 3-term operand split,
+// pipelined (gfx950).  Entry point l2i_conv2d_bf16x3_f32.
 //
-// OPT-IN path (conv.PRECISION = 'bf16x3'); the default everywhere is the exact-fp32 kernel of l2i_conv.hip.
-// Every fp32 operand x is split as x = hi + lo with hi = bf16(x), lo = bf16(x - hi); the product a*b is evaluated as
-// ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped al*bl term is <= 2^-18 |ab|, the
-// split itself is accurate to 2^-17 |x|): fp32-class results (far inside the path's rtol 1e-3 parity bar) at 3/16 of
-// the matrix-pipe time of v_mfma_f32_32x32x2_f32.  fp16 is not used: gradients of the path span ~1e-9..1e2 and would
-// flush; bf16 keeps fp32's exponent.
+// Arithmetic: every fp32 operand is x = hi + lo, hi = bf16(x), lo = bf16(x - hi); a*b = ah*bh + ah*bl + al*bh on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative product error <= ~2^-17: fp32-class results at 3/16 of the
+// matrix-pipe time of v_mfma_f32_32x32x2_f32).  fp32 tensors in HBM on both sides: the streaming kernels around the convs are
+// unchanged and the parity tests run on both matrix paths.
 //
-// Same implicit-GEMM mapping and epilogue as l2i_conv.hip (M = out-channels, N = 32-pixel row segments, accumulators in
-// the 32x32 C/D layout).  K runs over 16-channel groups: a lane's MFMA operand is 8 consecutive channels of one pixel /
-// one output channel, so the LDS images are channel-contiguous: input [pixel][2 x 8 ch] and weights [tap][cout][2 x 8 ch],
-// each as a hi plane and a lo plane; fragments are single ds_read_b128.  The fp32 -> (hi, lo) split of the activations
-// happens on the register -> LDS commit of the staging pipeline (with the style/demod scale and the activation-gradient
-// mask); weights are split once on the host.  Large maps only (OW >= 32, Cin % 16 == 0, stride 1); everything else
-// stays on the fp32 kernel.
+// What the first generation left on the table (254-352 TFLOP/s of the 833 the split allows): two barriers per chunk with
+// nothing in flight across them, 4-byte staging loads, weights through registers, 2-way conflicts on every fragment read.
+// This kernel:
+//   * K chunk = 16 channels (3x3) or 32 (1x1).  The fp32 halo tile of the NEXT chunk travels global -> registers as aligned
+//     16-byte row vectors (8 channels x 4 pixels per thread item: the 8 channels of a pixel are then lane-local, so the
+//     hi/lo split and the bf16x8 pack need no cross-lane traffic) while the current chunk is on the matrix cores, and is
+//     committed (activation-gradient mask, style scale, split) to the other LDS stage after them: ONE barrier per phase.
+//   * Weights are split and packed on the host in exactly the LDS image order ([Cin/16][tap][half][CoutP][8 bf16]) and go
+//     global -> LDS by DMA (buffer_load_dwordx4 ... lds), one kernel ROW (K taps) per phase, double buffered: no registers,
+//     no VALU, and a 3x3 layer keeps two blocks per CU (76 KiB of LDS each).
+//   * LDS images are [8-channel half][row][column] x 16 B: a fragment read is one ds_read_b128 at lane base + immediate,
+//     consecutive lanes on consecutive 16-byte slots (conflict free); stride-2 layers store even and odd columns in separate
+//     planes of the row so that their reads are unit-stride too.
+//   * Blocks are renumbered so that the channel blocks of one pixel tile run back to back on one XCD (the tile is fetched
+//     from HBM once, then from that XCD's L2).
+// Mapping as everywhere in this library: M = out-channels (A operand, weights), N = 32-pixel row segments (B operand),
+// 4 waves along N, accumulators in the 32x32 C/D layout (one register = 32 consecutive pixels of one channel).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "l2i.h"
 #include "l2i_internal.h"
+#include "l2i_epilogue.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-struct Conv16Launch {
-    int tiles_x, tiles_y, mblocks;
-    int IH, IW, nitems;                // staged pixels, items = pixels * 2 (8-channel halves)
-    unsigned magic_iw;
-    int w_vec;                         // uint4 per weight plane and chunk: KK*BM*2
-    int off_in_lo, off_w_hi, off_w_lo; // uint4 offsets of the planes inside LDS
+namespace s16 {
+// K x K window, stride S, WN 32-pixel rows per wave (TH = 4 WN output rows per block, 32 columns)
+template <int WN, int K, int S> struct Geo {
+    static constexpr int TH = 4 * WN;
+    static constexpr bool GATHER = (K == 1 && S == 2);                    // 1x1 stride 2: only even rows / columns are staged
+    static constexpr int ROWS = GATHER ? TH : (TH - 1) * S + K;           // staged input rows
+    static constexpr int RSTEP = GATHER ? 2 : 1;                          // global row step between staged rows
+    static constexpr int NV = (S == 1) ? (K == 1 ? 8 : 10) : (K == 1 ? 16 : 17);   // aligned 4-pixel vectors per staged row
+    static constexpr int RP = GATHER ? 32 : NV * 4;                       // 16-byte slots per staged row and 8-channel half
+    static constexpr int RPH = RP / 2;                                    // stride 2: odd columns start here
+    static constexpr int KS = (K == 1) ? 2 : 1;                           // 16-channel MFMA steps per chunk
+    static constexpr int NH = 2 * KS;                                     // 8-channel halves per chunk
+    static constexpr int CK = 16 * KS;
+    static constexpr int IN_SLOTS = NH * ROWS * RP;                       // slots per plane (hi or lo) per stage
+    static constexpr int NITEM = ROWS * NV;                               // (row, vector) items per half; a thread keeps one half
+    static constexpr int TPH = 256 / NH;                                  // threads per half
+    static constexpr int NS = (NITEM + TPH - 1) / TPH;                    // items per thread per chunk
+};
+}
+
+struct S16Launch {
+    int tiles_x, tiles_y, mblocks, total, nchunks;
+    int shift;                         // columns between the first staged column (aligned to 4) and the tile's first tap column
     int vec_epi;
 };
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+__device__ __forceinline__ unsigned cvt_pk_bf16_b(float lo, float hi) {
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
 
 // 8 fp32 -> 8 bf16 hi (round to nearest even) and 8 bf16 lo = bf16(x - hi)
-__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+__device__ __forceinline__ void split8b(const float (&v)[8], u32x4& hi, u32x4& lo) {
     unsigned h[4], l[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        h[q] = cvt_pk_bf16(v[2 * q], v[2 * q + 1]);
+        h[q] = cvt_pk_bf16_b(v[2 * q], v[2 * q + 1]);
         const float h0 = __uint_as_float(h[q] << 16), h1 = __uint_as_float(h[q] & 0xffff0000u);
-        l[q] = cvt_pk_bf16(v[2 * q] - h0, v[2 * q + 1] - h1);
+        l[q] = cvt_pk_bf16_b(v[2 * q] - h0, v[2 * q + 1] - h1);
     }
     hi = u32x4{h[0], h[1], h[2], h[3]};
     lo = u32x4{l[0], l[1], l[2], l[3]};
 }
 
-template <int WM, int WN, bool MASK>
-__global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const l2i_conv_params p, const Conv16Launch L) {
+template <int WM, int WN, int K, int S, bool MASK>
+__global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf16x3_pipe_kernel(const l2i_conv_params p, const S16Launch L) {
+    using G = s16::Geo<WN, K, S>;
     constexpr int BM = WM * 32;
-    constexpr int NS = (WN <= 2) ? 3 : 5;                 // input item slots per thread per chunk
-    constexpr int NWS = (BM == 64) ? 5 : 3;               // weight uint4 slots per thread per plane per chunk (3x3: KK*BM*2/256)
+    constexpr int WSLOTS = K * G::KS * 2 * BM;             // slots per weight plane per phase: K taps x KS steps x 2 halves x BM channels
+    constexpr int WPIECES = 2 * WSLOTS / 64;               // 1 KiB DMA pieces per phase, both planes
+    constexpr int WPW = (WPIECES + 3) / 4;                 // per wave
+    constexpr int IN_STAGE = 2 * G::IN_SLOTS, W_STAGE = 2 * WSLOTS;
+    constexpr int NLOADS = G::NS * 8 * (MASK ? 2 : 1);     // register loads issued AFTER the weight DMA of a phase
     extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
-    u32x4* in_hi = smem4;
-    u32x4* in_lo = smem4 + L.off_in_lo;
-    u32x4* w_hi = smem4 + L.off_w_hi;
-    u32x4* w_lo = smem4 + L.off_w_lo;
+    u32x4* const in_st = smem4;                            // 2 stages x [hi | lo] x [half][row][slot]
+    u32x4* const w_st = smem4 + 2 * IN_STAGE;              // 2 stages x [hi | lo] x [tap][step][half][channel]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
-    const int KK = p.KH * p.KW;
-    constexpr int TH = 4 * WN;
-    int bid = blockIdx.x;
-    const int mblk = bid % L.mblocks; bid /= L.mblocks;
-    const int tx = bid % L.tiles_x; bid /= L.tiles_x;
-    const int ty = bid % L.tiles_y; bid /= L.tiles_y;
-    const int b = bid;
-    const int m0 = mblk * BM;
-    const int oy0 = ty * TH, ox0 = tx * 32;
-    const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
-    int pixbase[WN];                                       // staged-pixel index of this lane's pixel, tap (0,0)
+    // blocks are dealt round-robin to the 8 XCDs: renumber so that the channel blocks of a pixel tile share an XCD (and its L2)
+    int w = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (w >= L.total) return;
+    const int mblk = w % L.mblocks; w /= L.mblocks;
+    const int tx = w % L.tiles_x; w /= L.tiles_x;
+    const int ty = w % L.tiles_y; w /= L.tiles_y;
+    const int b = w, m0 = mblk * BM, oy0 = ty * G::TH, ox0 = tx * 32;
+    const int iy0 = oy0 * S - p.pad_y;
+    const int xs = ox0 * S - p.pad_x - L.shift;            // first staged column: multiple of 4 (may be negative)
+
+    // ---- descriptors ----
+    const size_t plane_x = (size_t)p.H * p.W;
+    const unsigned plane_b = (unsigned)(plane_x * sizeof(float));
+    const unsigned in_bytes = (unsigned)p.Cin * plane_b;
+    const size_t smp = (size_t)b * p.Cin * plane_x;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + smp), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)((MASK ? p.in_mask : p.x) + smp), 0, in_bytes, 0x00020000);
+    const unsigned wpl_bytes = (unsigned)((size_t)(p.Cin / 16) * K * K * 2 * p.CoutP * 16);
+    const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, wpl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, wpl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)((p.in_scale ? p.in_scale : p.x) + (size_t)b * p.Cin), 0,
+                                                                            p.in_scale ? (unsigned)(p.Cin * sizeof(float)) : 0u, 0x00020000);
+
+    // ---- input staging: a thread owns one 8-channel half and NS (row, 4-pixel vector) items of the tile ----
+    const int nh = tid % G::NH, tq = tid / G::NH;
+    unsigned voff[G::NS];
+    int lslot[G::NS];
 #pragma unroll
-    for (int n = 0; n < WN; ++n) pixbase[n] = (wave * WN + n) * L.IW + j;
+    for (int u = 0; u < G::NS; ++u) {
+        const int it = tq + u * G::TPH;
+        voff[u] = in_bytes;
+        lslot[u] = -1;
+        if (it < G::NITEM) {
+            const int row = it / G::NV, v = it - row * G::NV;
+            const int gy = iy0 + row * G::RSTEP, gx = xs + 4 * v;
+            lslot[u] = (nh * G::ROWS + row) * G::RP + (G::GATHER ? 2 * v : (S == 2 ? 2 * v : 4 * v));
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)        // W % 4 == 0: a vector is inside the row or outside it, never across
+                voff[u] = (unsigned)nh * 8u * plane_b + (unsigned)(gy * p.W + gx) * 4u;
+        }
+    }
+    u32x4 xin[G::NS][8];
+    u32x4 xmk[MASK ? G::NS : 1][MASK ? 8 : 1];
+    float scl[8];
+
+    // weight DMA pieces of this wave: piece q = wave + 4 t covers LDS slots [64 q, 64 q + 64) of the phase ([plane][tap][step][half][channel])
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int t = 0; t < WPW; ++t) {
+        const int q = wave + 4 * t;
+        const int sl = (q * 64 + lane) % WSLOTS;                           // slot inside the plane
+        const int r = sl / BM, i = sl - r * BM;                            // r = (tap * KS + step) * 2 + half
+        const int hf = r & 1, st = (r >> 1) % G::KS, tap = (r >> 1) / G::KS;
+        wvoff[t] = (unsigned)((((st * K * K + tap) * 2 + hf) * p.CoutP + m0 + i) * 16);
+    }
+
+    auto dma_w = [&](int chunk, int ky, int stage) {
+        const unsigned soff = (unsigned)((((size_t)chunk * G::KS * K * K + ky * K) * 2) * p.CoutP * 16);
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(w_st + stage * W_STAGE);
+#pragma unroll
+        for (int t = 0; t < WPW; ++t) {
+            const int q = wave_u + 4 * t;                  // wave-uniform: a scalar branch (a DMA through a null descriptor would WRITE zeros)
+            if (q < WPIECES) {
+                const bool lo = q >= WPIECES / 2;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(wvoff[t]), "s"(lo ? rs_wl : rs_wh), "s"(__builtin_amdgcn_readfirstlane(lds0 + q * 1024)), "s"(soff)
+                             : "memory");
+            }
+        }
+    };
+    auto issue_scales = [&](int c0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            scl[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, (unsigned)((nh * 8 + e) * sizeof(float)), (unsigned)(c0 * sizeof(float)), 0));
+    };
+    auto issue_loads = [&](int c0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned so = (unsigned)(c0 + e) * plane_b;
+#pragma unroll
+            for (int u = 0; u < G::NS; ++u) {
+                xin[u][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff[u], so, 0);
+                if constexpr (MASK) xmk[u][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, voff[u], so, 0);
+            }
+        }
+    };
+    auto commit = [&](int stage) {
+        u32x4* ih = in_st + stage * IN_STAGE;
+        u32x4* il = ih + G::IN_SLOTS;
+#pragma unroll
+        for (int u = 0; u < G::NS; ++u) {
+            if (lslot[u] >= 0) {
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    if (G::GATHER && (px & 1)) continue;                   // 1x1 stride 2 reads even columns only
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = __uint_as_float(xin[u][e][px]);
+                        if constexpr (MASK) t *= (__uint_as_float(xmk[u][e][px]) > 0.f) ? p.mask_pos : p.mask_neg;
+                        if (p.in_scale) t *= scl[e];
+                        v[e] = t;
+                    }
+                    u32x4 hi, lo;
+                    split8b(v, hi, lo);
+                    const int s = lslot[u] + ((S == 2) ? ((G::GATHER ? 0 : (px & 1) * G::RPH) + (px >> 1)) : px);
+                    ih[s] = hi;
+                    il[s] = lo;
+                }
+            }
+        }
+    };
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -87,112 +216,40 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const l2i_conv_para
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    // ---- staging state: thread = (pixel, 8-channel half) items; the 8 channels of an item share one VGPR offset and
-    //      differ by an SGPR offset, so issuing a chunk costs no VALU at all ----
-    const size_t plane_x = (size_t)p.H * p.W;
-    const unsigned in_bytes = (unsigned)((size_t)p.Cin * plane_x * sizeof(float));
-    const size_t smp_off = (size_t)b * p.Cin * plane_x;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + smp_off), 0, in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)((MASK ? p.in_mask : p.x) + smp_off), 0, in_bytes, 0x00020000);
-    const unsigned wpl_bytes = (unsigned)((size_t)(p.Cin / 16) * KK * p.CoutP * 32);           // one weight plane
-    const __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, wpl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_lo, 0, wpl_bytes, 0x00020000);
-    const unsigned sc_bytes = (unsigned)((size_t)p.Cin * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((p.in_scale ? p.in_scale : p.x) + (size_t)b * p.Cin), 0, p.in_scale ? sc_bytes : 0u, 0x00020000);
-
-    const int kg = tid & 1;                                // this thread always stages the same 8-channel half
-    unsigned voff[NS];
-    float xin[NS][8];
-    float xmk[MASK ? NS : 1][MASK ? 8 : 1];
-    float scl[8];
-    u32x4 rwh[NWS], rwl[NWS];
+    // fragment bases (in slots): lane (half, j); everything else is a compile-time or wave-uniform offset
+    const int rstep_out = G::GATHER ? 1 : S;               // staged rows between consecutive output rows
+    const int bbase = (half * G::ROWS + wave * WN * rstep_out) * G::RP + j;
+    int coloff[K];                                         // slot offset of tap column kx for output pixel 0
 #pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        const int it = tid + u * 256;
-        voff[u] = in_bytes;
-        if (it < L.nitems) {
-            const unsigned pix = (unsigned)it >> 1;
-            const unsigned iy = __umulhi(pix, L.magic_iw), ix = pix - iy * L.IW;
-            const int gy = iy0 + (int)iy, gx = ix0 + (int)ix;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                voff[u] = (unsigned)(((size_t)(kg * 8) * plane_x + (size_t)gy * p.W + gx) * sizeof(float));
-        }
+    for (int kx = 0; kx < K; ++kx) {
+        const int c = kx + L.shift;
+        coloff[kx] = G::GATHER ? 0 : (S == 2 ? (c & 1) * G::RPH + (c >> 1) : c);
     }
-    // weights: plane layout [chunk][tap][CoutP][2] uint4; the block's rows (tap, m0..m0+BM) are 2*BM consecutive uint4
-    const int wrow = tid / (2 * BM), wcol = tid - wrow * (2 * BM);            // tap row / uint4 inside the row for slot 0
-    constexpr int ROWS_PER_SLOT = 256 / (2 * BM);                             // BM=64: 2 taps per slot, BM=32: 4
-    const unsigned wvoff = (unsigned)((((size_t)wrow * p.CoutP + m0) * 2 + wcol) * 16);
-    const unsigned wstep = (unsigned)((size_t)ROWS_PER_SLOT * p.CoutP * 32);
-    const unsigned wchunk = (unsigned)((size_t)KK * p.CoutP * 32);
+    const int abase = half * BM + j;
 
-    auto issue = [&](int c0) {
+    auto mfma_phase = [&](int in_stage, int w_stage, int ky) {
+        const u32x4* ih = in_st + in_stage * IN_STAGE + bbase + (G::GATHER ? 0 : ky) * G::RP;
+        const u32x4* il = ih + G::IN_SLOTS;
+        const u32x4* wh = w_st + w_stage * W_STAGE + abase;
+        const u32x4* wl = wh + WSLOTS;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const unsigned so = (unsigned)((size_t)(c0 + e) * plane_x * sizeof(float));
+        for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                xin[u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, voff[u], so, 0));
-                if constexpr (MASK) xmk[u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_m, voff[u], so, 0));
-            }
-            scl[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, (unsigned)((kg * 8 + e) * sizeof(float)), (unsigned)(c0 * sizeof(float)), 0));
-        }
-        const unsigned sw = (unsigned)(c0 / 16) * wchunk;
-#pragma unroll
-        for (int u = 0; u < NWS; ++u) {
-            rwh[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_wh, wvoff, sw + u * wstep, 0);
-            rwl[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_wl, wvoff, sw + u * wstep, 0);
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            const int it = tid + u * 256;
-            if (it < L.nitems) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t = xin[u][e];
-                    if constexpr (MASK) t *= (xmk[u][e] > 0.f) ? p.mask_pos : p.mask_neg;
-                    if (p.in_scale) t *= scl[e];
-                    v[e] = t;
-                }
-                u32x4 hi, lo;
-                split8(v, hi, lo);
-                in_hi[it] = hi;
-                in_lo[it] = lo;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NWS; ++u) {
-            const int idx = tid + u * 256;
-            if (idx < L.w_vec) { w_hi[idx] = rwh[u]; w_lo[idx] = rwl[u]; }
-        }
-    };
-
-    issue(0);
-    for (int c0 = 0; c0 < p.Cin; c0 += 16) {
-        commit();
-        __syncthreads();
-        if (c0 + 16 < p.Cin) issue(c0 + 16);
-        for (int ky = 0; ky < p.KH; ++ky) {
-            for (int kx = 0; kx < p.KW; ++kx) {
-                const int tap = ky * p.KW + kx;
+            for (int ks = 0; ks < G::KS; ++ks) {
                 bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
                 for (int m = 0; m < WM; ++m) {
-                    const int idx = ((tap * BM + m * 32 + j) << 1) + half;
-                    ah[m] = __builtin_bit_cast(bf16x8, w_hi[idx]);
-                    al[m] = __builtin_bit_cast(bf16x8, w_lo[idx]);
+                    const int idx = ((kx * G::KS + ks) * 2) * BM + m * 32;
+                    ah[m] = __builtin_bit_cast(bf16x8, wh[idx]);
+                    al[m] = __builtin_bit_cast(bf16x8, wl[idx]);
                 }
-                const int toff = ky * L.IW + kx;
 #pragma unroll
                 for (int n = 0; n < WN; ++n) {
-                    const int idx = ((pixbase[n] + toff) << 1) + half;
-                    bh[n] = __builtin_bit_cast(bf16x8, in_hi[idx]);
-                    bl[n] = __builtin_bit_cast(bf16x8, in_lo[idx]);
+                    const int idx = (ks * 2 * G::ROWS + n * rstep_out) * G::RP + coloff[kx];
+                    bh[n] = __builtin_bit_cast(bf16x8, ih[idx]);
+                    bl[n] = __builtin_bit_cast(bf16x8, il[idx]);
                 }
-                // three passes over the WM x WN tiles so that dependent accumulations are WM*WN MFMAs apart
+                // three passes over the WM x WN tiles: dependent accumulations are WM*WN MFMAs apart
 #pragma unroll
                 for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -207,176 +264,98 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const l2i_conv_para
                     for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
             }
         }
-        __syncthreads();
-    }
+    };
 
-    // ---- epilogue (same fusions as l2i_conv.hip): per-wave LDS transpose -> 16-byte global accesses, or scalar ----
-    const size_t plane_o = (size_t)p.OHf * p.OWf;
-    float* smemf = reinterpret_cast<float*>(smem4);
-    if (L.vec_epi) {
-        float* reg = smemf + wave * (32 * 64);
-        const int ch_l = lane >> 4;
-        const int px = (lane & 15) * 4;
-#pragma unroll
-        for (int n0 = 0; n0 < WN; n0 += 2) {
-            const int nn = px >> 5;
-            const int oy = oy0 + wave * WN + n0 + nn;
-            const int ox = ox0 + (px & 31);
-            const bool pok = (n0 + nn < WN) && (oy < p.OH) && (ox < p.OW);
-            const size_t poff = (size_t)(oy + p.oy_off) * p.OWf + ox + p.ox_off;
-            float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pok && p.noise) {
-                nz = *reinterpret_cast<const float4*>(p.noise + (size_t)b * plane_o + poff);
-                nz.x *= p.noise_w; nz.y *= p.noise_w; nz.z *= p.noise_w; nz.w *= p.noise_w;
-            }
-            const float* osc = (pok && p.out_scale) ? p.out_scale + (size_t)b * p.Cout : nullptr;
-#pragma unroll
-            for (int m = 0; m < WM; ++m) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (n0 + q < WN) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            reg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + q * 32 + j] = acc[m][(n0 + q) < WN ? (n0 + q) : 0][r];
-                    }
-                }
-#pragma unroll 2
-                for (int i = 0; i < 8; ++i) {
-                    const int ch = i * 4 + ch_l;
-                    const int co = m0 + m * 32 + ch;
-                    const float4 t = *reinterpret_cast<const float4*>(&reg[ch * 64 + px]);
-                    if (pok && co < p.Cout) {
-                        float4 v = t;
-                        if (osc) { const float sc = osc[co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
-                        const size_t oidx = ((size_t)b * p.Cout + co) * plane_o + poff;
-                        if (p.out_mask) {
-                            const float4 mk = *reinterpret_cast<const float4*>(p.out_mask + oidx);
-                            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-                        }
-                        v.x += nz.x; v.y += nz.y; v.z += nz.z; v.w += nz.w;
-                        if (p.bias) { const float bv = p.bias[co]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
-                        if (p.residual) {
-                            float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
-                            if (p.res_sub) {                                   // residual term = res_coef * (residual - res_sub)
-                                const float4 sb = *reinterpret_cast<const float4*>(p.res_sub + oidx);
-                                const float rc = p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f);
-                                rv.x = rc * (rv.x - sb.x); rv.y = rc * (rv.y - sb.y); rv.z = rc * (rv.z - sb.z); rv.w = rc * (rv.w - sb.w);
-                            }
-                            if (p.res_mask) {
-                                const float4 mk = *reinterpret_cast<const float4*>(p.res_mask + oidx);
-                                rv.x = mk.x > 0.f ? rv.x : 0.f; rv.y = mk.y > 0.f ? rv.y : 0.f; rv.z = mk.z > 0.f ? rv.z : 0.f; rv.w = mk.w > 0.f ? rv.w : 0.f;
-                            }
-                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                        }
-                        if (p.act == L2I_ACT_LRELU) {
-                            v.x = (v.x > 0.f ? v.x : v.x * p.act_slope) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.act_slope) * p.act_gain;
-                            v.z = (v.z > 0.f ? v.z : v.z * p.act_slope) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.act_slope) * p.act_gain;
-                        } else if (p.act == L2I_ACT_RELU) {
-                            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-                        }
-                        v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain;
-                        if (p.accumulate) {
-                            const float4 o = *reinterpret_cast<const float4*>(p.y + oidx);
-                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                        }
-                        *reinterpret_cast<float4*>(p.y + oidx) = v;
-                    }
-                }
-            }
+    // ---- pipeline: phase = (chunk, kernel row).  Per phase: wait for this phase's weights, ONE barrier, start the next phase's
+    //      weight DMA (and, in the first phase of a chunk, the next chunk's tile loads), MFMAs.  The next chunk's tile is committed
+    //      to the other input stage after the chunk's last phase. ----
+    const int nphases = L.nchunks * K;
+    issue_scales(0);
+    dma_w(0, 0, 0);
+    issue_loads(0);
+    commit(0);
+    for (int ch = 0; ch < L.nchunks; ++ch) {
+        const bool more = ch + 1 < L.nchunks;
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            const int ph = ch * K + ky;
+            // the DMA of this phase's weights has landed; register loads issued after it (first phase of a chunk, K > 1) stay in flight
+            if (K > 1 && ky == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ky == 0 && more) issue_scales((ch + 1) * G::CK);
+            if (ph + 1 < nphases) dma_w(ky + 1 < K ? ch : ch + 1, ky + 1 < K ? ky + 1 : 0, (ph + 1) & 1);
+            if (ky == 0 && more) issue_loads((ch + 1) * G::CK);
+            mfma_phase(ch & 1, ph & 1, ky);
         }
-        return;
+        if (more) commit((ch + 1) & 1);
     }
-#pragma unroll
-    for (int n = 0; n < WN; ++n) {
-        const int oy = oy0 + wave * WN + n, ox = ox0 + j;
-        const bool pok = (oy < p.OH) && (ox < p.OW);
-        const size_t poff = (size_t)(oy * p.oy_step + p.oy_off) * p.OWf + ox * p.ox_step + p.ox_off;
-        float nz = 0.f;
-        if (pok && p.noise) nz = p.noise[(size_t)b * plane_o + poff] * p.noise_w;
-        const int co_lane = m0 + 4 * half;
-        const size_t lane_base = ((size_t)b * p.Cout + co_lane) * plane_o + poff;
-        const float* osc = p.out_scale ? p.out_scale + (size_t)b * p.Cout : nullptr;
-#pragma unroll
-        for (int m = 0; m < WM; ++m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cofs = m * 32 + (r & 3) + 8 * (r >> 2);
-                const int co = co_lane + cofs;
-                if (pok && co < p.Cout) {
-                    float v = acc[m][n][r];
-                    if (osc) v *= osc[co];
-                    const size_t oidx = lane_base + (size_t)cofs * plane_o;
-                    if (p.out_mask) v = (p.out_mask[oidx] > 0.f) ? v : 0.f;
-                    v += nz;
-                    if (p.bias) v += p.bias[co];
-                    if (p.residual) {
-                        float rv = p.residual[oidx];
-                        if (p.res_sub) rv = p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) * (rv - p.res_sub[oidx]);
-                        if (p.res_mask) rv = (p.res_mask[oidx] > 0.f) ? rv : 0.f;
-                        v += rv;
-                    }
-                    if (p.act == L2I_ACT_LRELU) v = (v > 0.f ? v : v * p.act_slope) * p.act_gain;
-                    else if (p.act == L2I_ACT_RELU) v = v > 0.f ? v : 0.f;
-                    v *= p.out_gain;
-                    if (p.accumulate) v += p.y[oidx];
-                    p.y[oidx] = v;
-                }
-            }
-        }
-    }
+    __syncthreads();                                       // the stages become the epilogue's transpose strips
+
+    l2i_epilogue_32x32<WM, WN>(p, acc, reinterpret_cast<float*>(smem4), b, m0, oy0, ox0, L.vec_epi != 0);
 }
 
-static unsigned magic16(unsigned d) { return d == 1 ? 0u : (unsigned)((0x100000000ULL + d - 1) / d); }
-
-template <int WM, int WN>
-static int launch16(const l2i_conv_params& p, hipStream_t st) {
-    constexpr int BM = WM * 32, TH = 4 * WN;
-    constexpr int NS = (WN <= 2) ? 3 : 5, NWS = (BM == 64) ? 5 : 3;
-    const int KK = p.KH * p.KW;
-    Conv16Launch L;
+// ------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int K, int S>
+static int launch_pipe(const l2i_conv_params& p, hipStream_t st) {
+    using G = s16::Geo<WN, K, S>;
+    constexpr int BM = WM * 32;
+    constexpr int WSLOTS = K * G::KS * 2 * BM;
+    S16Launch L;
     L.tiles_x = (p.OW + 31) / 32;
-    L.tiles_y = (p.OH + TH - 1) / TH;
+    L.tiles_y = (p.OH + G::TH - 1) / G::TH;
     L.mblocks = (p.CoutP + BM - 1) / BM;
-    L.IH = TH + p.KH - 1;
-    L.IW = 32 + p.KW - 1;
-    L.nitems = L.IH * L.IW * 2;
-    L.magic_iw = magic16((unsigned)L.IW);
-    L.w_vec = KK * BM * 2;
-    if (L.nitems > NS * 256 || L.w_vec > NWS * 256 || L.IW < 2) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_bf16x3: tile does not fit the staging slots");
-    L.off_in_lo = L.nitems;
-    L.off_w_hi = 2 * L.nitems;
-    L.off_w_lo = 2 * L.nitems + L.w_vec;
-    size_t lds = (size_t)(2 * L.nitems + 2 * L.w_vec) * 16;
-    auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
-    L.vec_epi = (p.ox_step == 1 && p.oy_step == 1 && (p.OWf % 4) == 0 && (p.OW % 4) == 0 && (p.ox_off % 4) == 0 &&
-                 al16(p.y) && al16(p.residual) && al16(p.res_mask) && al16(p.res_sub) && al16(p.out_mask) && al16(p.noise)) ? 1 : 0;
-    if (L.vec_epi && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
-    if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            done = true;
-        }
+    const long total = (long)p.B * L.tiles_y * L.tiles_x * L.mblocks;
+    if (total <= 0 || total > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: grid too large");
+    L.total = (int)total;
+    L.nchunks = p.Cin / G::CK;
+    L.shift = (4 - (p.pad_x & 3)) & 3;                      // ox0 * S is a multiple of 4
+    L.vec_epi = l2i_epilogue_vec_ok(p) ? 1 : 0;
+    size_t lds = (size_t)(2 * 2 * G::IN_SLOTS + 2 * 2 * WSLOTS) * 16;
+    if (lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
+    if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_bf16x3: tile does not fit the LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_pipe_kernel<WM, WN, K, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_pipe_kernel<WM, WN, K, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
     }
-    const long grid = (long)p.B * L.tiles_y * L.tiles_x * L.mblocks;
-    if (grid <= 0 || grid > 0x7fffffffL) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: grid too large");
-    if (p.in_mask) hipLaunchKernelGGL((conv_bf16x3_kernel<WM, WN, true>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
-    else hipLaunchKernelGGL((conv_bf16x3_kernel<WM, WN, false>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
+    const unsigned grid = (unsigned)((total + 7) & ~7L);
+    if (p.in_mask) hipLaunchKernelGGL((conv_bf16x3_pipe_kernel<WM, WN, K, S, true>), dim3(grid), dim3(256), lds, st, p, L);
+    else hipLaunchKernelGGL((conv_bf16x3_pipe_kernel<WM, WN, K, S, false>), dim3(grid), dim3(256), lds, st, p, L);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
+}
+
+static bool l2i_bf16x3_pipe_eligible(const l2i_conv_params& p) {
+    auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
+    const bool k1 = (p.KH == 1 && p.KW == 1 && p.pad_y == 0 && p.pad_x == 0);
+    const bool k3 = (p.KH == 3 && p.KW == 3 && p.pad_y == p.pad_x && (p.pad_x == 1 || (p.pad_x == 0 && p.stride == 2)));
+    return (k1 || k3) && (p.stride == 1 || p.stride == 2) && p.oy_step == 1 && p.ox_step == 1 && (p.Cin % (k1 ? 32 : 16)) == 0 && p.OW >= 32 &&
+           (p.W % 4) == 0 && al16(p.x) && al16(p.in_mask) && p.w_hi && p.w_lo && al16(p.w_hi) && al16(p.w_lo) && p.ksplit <= 1 &&
+           (size_t)p.Cin * p.H * p.W * sizeof(float) < 0xFFFFFFF0ull && (size_t)(p.Cin / 16) * p.KH * p.KW * 2 * p.CoutP * 16 < 0xFFFFFFF0ull;
+}
+
+static int l2i_launch_bf16x3_pipe(const l2i_conv_params& p, hipStream_t st) {
+    const bool wide = (p.CoutP % 64) == 0;
+    if (p.KH == 3 && p.stride == 1) return wide ? launch_pipe<2, 2, 3, 1>(p, st) : launch_pipe<1, 2, 3, 1>(p, st);
+    if (p.KH == 1 && p.stride == 1) return wide ? launch_pipe<2, 2, 1, 1>(p, st) : launch_pipe<1, 2, 1, 1>(p, st);
+    if (p.KH == 3 && p.stride == 2) return wide ? launch_pipe<2, 1, 3, 2>(p, st) : launch_pipe<1, 1, 3, 2>(p, st);
+    return wide ? launch_pipe<2, 2, 1, 2>(p, st) : launch_pipe<1, 2, 1, 2>(p, st);
 }
 
 extern "C" int l2i_conv2d_bf16x3_f32(const l2i_conv_params* pp, void* stream) {
     if (!pp) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: null params");
     const l2i_conv_params& p = *pp;
     if (!p.x || !p.w_hi || !p.w_lo || !p.y) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: null tensor");
-    if (p.stride != 1 || (p.Cin % 16) != 0 || p.OW < 32 || p.KH < 1 || p.KW < 1 || p.KH > 3 || p.KW > 3)
-        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_bf16x3: needs stride 1, Cin % 16 == 0, OW >= 32, kernel <= 3x3");
+    if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0)
+        return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: non-positive dimension");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: CoutP must be Cout rounded up to 32");
-    if ((size_t)p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_bf16x3: sample >= 4 GiB");
-    if ((((uintptr_t)p.w_hi) | ((uintptr_t)p.w_lo)) % 16) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: weight planes must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    if (p.CoutP % 64 == 0) return launch16<2, 2>(p, st);
-    return launch16<1, 2>(p, st);
+    if (p.res_sub && !p.residual) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: res_sub needs residual");
+    if (p.oy_off < 0 || p.ox_off < 0 || p.OH + p.oy_off > p.OHf || p.OW + p.ox_off > p.OWf)
+        return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: output window exceeds the output tensor");
+    if (!l2i_bf16x3_pipe_eligible(p))
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_bf16x3: needs a 1x1 (pad 0) or 3x3 (pad 1; stride 2 also pad 0) layer, stride 1 or 2, dense output, "
+                                                "Cin % 16 == 0 (1x1: % 32), OW >= 32, W % 4 == 0, 16-byte aligned tensors");
+    return l2i_launch_bf16x3_pipe(p, (hipStream_t)stream);
 }

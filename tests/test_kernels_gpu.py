@@ -124,38 +124,52 @@ def test_fused_transposed_conv_matches_per_parity_launches(cin, cout, k, pad, tr
             close(yh, ref, 1e-4, 2e-5)
 
 
-@pytest.mark.parametrize('cin,cout,k,h,w,b', [(64, 64, 3, 64, 64, 2), (32, 32, 3, 40, 96, 1), (128, 96, 1, 32, 64, 2), (16, 40, 3, 33, 37, 1),
-                                              (512, 512, 3, 32, 32, 1)])
-def test_bf16x3_split_precision_conv(cin, cout, k, h, w, b):
-    """Opt-in bf16 MFMA path with the 3-term operand split: fp32-class accuracy (products exact to ~2^-17), same fused
-    prologue / epilogue semantics, forward and input-gradient."""
-    rs = np.random.RandomState(cin + cout + h)
+BF16X3_CASES = [  # cin, cout, k, stride, pad, h, w, batch
+    (64, 64, 3, 1, 1, 64, 64, 2), (32, 32, 3, 1, 1, 40, 96, 1), (16, 40, 3, 1, 1, 36, 36, 1), (512, 512, 3, 1, 1, 32, 32, 1), (48, 100, 3, 1, 1, 33, 64, 2),
+    (128, 96, 1, 1, 0, 32, 64, 2), (64, 256, 1, 1, 0, 64, 64, 1), (256, 64, 1, 1, 0, 37, 40, 2),
+    (64, 64, 3, 2, 1, 64, 64, 2), (32, 48, 3, 2, 1, 66, 128, 1), (128, 128, 3, 2, 0, 65, 68, 1), (32, 64, 3, 2, 0, 129, 132, 2),
+    (64, 128, 1, 2, 0, 64, 64, 2), (256, 512, 1, 2, 0, 66, 72, 1),
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,h,w,b', BF16X3_CASES)
+def test_bf16x3_split_precision_conv(cin, cout, k, stride, pad, h, w, b):
+    """The bf16 MFMA path with the 3-term operand split (csrc/l2i_conv16.hip: pipelined 1x1 / 3x3, stride 1 / 2): fp32-class accuracy
+    (products exact to ~2^-17) against a float64 reference, same fused prologue / epilogue semantics as the fp32 kernels, partial tiles,
+    channel counts that are not multiples of the block, and the input-gradient of the stride-1 layers (same kernel, flipped pack)."""
+    rs = np.random.RandomState(cin + cout + h + k + stride)
     wt = T(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
     x, s, d = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cin) + 0.5), T(rs.rand(b, cout) + 0.5)
     bias, msk = T(rs.randn(cout)), T(rs.randn(b, cin, h, w))
     g = lambda t: t.to(DEV)
-    fc = conv.FrozenConv2d(wt, 1, k // 2, device=DEV)
+    fc = conv.FrozenConv2d(wt, stride, pad, device=DEV)
+    oh, ow = fc.out_hw(h, w)
+    nz, res, rmask = T(rs.randn(b, 1, oh, ow)), T(rs.randn(b, cout, oh, ow)), T(rs.randn(b, cout, oh, ow))
     xd = x.double()
-    ref = F.leaky_relu(F.conv2d(xd * s.double()[:, :, None, None], wt.double(), padding=k // 2) * d.double()[:, :, None, None]
-                       + bias.double()[None, :, None, None], 0.2) * 2 ** 0.5
+    cv = lambda t: F.conv2d(t, wt.double(), stride=stride, padding=pad)
+    ref = F.leaky_relu(cv(xd * s.double()[:, :, None, None]) * d.double()[:, :, None, None] + 0.3 * nz.double() + bias.double()[None, :, None, None], 0.2) * 2 ** 0.5
     xm = xd * torch.where(msk > 0, torch.tensor(1.0, dtype=torch.float64), torch.tensor(0.2, dtype=torch.float64))
-    ref2 = F.conv2d(xm, wt.double(), padding=k // 2)
-    gy = T(rs.randn(b, cout, h, w))
-    xr = xd.clone().requires_grad_(True)
-    gref, = torch.autograd.grad(F.conv2d(xr, wt.double(), padding=k // 2), xr, gy.double())
-    conv.PRECISION = 'bf16x3'
+    ref2 = torch.relu(cv(xm) + bias.double()[None, :, None, None] + res.double() * (rmask > 0)) * 0.5
+    launched = []
+    conv.PRECISION, conv.PROFILE = 'bf16x3', launched
     try:
-        y = fc.forward(g(x), in_scale=g(s), out_scale=g(d), bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
-        y2 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.2))
-        gx = fc.dgrad(g(gy), (h, w))
+        y = fc.forward(g(x), in_scale=g(s), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+        y2 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.2), bias=g(bias), residual=g(res), res_mask=g(rmask), act=conv.ACT_RELU, out_gain=0.5)
+        y0 = g(res).clone()
+        fc.forward(g(x), out=y0, accumulate=True)
+        if stride == 1:
+            gy = T(rs.randn(b, cout, oh, ow))
+            xr = xd.clone().requires_grad_(True)
+            gref, = torch.autograd.grad(cv(xr), xr, gy.double())
+            gx = fc.dgrad(g(gy), (h, w))
     finally:
-        conv.PRECISION = 'f32'
-    y32 = fc.forward(g(x), in_scale=g(s), out_scale=g(d), bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
-    for got, want in ((y, ref), (y2, ref2), (gx, gref)):
+        conv.PRECISION, conv.PROFILE = 'f32', None
+    torch.cuda.synchronize()
+    assert launched and all(q[4] == 'l2i_conv2d_bf16x3_f32' for q in launched), [q[4] for q in launched]     # the split kernel ran, not a fallback
+    checks = [(y, ref), (y2, ref2), (y0, res.double() + cv(xd))] + ([(gx, gref)] if stride == 1 else [])
+    for got, want in checks:
         err = float((got.double().cpu() - want).abs().max() / want.abs().max())
         assert err < 2e-5, err
-    e32 = float((y32.double().cpu() - ref).abs().max() / ref.abs().max())
-    assert e32 < 5e-6, e32                     # the exact-fp32 kernel, for scale
 
 
 @pytest.mark.parametrize('cin,cout,h,w,b', [(64, 64, 64, 64, 2), (32, 32, 40, 96, 1), (128, 96, 32, 64, 2), (16, 40, 36, 36, 1),
