@@ -97,10 +97,12 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
     // blocks are dealt round-robin to the 8 XCDs: renumber so that the channel blocks of a pixel tile share an XCD (and its L2)
     int w = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     if (w >= L.total) return;
-    const int mblk = w % L.mblocks; w /= L.mblocks;
-    const int tx = w % L.tiles_x; w /= L.tiles_x;
-    const int ty = w % L.tiles_y; w /= L.tiles_y;
-    const int b = w, m0 = mblk * BM, oy0 = ty * G::TH, ox0 = tx * 32;
+    // (the divisions run on the VALU: readfirstlane makes the block coordinates provably wave-uniform again, otherwise every buffer
+    // descriptor built from them is wrapped in a waterfall loop with a vmcnt(0) inside)
+    const int mblk = __builtin_amdgcn_readfirstlane(w % L.mblocks); w /= L.mblocks;
+    const int tx = __builtin_amdgcn_readfirstlane(w % L.tiles_x); w /= L.tiles_x;
+    const int ty = __builtin_amdgcn_readfirstlane(w % L.tiles_y); w /= L.tiles_y;
+    const int b = __builtin_amdgcn_readfirstlane(w), m0 = mblk * BM, oy0 = ty * G::TH, ox0 = tx * 32;
     const int iy0 = oy0 * S - p.pad_y;
     const int xs = ox0 * S - p.pad_x - L.shift;            // first staged column: multiple of 4 (may be negative)
 

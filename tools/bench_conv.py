@@ -38,6 +38,16 @@ SHAPES = [  # name, cin, cout, k, stride, pad, transposed, res, batch
     ('r_1024_256', 1024, 256, 1, 1, 0, False, 64, 8),
     ('r_2048_512', 2048, 512, 1, 1, 0, False, 32, 8),
     ('r_512_128', 512, 128, 1, 1, 0, False, 128, 8),
+    ('r_64_256', 64, 256, 1, 1, 0, False, 256, 8),
+    ('r_3x3s2_128', 128, 128, 3, 2, 1, False, 256, 8),
+    ('r_3x3s2_256', 256, 256, 3, 2, 1, False, 128, 8),
+    ('d_3x3s2_64', 64, 128, 3, 2, 0, False, 513, 8),
+    ('d_3x3s2_256', 256, 512, 3, 2, 0, False, 129, 8),
+    ('r_1x1s2_256', 256, 512, 1, 2, 0, False, 256, 8),
+    ('v_128', 128, 128, 3, 1, 1, False, 512, 8),
+    ('r_3x3_64', 64, 64, 3, 1, 1, False, 256, 8),
+    ('r_3x3_128', 128, 128, 3, 1, 1, False, 128, 8),
+    ('r_3x3_512', 512, 512, 3, 1, 1, False, 32, 8),
 ]
 
 
