@@ -123,6 +123,7 @@ def main():
     ap.add_argument('--direct_3x3', action='store_true', help='run 3x3 stride-1 layers on the direct implicit-GEMM kernel instead of Winograd F(2x2,3x3)')
     ap.add_argument('--serial_streams', action='store_true', help='run the three loss branches on one stream (profiling aid: with '
                     'concurrent streams the per-kernel durations rocprof reports include time shared with other kernels)')
+    ap.add_argument('--dump_launches', type=str, default=None, help='write the per-launch table of the event pass (shape, family, ms, TFLOP/s) to this JSON file')
     ap.add_argument('--noise_strength', type=float, default=NOISE_STRENGTH, help='generator NoiseInjection weights (0: no noise drawn)')
     a = ap.parse_args()
 
@@ -244,6 +245,16 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = global_b * a.steps / elapsed
     roof = None
+    if prof and a.dump_launches:
+        agg = {}
+        for q in prof:
+            e = agg.setdefault((q[5],) + tuple(q[3]), [0, 0.0, q[2], call_bytes(q)])
+            e[0] += 1
+            e[1] += q[0].elapsed_time(q[1])
+        rows = [dict(family=k[0], shape=list(k[1:]), launches_per_step=v[0] / a.steps, ms_per_launch=round(v[1] / v[0], 4), ms_per_step=round(v[1] / a.steps, 3),
+                     tflops=round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 1), GBs=round(v[3] / (v[1] / v[0] * 1e-3) / 1e9, 1)) for k, v in agg.items()]
+        rows.sort(key=lambda r: -r['ms_per_step'])
+        json.dump(rows, open(a.dump_launches, 'w'), indent=0)
     if prof:
         fams = family_table(prof, a.steps)
         dom = fams[0]                                       # the family with the most GPU time per step

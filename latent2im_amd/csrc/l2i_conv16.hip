@@ -26,12 +26,17 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "l2i.h"
 #include "l2i_internal.h"
 #include "l2i_epilogue.h"
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef L2I_C16_AHEAD
+#define L2I_C16_AHEAD 0
+#endif
 
 namespace s16 {
 // K x K window, stride S, WN 32-pixel rows per wave (TH = 4 WN output rows per block, 32 columns)
@@ -41,15 +46,20 @@ template <int WN, int K, int S> struct Geo {
     static constexpr int ROWS = GATHER ? TH : (TH - 1) * S + K;           // staged input rows
     static constexpr int RSTEP = GATHER ? 2 : 1;                          // global row step between staged rows
     static constexpr int NV = (S == 1) ? (K == 1 ? 8 : 10) : (K == 1 ? 16 : 17);   // aligned 4-pixel vectors per staged row
-    static constexpr int RP = GATHER ? 32 : NV * 4;                       // 16-byte slots per staged row and 8-channel half
+    // 16-byte slots per staged row and 8-channel half (dense: measured, a padded pitch that makes the staging stores conflict-free
+    // buys nothing — loads, split VALU and stores each cost ~10-15 % of the kernel, see DESIGN.md — and row-major items coalesce better)
+    static constexpr int RP = GATHER ? 32 : NV * 4;
     static constexpr int RPH = RP / 2;                                    // stride 2: odd columns start here
     static constexpr int KS = (K == 1) ? 2 : 1;                           // 16-channel MFMA steps per chunk
     static constexpr int NH = 2 * KS;                                     // 8-channel halves per chunk
     static constexpr int CK = 16 * KS;
-    static constexpr int IN_SLOTS = NH * ROWS * RP;                       // slots per plane (hi or lo) per stage
+    static constexpr int HSTRIDE = ROWS * RP;                             // slots of an 8-channel half
+    static constexpr int IN_SLOTS = NH * HSTRIDE;                         // slots per plane (hi or lo) per stage
     static constexpr int NITEM = ROWS * NV;                               // (row, vector) items per half; a thread keeps one half
     static constexpr int TPH = 256 / NH;                                  // threads per half
     static constexpr int NS = (NITEM + TPH - 1) / TPH;                    // items per thread per chunk
+    static constexpr int DUMP = (NS * TPH == NITEM) ? 0 : (NS * TPH - NITEM) * NH + (S == 2 ? 36 : 4);   // slots behind a plane for the threads without an item
+    static constexpr int IN_PLANE = IN_SLOTS + DUMP;
 };
 }
 
@@ -85,7 +95,8 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
     constexpr int WSLOTS = K * G::KS * 2 * BM;             // slots per weight plane per phase: K taps x KS steps x 2 halves x BM channels
     constexpr int WPIECES = 2 * WSLOTS / 64;               // 1 KiB DMA pieces per phase, both planes
     constexpr int WPW = (WPIECES + 3) / 4;                 // per wave
-    constexpr int IN_STAGE = 2 * G::IN_SLOTS, W_STAGE = 2 * WSLOTS;
+    constexpr int IN_PLANE = G::IN_PLANE;                  // tile slots + the dump slots of the threads without an item (see lslot)
+    constexpr int IN_STAGE = 2 * IN_PLANE, W_STAGE = 2 * WSLOTS;
     constexpr int NLOADS = G::NS * 8 * (MASK ? 2 : 1);     // register loads issued AFTER the weight DMA of a phase
     extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
     u32x4* const in_st = smem4;                            // 2 stages x [hi | lo] x [half][row][slot]
@@ -127,11 +138,11 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
     for (int u = 0; u < G::NS; ++u) {
         const int it = tq + u * G::TPH;
         voff[u] = in_bytes;
-        lslot[u] = -1;
-        if (it < G::NITEM) {
+        lslot[u] = G::IN_SLOTS + (it - G::NITEM) * G::NH + nh;   // threads without an item store their zeros to a dump slot behind the plane:
+        if (it < G::NITEM) {                               // the commit stays branch-free and can be scheduled between the MFMAs
             const int row = it / G::NV, v = it - row * G::NV;
             const int gy = iy0 + row * G::RSTEP, gx = xs + 4 * v;
-            lslot[u] = (nh * G::ROWS + row) * G::RP + (G::GATHER ? 2 * v : (S == 2 ? 2 * v : 4 * v));
+            lslot[u] = nh * G::HSTRIDE + row * G::RP + (G::GATHER ? 2 * v : (S == 2 ? 2 * v : 4 * v));
             if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)        // W % 4 == 0: a vector is inside the row or outside it, never across
                 voff[u] = (unsigned)nh * 8u * plane_b + (unsigned)(gy * p.W + gx) * 4u;
         }
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
     auto issue_scales = [&](int c0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            scl[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, (unsigned)((nh * 8 + e) * sizeof(float)), (unsigned)(c0 * sizeof(float)), 0));
+            scl[e] = p.in_scale ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_s, (unsigned)((nh * 8 + e) * sizeof(float)), (unsigned)(c0 * sizeof(float)), 0)) : 1.f;
     };
     auto issue_loads = [&](int c0) {
 #pragma unroll
@@ -183,31 +194,45 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
             }
         }
     };
-    auto commit = [&](int stage) {
+    // one pixel column (px of the 4-pixel vectors) of every item of the prefetched tile -> LDS stage: mask, style scale, split, two 16-byte stores.
+    // The K > 1 pipeline spreads the four columns over the MFMA steps of the chunk's later phases (VALU in the shadow of the matrix pipe).
+    auto commit_px = [&](int stage, int px) {
+#ifdef L2I_ABL_NOCOMMIT
+        return;
+#endif
+#ifdef L2I_ABL_LOADSONLY                                   // keep the loads alive, no VALU, no LDS stores
+#pragma unroll
+        for (int u = 0; u < G::NS; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(xin[u][e]));
+        return;
+#endif
+        if (G::GATHER && (px & 1)) return;                 // 1x1 stride 2 reads even columns only
         u32x4* ih = in_st + stage * IN_STAGE;
-        u32x4* il = ih + G::IN_SLOTS;
+        u32x4* il = ih + IN_PLANE;
 #pragma unroll
         for (int u = 0; u < G::NS; ++u) {
-            if (lslot[u] >= 0) {
+            float v[8];
 #pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    if (G::GATHER && (px & 1)) continue;                   // 1x1 stride 2 reads even columns only
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float t = __uint_as_float(xin[u][e][px]);
-                        if constexpr (MASK) t *= (__uint_as_float(xmk[u][e][px]) > 0.f) ? p.mask_pos : p.mask_neg;
-                        if (p.in_scale) t *= scl[e];
-                        v[e] = t;
-                    }
-                    u32x4 hi, lo;
-                    split8b(v, hi, lo);
-                    const int s = lslot[u] + ((S == 2) ? ((G::GATHER ? 0 : (px & 1) * G::RPH) + (px >> 1)) : px);
-                    ih[s] = hi;
-                    il[s] = lo;
-                }
+            for (int e = 0; e < 8; ++e) {
+                float t = __uint_as_float(xin[u][e][px]);
+                if constexpr (MASK) t *= (__uint_as_float(xmk[u][e][px]) > 0.f) ? p.mask_pos : p.mask_neg;
+                v[e] = t * scl[e];
             }
+            u32x4 hi, lo;
+            split8b(v, hi, lo);
+            const int s = lslot[u] + ((S == 2) ? ((G::GATHER ? 0 : (px & 1) * G::RPH) + (px >> 1)) : px);
+#ifdef L2I_ABL_NOSTORE
+            asm volatile("" ::"v"(hi), "v"(lo), "v"(s));
+#else
+            ih[s] = hi;
+            il[s] = lo;
+#endif
         }
+    };
+    auto commit = [&](int stage) {
+#pragma unroll
+        for (int px = 0; px < 4; ++px) commit_px(stage, px);
     };
 
     f32x16 acc[WM][WN];
@@ -220,7 +245,7 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
 
     // fragment bases (in slots): lane (half, j); everything else is a compile-time or wave-uniform offset
     const int rstep_out = G::GATHER ? 1 : S;               // staged rows between consecutive output rows
-    const int bbase = (half * G::ROWS + wave * WN * rstep_out) * G::RP + j;
+    const int bbase = half * G::HSTRIDE + wave * WN * rstep_out * G::RP + j;
     int coloff[K];                                         // slot offset of tap column kx for output pixel 0
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
@@ -229,68 +254,113 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
     }
     const int abase = half * BM + j;
 
-    auto mfma_phase = [&](int in_stage, int w_stage, int ky) {
+    // fragments of one MFMA step (tap kx, 16-channel step ks): WM + WN pairs of 16-byte LDS reads
+    struct Frag { bf16x8 ah[WM], al[WM], bh[WN], bl[WN]; };
+    constexpr int NSTEP = K * G::KS;
+    auto load_frags = [&](Frag& f, const u32x4* ih, const u32x4* il, const u32x4* wh, const u32x4* wl, int stp) {
+        const int kx = stp / G::KS, ks = stp % G::KS;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            const int idx = ((kx * G::KS + ks) * 2) * BM + m * 32;
+            f.ah[m] = __builtin_bit_cast(bf16x8, wh[idx]);
+            f.al[m] = __builtin_bit_cast(bf16x8, wl[idx]);
+        }
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int idx = ks * 2 * G::HSTRIDE + n * rstep_out * G::RP + coloff[kx];
+            f.bh[n] = __builtin_bit_cast(bf16x8, ih[idx]);
+            f.bl[n] = __builtin_bit_cast(bf16x8, il[idx]);
+        }
+    };
+    auto mma = [&](const Frag& f) {                        // three passes over the WM x WN tiles: dependent accumulations are WM*WN MFMAs apart
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[m], f.bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[m], f.bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[m], f.bh[n], acc[m][n], 0, 0, 0);
+    };
+    // One phase: NSTEP MFMA steps; the fragments of step s+1 are read while step s is on the matrix pipe (two register sets), and
+    // `px_of(step)` >= 0 names the pixel column of the NEXT chunk's tile that is committed to `commit_stage` beside that step's MFMAs.
+    auto mfma_phase = [&](int in_stage, int w_stage, int ky, int commit_stage, auto px0_t, auto px1_t, auto px2_t) {
+        constexpr int px0 = decltype(px0_t)::value, px1 = decltype(px1_t)::value, px2 = decltype(px2_t)::value;   // compile time: no branch in the MFMA stream
         const u32x4* ih = in_st + in_stage * IN_STAGE + bbase + (G::GATHER ? 0 : ky) * G::RP;
-        const u32x4* il = ih + G::IN_SLOTS;
+        const u32x4* il = ih + IN_PLANE;
         const u32x4* wh = w_st + w_stage * W_STAGE + abase;
         const u32x4* wl = wh + WSLOTS;
+        constexpr bool AHEAD = (L2I_C16_AHEAD != 0);
+        Frag f[2];
+        load_frags(f[0], ih, il, wh, wl, 0);
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) {
-                bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
-#pragma unroll
-                for (int m = 0; m < WM; ++m) {
-                    const int idx = ((kx * G::KS + ks) * 2) * BM + m * 32;
-                    ah[m] = __builtin_bit_cast(bf16x8, wh[idx]);
-                    al[m] = __builtin_bit_cast(bf16x8, wl[idx]);
-                }
-#pragma unroll
-                for (int n = 0; n < WN; ++n) {
-                    const int idx = (ks * 2 * G::ROWS + n * rstep_out) * G::RP + coloff[kx];
-                    bh[n] = __builtin_bit_cast(bf16x8, ih[idx]);
-                    bl[n] = __builtin_bit_cast(bf16x8, il[idx]);
-                }
-                // three passes over the WM x WN tiles: dependent accumulations are WM*WN MFMAs apart
-#pragma unroll
-                for (int m = 0; m < WM; ++m)
-#pragma unroll
-                    for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < WM; ++m)
-#pragma unroll
-                    for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < WM; ++m)
-#pragma unroll
-                    for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
-            }
+        for (int stp = 0; stp < NSTEP; ++stp) {
+            if (AHEAD && stp + 1 < NSTEP) load_frags(f[(stp + 1) & 1], ih, il, wh, wl, stp + 1);
+            constexpr int pxs[3] = {px0, px1, px2};
+            if constexpr (NSTEP == 3) { if (pxs[stp] >= 0) commit_px(commit_stage, pxs[stp]); }
+            mma(f[AHEAD ? (stp & 1) : 0]);
+            if (!AHEAD && stp + 1 < NSTEP) load_frags(f[0], ih, il, wh, wl, stp + 1);
         }
     };
 
     // ---- pipeline: phase = (chunk, kernel row).  Per phase: wait for this phase's weights, ONE barrier, start the next phase's
-    //      weight DMA (and, in the first phase of a chunk, the next chunk's tile loads), MFMAs.  The next chunk's tile is committed
-    //      to the other input stage after the chunk's last phase. ----
+    //      weight DMA (and, in the first phase of a chunk, the next chunk's tile loads), MFMAs.  3x3: the next chunk's tile (loaded
+    //      during phase 0) is committed to the other input stage column by column beside the MFMAs of phases 1 and 2; 1x1: after the
+    //      chunk's only phase. ----
     const int nphases = L.nchunks * K;
     issue_scales(0);
     dma_w(0, 0, 0);
     issue_loads(0);
     commit(0);
+    auto phase_head = [&](int ch, int ky, bool more) {
+        const int ph = ch * K + ky;
+        // the DMA of this phase's weights has landed; register loads issued after it (first phase of a chunk, K > 1) stay in flight
+        if (K > 1 && ky == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef L2I_ABL_NOBARRIER
+        __syncthreads();
+#endif
+#ifndef L2I_ABL_NOLOADS
+        if (ky == 0 && more) issue_scales((ch + 1) * G::CK);
+#endif
+#ifndef L2I_ABL_NODMA
+        if (ph + 1 < nphases) dma_w(ky + 1 < K ? ch : ch + 1, ky + 1 < K ? ky + 1 : 0, (ph + 1) & 1);
+#endif
+#ifndef L2I_ABL_NOLOADS
+        if (ky == 0 && more) issue_loads((ch + 1) * G::CK);
+#endif
+    };
     for (int ch = 0; ch < L.nchunks; ++ch) {
         const bool more = ch + 1 < L.nchunks;
-#pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {
-            const int ph = ch * K + ky;
-            // the DMA of this phase's weights has landed; register loads issued after it (first phase of a chunk, K > 1) stay in flight
-            if (K > 1 && ky == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (ky == 0 && more) issue_scales((ch + 1) * G::CK);
-            if (ph + 1 < nphases) dma_w(ky + 1 < K ? ch : ch + 1, ky + 1 < K ? ky + 1 : 0, (ph + 1) & 1);
-            if (ky == 0 && more) issue_loads((ch + 1) * G::CK);
-            mfma_phase(ch & 1, ph & 1, ky);
+        using N_ = std::integral_constant<int, -1>;
+        if constexpr (K == 3 && MASK) {                    // mask variants: 32 more staging registers; interleaving the commit spills them
+            const int cs = (ch + 1) & 1;
+            phase_head(ch, 0, more);
+            mfma_phase(ch & 1, (ch * 3) & 1, 0, cs, N_(), N_(), N_());
+            phase_head(ch, 1, more);
+            mfma_phase(ch & 1, (ch * 3 + 1) & 1, 1, cs, N_(), N_(), N_());
+            phase_head(ch, 2, more);
+            mfma_phase(ch & 1, (ch * 3 + 2) & 1, 2, cs, N_(), N_(), N_());
+            if (more) commit(cs);
+        } else if constexpr (K == 3) {
+            const int cs = (ch + 1) & 1;
+            phase_head(ch, 0, more);
+            mfma_phase(ch & 1, (ch * 3) & 1, 0, cs, N_(), N_(), N_());
+            phase_head(ch, 1, more);
+            if (more) mfma_phase(ch & 1, (ch * 3 + 1) & 1, 1, cs, N_(), N_(), std::integral_constant<int, 0>());
+            else mfma_phase(ch & 1, (ch * 3 + 1) & 1, 1, cs, N_(), N_(), N_());
+            phase_head(ch, 2, more);
+            if (more) mfma_phase(ch & 1, (ch * 3 + 2) & 1, 2, cs, std::integral_constant<int, 1>(), std::integral_constant<int, 2>(), std::integral_constant<int, 3>());
+            else mfma_phase(ch & 1, (ch * 3 + 2) & 1, 2, cs, N_(), N_(), N_());
+        } else {
+            phase_head(ch, 0, more);
+            mfma_phase(ch & 1, ch & 1, 0, 0, N_(), N_(), N_());
+            if (more) commit((ch + 1) & 1);
         }
-        if (more) commit((ch + 1) & 1);
     }
     __syncthreads();                                       // the stages become the epilogue's transpose strips
 
@@ -313,7 +383,7 @@ static int launch_pipe(const l2i_conv_params& p, hipStream_t st) {
     L.nchunks = p.Cin / G::CK;
     L.shift = (4 - (p.pad_x & 3)) & 3;                      // ox0 * S is a multiple of 4
     L.vec_epi = l2i_epilogue_vec_ok(p) ? 1 : 0;
-    size_t lds = (size_t)(2 * 2 * G::IN_SLOTS + 2 * 2 * WSLOTS) * 16;
+    size_t lds = (size_t)(2 * 2 * G::IN_PLANE + 2 * 2 * WSLOTS) * 16;
     if (lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_bf16x3: tile does not fit the LDS");
     static bool attr_done = false;
