@@ -106,12 +106,20 @@ int l2i_conv2d_family(const l2i_conv_params* p);
  * l2i_conv2d_f32 calls). */
 int l2i_conv_transpose2d_f32(const l2i_conv_params* p, void* stream);
 
-/* OPT-IN split-precision variant of l2i_conv2d_f32 for stride-1 layers on large maps (Cin % 16 == 0, OW >= 32, kernel <=
- * 3x3): operands are split x = bf16(x) + bf16(x - bf16(x)) and a*b is evaluated as ah*bh + ah*bl + al*bh on
- * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative product error <= ~2^-17).  fp32 tensors in and out, same
- * prologue / epilogue fusions; `w` is ignored, `w_hi` / `w_lo` are the host-split weight planes.  Nothing on the default
- * path calls it (latent2im_amd.conv.PRECISION selects it). */
+/* Split-precision variant of l2i_conv2d_f32 (BASELINE config 5's "16-bit MFMA" path; latent2im_amd.conv.PRECISION = 'bf16x3' selects
+ * it): operands are split x = bf16(x) + bf16(x - bf16(x)) and a*b is evaluated as ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16
+ * with fp32 accumulation (relative product error <= ~2^-17: fp32-class results).  fp32 tensors in and out, same prologue / epilogue
+ * fusions; `w` is ignored, `w_hi` / `w_lo` are the host-split weight planes [Cin/16][KH*KW][2][CoutP][8] (hi = bf16(w), lo = bf16(w - hi)).
+ * Layers: 1x1 (pad 0, Cin % 32 == 0) and 3x3 (pad 1; stride 2 also pad 0; Cin % 16 == 0), stride 1 or 2, dense output window, OW >= 32,
+ * W % 4 == 0, 16-byte aligned x / in_mask.  Anything else returns L2I_E_UNSUPPORTED (callers use l2i_conv2d_f32). */
 int l2i_conv2d_bf16x3_f32(const l2i_conv_params* p, void* stream);
+
+/* l2i_conv_transpose2d_f32 on the split-precision bf16 matrix path (same arithmetic as l2i_conv2d_bf16x3_f32): 3x3 stride-2 transposed
+ * conv, pad 0 (the generator's up layers, networks.py:246-255) or pad 1 (input-gradient of a 3x3 stride-2 pad-1 conv), all four output
+ * parities per launch.  `w_hi` / `w_lo`: the bf16 planes of the [Cout, Cin, 3, 3] correlation-form weight in the layout of
+ * l2i_conv2d_bf16x3_f32 ([Cin/16][9][2][CoutP][8]); `w` is ignored.  Fused: in_scale, in_mask, out_scale, out_gain.  Needs Cin % 16 == 0,
+ * W % 4 == 0, W >= 32 and the natural output size; other shapes return L2I_E_UNSUPPORTED (use l2i_conv_transpose2d_f32). */
+int l2i_conv_transpose2d_bf16x3_f32(const l2i_conv_params* p, void* stream);
 
 /* 3x3 stride-1 layers (KH = KW = 3, stride 1, dense output window, Cin % 8 == 0, output rows 16-byte aligned multiples of
  * 4 pixels) as Winograd F(2x2,3x3) on the fp32 matrix cores: exact-fp32 products and accumulation like l2i_conv2d_f32,

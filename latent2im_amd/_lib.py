@@ -42,6 +42,7 @@ _SIGNATURES = {
     'l2i_conv2d_family': (c_i, [ctypes.POINTER(ConvParams)]),
     'l2i_conv_transpose2d_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_bf16x3_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
+    'l2i_conv_transpose2d_bf16x3_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_wino_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_fused_bias_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
     'l2i_upfirdn2d_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,

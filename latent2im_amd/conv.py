@@ -32,7 +32,8 @@ FAMILY_INFO = {
     'transposed_f32': ('convt_mfma_kernel', 1.0, 157.3),
     'cin3_f32': ('conv_cin3_kernel', 28.0 / 27.0, 157.3),
     'direct_small_valu': ('conv_direct_small_kernel', 1.0, 157.3),
-    'implicit_gemm_bf16x3': ('conv_bf16x3_kernel', 3.0, 2500.0),
+    'implicit_gemm_bf16x3': ('conv_bf16x3_pipe_kernel', 3.0, 2500.0),
+    'transposed_bf16x3': ('conv_bf16x3_pipe_kernel<TR>', 3.0, 2500.0),
 }
 
 
@@ -178,8 +179,9 @@ def fused_transposed_taps(K, pad):
 
 
 class FusedTransposed:
-    """One-launch stride-2 transposed conv (l2i_conv_transpose2d_f32): weights packed in the kernel's tap order."""
-    __slots__ = ('w', 'cin', 'cout', 'k', 'pad')
+    """One-launch stride-2 transposed conv (l2i_conv_transpose2d_f32): weights packed in the kernel's tap order; for the split-precision
+    path (l2i_conv_transpose2d_bf16x3_f32) the bf16 planes of the plain [Cout, Cin, 3, 3] weight, built on first use."""
+    __slots__ = ('w', 'cin', 'cout', 'k', 'pad', 'w_src', 'w16')
 
     def __init__(self, w_oihw, pad):
         w = torch.as_tensor(w_oihw, dtype=torch.float32)
@@ -188,6 +190,14 @@ class FusedTransposed:
         taps = fused_transposed_taps(self.k, pad)
         sel = torch.stack([w[:, :, ky, kx] for ky, kx in taps], 2)               # [Cout, Cin, K*K]
         self.w = pack_weight(sel.reshape(self.cout, self.cin, self.k * self.k, 1))
+        self.w_src = w if (self.k == 3 and pad in (0, 1) and self.cin % 16 == 0) else None
+        self.w16 = None
+
+    def bf16x3_planes(self):
+        if self.w16 is None and self.w_src is not None:
+            hi, lo = pack_weight_bf16x3(self.w_src)
+            self.w16 = (hi.to(self.w.device), lo.to(self.w.device))
+        return self.w16
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -229,17 +239,24 @@ def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), 
     p.tile_hint = tile_hint
     if in_mask is not None:
         assert in_mask.shape == x.shape
-    _split_k(p, B * H * W, cin, y)
+    entry, name, family = lib.l2i_conv_transpose2d_f32, 'l2i_conv_transpose2d_f32', 'transposed_f32'
+    nat_h, nat_w = (H - 1) * 2 - 2 * F.pad + F.k, (W - 1) * 2 - 2 * F.pad + F.k
+    if (PRECISION == 'bf16x3' and tile_hint == 0 and F.w_src is not None and W % 4 == 0 and W >= 32 and x.data_ptr() % 16 == 0
+            and (in_mask is None or in_mask.data_ptr() % 16 == 0) and 0 <= p.OHf - nat_h <= 1 and 0 <= p.OWf - nat_w <= 1):
+        planes = F.bf16x3_planes()
+        p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
+        entry, name, family = lib.l2i_conv_transpose2d_bf16x3_f32, 'l2i_conv_transpose2d_bf16x3_f32', 'transposed_bf16x3'
+    else:
+        _split_k(p, B * H * W, cin, y)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.check(lib.l2i_conv_transpose2d_f32(p, _lib.stream_ptr()), 'l2i_conv_transpose2d_f32')
+        _lib.check(entry(p, _lib.stream_ptr()), name)
         e1.record()
         PROFILE.append((e0, e1, 2.0 * B * F.cout * cin * F.k * F.k * H * W,
-                        (B, cin, F.cout, F.k, F.k, 2, H, W, int(p.OHf), int(p.OWf), 2, in_mask is not None, in_scale is not None), 'l2i_conv_transpose2d_f32',
-                        'transposed_f32'))
+                        (B, cin, F.cout, F.k, F.k, 2, H, W, int(p.OHf), int(p.OWf), 2, in_mask is not None, in_scale is not None), name, family))
         return y
-    _lib.check(lib.l2i_conv_transpose2d_f32(p, _lib.stream_ptr()), 'l2i_conv_transpose2d_f32')
+    _lib.check(entry(p, _lib.stream_ptr()), name)
     return y
 
 
@@ -316,6 +333,8 @@ def _bf16x3_eligible(L, x, in_mask, OW):
     the direct VALU kernel, everything else that is not eligible on the fp32 matrix kernels."""
     k1 = L.kh == 1 and L.kw == 1 and L.pad_y == 0 and L.pad_x == 0
     k3 = L.kh == 3 and L.kw == 3 and L.pad_y == L.pad_x and (L.pad_x == 1 or (L.pad_x == 0 and L.stride == 2))
+    if k1 and L.stride == 1 and (in_mask is not None or L.cin * L.cout < 65536):
+        return False        # HBM-bound 1x1 layers: the DMA-fed fp32 GEMM (no staging registers, no split VALU) streams faster (measured per shape)
     return ((k1 or k3) and L.step == 1 and L.w_src is not None and L.cin % (32 if k1 else 16) == 0 and L.cout > 4 and OW >= 32
             and x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and (in_mask is None or in_mask.data_ptr() % 16 == 0))
 

@@ -39,13 +39,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 
 namespace s16 {
-// K x K window, stride S, WN 32-pixel rows per wave (TH = 4 WN output rows per block, 32 columns)
-template <int WN, int K, int S> struct Geo {
+// K x K window, stride S, WN 32-pixel rows per wave (TH = 4 WN output rows per block, 32 columns).
+// TR != 0: stride-2 TRANSPOSED 3x3 conv (TR = 1: pad 0, TR = 2: pad 1), all four output parities from one staged tile: the tile is
+// TH x 32 input POSITIONS t, output (2t + py, 2s + px) = sum over the taps of that parity of x[t + dy][s + dx] w[ky][kx], dy, dx in
+// {dmin, dmin + 1} (dmin = -1 for pad 0, 0 for pad 1): a 2x2-tap correlation per parity on a tile with one halo row / column.
+template <int WN, int K, int S, int TR = 0> struct Geo {
     static constexpr int TH = 4 * WN;
     static constexpr bool GATHER = (K == 1 && S == 2);                    // 1x1 stride 2: only even rows / columns are staged
-    static constexpr int ROWS = GATHER ? TH : (TH - 1) * S + K;           // staged input rows
+    static constexpr int ROWS = TR ? TH + 1 : (GATHER ? TH : (TH - 1) * S + K);   // staged input rows
     static constexpr int RSTEP = GATHER ? 2 : 1;                          // global row step between staged rows
-    static constexpr int NV = (S == 1) ? (K == 1 ? 8 : 10) : (K == 1 ? 16 : 17);   // aligned 4-pixel vectors per staged row
+    static constexpr int NV = (S == 1) ? (K == 1 ? 8 : (TR == 2 ? 9 : 10)) : (K == 1 ? 16 : 17);   // aligned 4-pixel vectors per staged row
     // 16-byte slots per staged row and 8-channel half (dense: measured, a padded pitch that makes the staging stores conflict-free
     // buys nothing — loads, split VALU and stores each cost ~10-15 % of the kernel, see DESIGN.md — and row-major items coalesce better)
     static constexpr int RP = GATHER ? 32 : NV * 4;
@@ -88,9 +91,11 @@ __device__ __forceinline__ void split8b(const float (&v)[8], u32x4& hi, u32x4& l
     lo = u32x4{l[0], l[1], l[2], l[3]};
 }
 
-template <int WM, int WN, int K, int S, bool MASK>
+template <int WM, int WN, int K, int S, bool MASK, int TR = 0>
 __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf16x3_pipe_kernel(const l2i_conv_params p, const S16Launch L) {
-    using G = s16::Geo<WN, K, S>;
+    using G = s16::Geo<WN, K, S, TR>;
+    constexpr int NACC = TR ? 4 : 1;                       // transposed: one accumulator set per output parity (py, px)
+    constexpr int DMIN = (TR == 1) ? -1 : 0;               // first input offset of the transposed taps
     constexpr int BM = WM * 32;
     constexpr int WSLOTS = K * G::KS * 2 * BM;             // slots per weight plane per phase: K taps x KS steps x 2 halves x BM channels
     constexpr int WPIECES = 2 * WSLOTS / 64;               // 1 KiB DMA pieces per phase, both planes
@@ -114,8 +119,8 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
     const int tx = __builtin_amdgcn_readfirstlane(w % L.tiles_x); w /= L.tiles_x;
     const int ty = __builtin_amdgcn_readfirstlane(w % L.tiles_y); w /= L.tiles_y;
     const int b = __builtin_amdgcn_readfirstlane(w), m0 = mblk * BM, oy0 = ty * G::TH, ox0 = tx * 32;
-    const int iy0 = oy0 * S - p.pad_y;
-    const int xs = ox0 * S - p.pad_x - L.shift;            // first staged column: multiple of 4 (may be negative)
+    const int iy0 = TR ? oy0 + DMIN : oy0 * S - p.pad_y;
+    const int xs = TR ? ox0 + DMIN - L.shift : ox0 * S - p.pad_x - L.shift;     // first staged column: multiple of 4 (may be negative)
 
     // ---- descriptors ----
     const size_t plane_x = (size_t)p.H * p.W;
@@ -235,13 +240,15 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
         for (int px = 0; px < 4; ++px) commit_px(stage, px);
     };
 
-    f32x16 acc[WM][WN];
+    f32x16 acc[NACC][WM][WN];
 #pragma unroll
-    for (int m = 0; m < WM; ++m)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int n = 0; n < WN; ++n)
+        for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
 
     // fragment bases (in slots): lane (half, j); everything else is a compile-time or wave-uniform offset
     const int rstep_out = G::GATHER ? 1 : S;               // staged rows between consecutive output rows
@@ -249,7 +256,8 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
     int coloff[K];                                         // slot offset of tap column kx for output pixel 0
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
-        const int c = kx + L.shift;
+        // transposed: tap kx feeds output parity (kx + pad) & 1 from input column s + dx, dx = (px + pad - kx) / 2; staged column dx - DMIN
+        const int c = TR ? (((kx + (TR == 2)) & 1) + (TR == 2) - kx) / 2 - DMIN + L.shift : kx + L.shift;
         coloff[kx] = G::GATHER ? 0 : (S == 2 ? (c & 1) * G::RPH + (c >> 1) : c);
     }
     const int abase = half * BM + j;
@@ -272,25 +280,30 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
             f.bl[n] = __builtin_bit_cast(bf16x8, il[idx]);
         }
     };
-    auto mma = [&](const Frag& f) {                        // three passes over the WM x WN tiles: dependent accumulations are WM*WN MFMAs apart
+    auto mma = [&](const Frag& f, f32x16 (&ac)[WM][WN]) {  // three passes over the WM x WN tiles: dependent accumulations are WM*WN MFMAs apart
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[m], f.bh[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < WN; ++n) ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[m], f.bh[n], ac[m][n], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[m], f.bl[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < WN; ++n) ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[m], f.bl[n], ac[m][n], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[m], f.bh[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < WN; ++n) ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[m], f.bh[n], ac[m][n], 0, 0, 0);
     };
     // One phase: NSTEP MFMA steps; the fragments of step s+1 are read while step s is on the matrix pipe (two register sets), and
     // `px_of(step)` >= 0 names the pixel column of the NEXT chunk's tile that is committed to `commit_stage` beside that step's MFMAs.
-    auto mfma_phase = [&](int in_stage, int w_stage, int ky, int commit_stage, auto px0_t, auto px1_t, auto px2_t) {
+    auto mfma_phase = [&](int in_stage, int w_stage, auto ky_t, int commit_stage, auto px0_t, auto px1_t, auto px2_t) {
         constexpr int px0 = decltype(px0_t)::value, px1 = decltype(px1_t)::value, px2 = decltype(px2_t)::value;   // compile time: no branch in the MFMA stream
-        const u32x4* ih = in_st + in_stage * IN_STAGE + bbase + (G::GATHER ? 0 : ky) * G::RP;
+        constexpr int ky = decltype(ky_t)::value;
+        // transposed: kernel row ky feeds output parity py = (ky + pad) & 1 from input row t + dy, dy = (py + pad - ky) / 2
+        constexpr int PADT = (TR == 2) ? 1 : 0;
+        constexpr int py = (ky + PADT) & 1;
+        constexpr int rowoff = TR ? (py + PADT - ky) / 2 - DMIN : (G::GATHER ? 0 : ky);
+        const u32x4* ih = in_st + in_stage * IN_STAGE + bbase + rowoff * G::RP;
         const u32x4* il = ih + IN_PLANE;
         const u32x4* wh = w_st + w_stage * W_STAGE + abase;
         const u32x4* wl = wh + WSLOTS;
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
             if (AHEAD && stp + 1 < NSTEP) load_frags(f[(stp + 1) & 1], ih, il, wh, wl, stp + 1);
             constexpr int pxs[3] = {px0, px1, px2};
             if constexpr (NSTEP == 3) { if (pxs[stp] >= 0) commit_px(commit_stage, pxs[stp]); }
-            mma(f[AHEAD ? (stp & 1) : 0]);
+            mma(f[AHEAD ? (stp & 1) : 0], acc[TR ? py * 2 + ((stp + PADT) & 1) : 0]);
             if (!AHEAD && stp + 1 < NSTEP) load_frags(f[0], ih, il, wh, wl, stp + 1);
         }
     };
@@ -337,34 +350,70 @@ __global__ __launch_bounds__(256, (S == 1 && WM * WN <= 4) ? 2 : 1) void conv_bf
     for (int ch = 0; ch < L.nchunks; ++ch) {
         const bool more = ch + 1 < L.nchunks;
         using N_ = std::integral_constant<int, -1>;
-        if constexpr (K == 3 && MASK) {                    // mask variants: 32 more staging registers; interleaving the commit spills them
-            const int cs = (ch + 1) & 1;
+        using K0 = std::integral_constant<int, 0>;
+        using K1 = std::integral_constant<int, 1>;
+        using K2 = std::integral_constant<int, 2>;
+        using K3 = std::integral_constant<int, 3>;
+        if constexpr (K == 3 && (MASK || TR)) {            // mask variants: 32 more staging registers (transposed: 4 accumulator sets);
+            const int cs = (ch + 1) & 1;                   // interleaving the commit spills them
             phase_head(ch, 0, more);
-            mfma_phase(ch & 1, (ch * 3) & 1, 0, cs, N_(), N_(), N_());
+            mfma_phase(ch & 1, (ch * 3) & 1, K0(), cs, N_(), N_(), N_());
             phase_head(ch, 1, more);
-            mfma_phase(ch & 1, (ch * 3 + 1) & 1, 1, cs, N_(), N_(), N_());
+            mfma_phase(ch & 1, (ch * 3 + 1) & 1, K1(), cs, N_(), N_(), N_());
             phase_head(ch, 2, more);
-            mfma_phase(ch & 1, (ch * 3 + 2) & 1, 2, cs, N_(), N_(), N_());
+            mfma_phase(ch & 1, (ch * 3 + 2) & 1, K2(), cs, N_(), N_(), N_());
             if (more) commit(cs);
         } else if constexpr (K == 3) {
             const int cs = (ch + 1) & 1;
             phase_head(ch, 0, more);
-            mfma_phase(ch & 1, (ch * 3) & 1, 0, cs, N_(), N_(), N_());
+            mfma_phase(ch & 1, (ch * 3) & 1, K0(), cs, N_(), N_(), N_());
             phase_head(ch, 1, more);
-            if (more) mfma_phase(ch & 1, (ch * 3 + 1) & 1, 1, cs, N_(), N_(), std::integral_constant<int, 0>());
-            else mfma_phase(ch & 1, (ch * 3 + 1) & 1, 1, cs, N_(), N_(), N_());
+            if (more) mfma_phase(ch & 1, (ch * 3 + 1) & 1, K1(), cs, N_(), N_(), K0());
+            else mfma_phase(ch & 1, (ch * 3 + 1) & 1, K1(), cs, N_(), N_(), N_());
             phase_head(ch, 2, more);
-            if (more) mfma_phase(ch & 1, (ch * 3 + 2) & 1, 2, cs, std::integral_constant<int, 1>(), std::integral_constant<int, 2>(), std::integral_constant<int, 3>());
-            else mfma_phase(ch & 1, (ch * 3 + 2) & 1, 2, cs, N_(), N_(), N_());
+            if (more) mfma_phase(ch & 1, (ch * 3 + 2) & 1, K2(), cs, K1(), K2(), K3());
+            else mfma_phase(ch & 1, (ch * 3 + 2) & 1, K2(), cs, N_(), N_(), N_());
         } else {
             phase_head(ch, 0, more);
-            mfma_phase(ch & 1, ch & 1, 0, 0, N_(), N_(), N_());
+            mfma_phase(ch & 1, ch & 1, K0(), 0, N_(), N_(), N_());
             if (more) commit((ch + 1) & 1);
         }
     }
     __syncthreads();                                       // the stages become the epilogue's transpose strips
 
-    l2i_epilogue_32x32<WM, WN>(p, acc, reinterpret_cast<float*>(smem4), b, m0, oy0, ox0, L.vec_epi != 0);
+    if constexpr (TR == 0) {
+        l2i_epilogue_32x32<WM, WN>(p, acc[0], reinterpret_cast<float*>(smem4), b, m0, oy0, ox0, L.vec_epi != 0);
+    } else {
+        // transposed epilogue: y[b, co, 2t + py, 2s + px] = acc[py][px] * out_scale[b, co] * out_gain; the two x parities of a lane are adjacent
+        // outputs: 8-byte stores, 256 contiguous bytes per channel row and lane half (the (2W+1)-wide rows are only 4-byte aligned)
+        const size_t plane_o = (size_t)p.OHf * p.OWf;
+        const float* osc = p.out_scale ? p.out_scale + (size_t)b * p.Cout : nullptr;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int t = oy0 + wave * WN + n, sx = ox0 + j;
+#pragma unroll
+            for (int py2 = 0; py2 < 2; ++py2) {
+                const int oy = 2 * t + py2, ox = 2 * sx;
+                if (oy < p.OHf && ox < p.OWf) {
+                    const bool two = ox + 1 < p.OWf;
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int co = m0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (co < p.Cout) {
+                                const float sc = (osc ? osc[co] : 1.f) * p.out_gain;
+                                float* dst = p.y + ((size_t)b * p.Cout + co) * plane_o + (size_t)oy * p.OWf + ox;
+                                const float v0 = acc[py2 * 2 + 0][m][n][r] * sc, v1 = acc[py2 * 2 + 1][m][n][r] * sc;
+                                if (two) *reinterpret_cast<float2*>(dst) = make_float2(v0, v1);      // 4-byte aligned: fine on gfx950
+                                else dst[0] = v0;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -397,6 +446,56 @@ static int launch_pipe(const l2i_conv_params& p, hipStream_t st) {
     else hipLaunchKernelGGL((conv_bf16x3_pipe_kernel<WM, WN, K, S, false>), dim3(grid), dim3(256), lds, st, p, L);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
+}
+
+// stride-2 transposed 3x3 conv (pad 0 or 1), all four output parities per launch
+template <int WM, int WN, int TR>
+static int launch_pipe_tr(const l2i_conv_params& p, hipStream_t st) {
+    using G = s16::Geo<WN, 3, 1, TR>;
+    constexpr int BM = WM * 32;
+    constexpr int WSLOTS = 3 * 2 * BM;
+    S16Launch L;
+    L.tiles_x = (p.OW + 31) / 32;                           // OH x OW = input positions t with an output: (OHf + 1) / 2
+    L.tiles_y = (p.OH + G::TH - 1) / G::TH;
+    L.mblocks = (p.CoutP + BM - 1) / BM;
+    const long total = (long)p.B * L.tiles_y * L.tiles_x * L.mblocks;
+    if (total <= 0 || total > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: grid too large");
+    L.total = (int)total;
+    L.nchunks = p.Cin / 16;
+    L.shift = (TR == 1) ? 3 : 0;
+    L.vec_epi = 0;
+    size_t lds = (size_t)(2 * 2 * G::IN_PLANE + 2 * 2 * WSLOTS) * 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_pipe_kernel<WM, WN, 3, 1, false, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_pipe_kernel<WM, WN, 3, 1, true, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)((total + 7) & ~7L);
+    if (p.in_mask) hipLaunchKernelGGL((conv_bf16x3_pipe_kernel<WM, WN, 3, 1, true, TR>), dim3(grid), dim3(256), lds, st, p, L);
+    else hipLaunchKernelGGL((conv_bf16x3_pipe_kernel<WM, WN, 3, 1, false, TR>), dim3(grid), dim3(256), lds, st, p, L);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+extern "C" int l2i_conv_transpose2d_bf16x3_f32(const l2i_conv_params* pp, void* stream) {
+    if (!pp) return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: null params");
+    const l2i_conv_params& p = *pp;
+    if (!p.x || !p.w_hi || !p.w_lo || !p.y) return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: null tensor");
+    if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OHf <= 0 || p.OWf <= 0)
+        return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: non-positive dimension");
+    if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: CoutP must be Cout rounded up to 32");
+    auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
+    const int nat = (p.H - 1) * 2 - 2 * p.pad_y + 3, natw = (p.W - 1) * 2 - 2 * p.pad_x + 3;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 2 || p.pad_y != p.pad_x || p.pad_x < 0 || p.pad_x > 1 || (p.Cin % 16) != 0 || (p.W % 4) != 0 || p.W < 32 ||
+        !al16(p.x) || !al16(p.in_mask) || !al16(p.w_hi) || !al16(p.w_lo) || p.ksplit > 1 || p.OHf < nat || p.OHf > nat + 1 || p.OWf < natw || p.OWf > natw + 1 ||
+        p.OH != (p.OHf + 1) / 2 || p.OW != (p.OWf + 1) / 2 || p.noise || p.bias || p.residual || p.out_mask || p.accumulate || p.act != L2I_ACT_NONE ||
+        (size_t)p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull)
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d_bf16x3: needs a 3x3 stride-2 layer (pad 0 or 1), Cin % 16 == 0, W % 4 == 0, W >= 32, natural output size, "
+                                                "in_scale / in_mask / out_scale / out_gain fusions only");
+    hipStream_t st = (hipStream_t)stream;
+    if (p.pad_x == 0) return (p.CoutP % 64) == 0 ? launch_pipe_tr<2, 1, 1>(p, st) : launch_pipe_tr<1, 2, 1>(p, st);
+    return (p.CoutP % 64) == 0 ? launch_pipe_tr<2, 1, 2>(p, st) : launch_pipe_tr<1, 2, 2>(p, st);
 }
 
 static bool l2i_bf16x3_pipe_eligible(const l2i_conv_params& p) {

@@ -498,3 +498,35 @@ def test_op_upfirdn2d_autograd_and_double_backward(golden):
         gg, = torch.autograd.grad((gx * v.to(DEV)).sum(), gy)
         close(gg, sg2.upfirdn2d(v, k, up=up, down=down, pad=(p0, p1)), 1e-5, 1e-6)
         close(gg, kernels.upfirdn2d(v.to(DEV), k.to(DEV), (up, up), (down, down), (p0, p1, p0, p1)), 1e-6, 1e-7)
+
+
+@pytest.mark.parametrize('cin,cout,pad,tr,h,w,b', [(64, 32, 0, True, 64, 64, 2), (128, 64, 0, True, 32, 32, 1), (32, 48, 0, True, 40, 36, 1), (512, 256, 0, True, 32, 32, 2),
+                                                   (64, 64, 1, False, 64, 64, 2), (48, 96, 1, False, 66, 72, 1), (32, 64, 0, False, 65, 65, 2), (64, 128, 0, False, 129, 129, 1)])
+def test_bf16x3_transposed_conv(cin, cout, pad, tr, h, w, b):
+    """l2i_conv_transpose2d_bf16x3_f32 (all four output parities of a 3x3 stride-2 transposed conv from one staged tile, 3-term bf16 split)
+    against float64: the generator's up layers (pad 0, style scale in, demod scale out) and the input-gradient of 3x3 stride-2 convs
+    (pad 1: ResNet-50; pad 0: the discriminator's blurred down convs) with the activation-gradient mask."""
+    rs = np.random.RandomState(cin + cout + h + pad)
+    wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    fc = conv.FrozenConv2d(wt, 2, pad, transposed=tr, device=DEV)
+    g = lambda t: t.to(DEV)
+    launched = []
+    conv.PRECISION, conv.PROFILE = 'bf16x3', launched
+    try:
+        if tr:
+            x, s, d = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cin) + 0.5), T(rs.rand(b, cout) + 0.5)
+            ref = F.conv_transpose2d(x.double() * s.double()[:, :, None, None], wt.double().transpose(0, 1), stride=2, padding=pad) * d.double()[:, :, None, None] * 0.7
+            got = fc.forward(g(x), in_scale=g(s), out_scale=g(d), out_gain=0.7)
+        else:
+            oh, ow = fc.out_hw(h, w)
+            gy, y = T(rs.randn(b, cout, oh, ow)), T(rs.randn(b, cout, oh, ow))
+            xr = T(rs.randn(b, cin, h, w)).double().requires_grad_(True)
+            gm = gy.double() * torch.where(y > 0, torch.tensor(1.0, dtype=torch.float64), torch.tensor(0.2, dtype=torch.float64))
+            ref, = torch.autograd.grad(F.conv2d(xr, wt.double(), stride=2, padding=pad), xr, gm)
+            got = fc.dgrad(g(gy), (h, w), in_mask=g(y), mask=(1.0, 0.2))
+    finally:
+        conv.PRECISION, conv.PROFILE = 'f32', None
+    torch.cuda.synchronize()
+    assert [q[4] for q in launched] == ['l2i_conv_transpose2d_bf16x3_f32'], [q[4] for q in launched]
+    err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
