@@ -100,7 +100,7 @@ int l2i_conv2d_family(const l2i_conv_params* p);
  *   y[b,co,2*iy+ky-pad,2*ix+kx-pad] += x[b,ci,iy,ix] * w[co,ci,ky,kx]          (F.conv_transpose2d(stride=2) of the up
  *   layers, networks.py:246-255, and the input-gradient of every stride-2 conv of the path).
  * Same struct as l2i_conv2d_f32 with KH = KW = K, pad_y = pad_x = pad, y = [B,Cout,OHf,OWf] of the natural size
- * (H-1)*2-2*pad+K (or one more); `w` is the FUSED pack [Cin][K*K][CoutP] whose tap order is the kernel's walk order
+ * (H-1)*2-2*pad+K (or up to 8 more: rows / columns no input reaches are written as zeros); `w` is the FUSED pack [Cin][K*K][CoutP] whose tap order is the kernel's walk order
  * (latent2im_amd/conv.py:fused_transposed_taps).  Fused: in_scale, in_mask, out_scale, out_gain; everything else must
  * be unset.  Built for (K,pad) in {(3,0),(3,1),(7,3)}; other shapes return L2I_E_UNSUPPORTED (use the per-parity
  * l2i_conv2d_f32 calls). */
@@ -134,6 +134,12 @@ int l2i_conv2d_wino_f32(const l2i_conv_params* p, void* stream);
 int l2i_fused_bias_act_f32(float* y, const float* x, const float* b, const float* ref, int64_t n,
                            int64_t step_b, int64_t size_b, int act, int grad, float alpha, float scale, void* stream);
 
+/* The same op for half tensors: the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF (fused_bias_act_kernel.cu:79).  y / x / b / ref
+ * point to IEEE binary16; arithmetic follows the reference's scalar_t = Half instantiation operation by operation (each binary op is
+ * the float op rounded to half; alpha and scale are rounded to half first), so results are bit-identical to it. */
+int l2i_fused_bias_act_f16(void* y, const void* x, const void* b, const void* ref, int64_t n, int64_t step_b, int64_t size_b,
+                           int act, int grad, float alpha, float scale, void* stream);
+
 /* The reference op on [major, in_h, in_w] maps (minor_dim == 1, the only layout the path uses:
  * op/upfirdn2d.py:98) with an optional fused epilogue (all NULL/0 = the plain reference op):
  *   y = act( fir(x) + noise[b,oy,ox]*noise_w + bias[c] + addend[idx] ) * act_gain,   major = b*channels + c */
@@ -141,6 +147,12 @@ int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64_t major, i
                       int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                       int channels, const float* noise, float noise_w, const float* bias, const float* addend,
                       int act, float act_slope, float act_gain, void* stream);
+
+/* upfirdn2d for half tensors (upfirdn2d_kernel.cu:225 dispatches half too): plain reference op, no fused epilogue.  y / x / k point to IEEE
+ * binary16; like the reference kernel the taps and products are float and the accumulator is rounded to half after every tap, taps in
+ * ascending input row / column order (upfirdn2d_kernel.cu:118-123): bit-identical results. */
+int l2i_upfirdn2d_f16(void* y, const void* x, const void* k, int64_t major, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
+                      int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
 /* ToRGB 1x1 modulated conv without demodulation (networks.py:346-351):
  *   rgb[b,o,p] = sum_c x[b,c,p] * wmod[b,o,c] + bias[o],  wmod = scale*W[o,c]*s[b,c] prepared by the caller [B,3,C] */

@@ -45,6 +45,8 @@ _SIGNATURES = {
     'l2i_conv_transpose2d_bf16x3_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_wino_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_fused_bias_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
+    'l2i_fused_bias_act_f16': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
+    'l2i_upfirdn2d_f16': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'l2i_upfirdn2d_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                 c_i, c_p, c_f, c_p, c_p, c_i, c_f, c_f, c_p]),
     'l2i_torgb_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),

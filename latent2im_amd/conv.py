@@ -242,7 +242,7 @@ def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), 
     entry, name, family = lib.l2i_conv_transpose2d_f32, 'l2i_conv_transpose2d_f32', 'transposed_f32'
     nat_h, nat_w = (H - 1) * 2 - 2 * F.pad + F.k, (W - 1) * 2 - 2 * F.pad + F.k
     if (PRECISION == 'bf16x3' and tile_hint == 0 and F.w_src is not None and W % 4 == 0 and W >= 32 and x.data_ptr() % 16 == 0
-            and (in_mask is None or in_mask.data_ptr() % 16 == 0) and 0 <= p.OHf - nat_h <= 1 and 0 <= p.OWf - nat_w <= 1):
+            and (in_mask is None or in_mask.data_ptr() % 16 == 0) and 0 <= p.OHf - nat_h <= 8 and 0 <= p.OWf - nat_w <= 8):
         planes = F.bf16x3_planes()
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
         entry, name, family = lib.l2i_conv_transpose2d_bf16x3_f32, 'l2i_conv_transpose2d_bf16x3_f32', 'transposed_bf16x3'

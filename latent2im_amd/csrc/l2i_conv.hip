@@ -43,6 +43,7 @@ struct ConvLaunch {
     int w_vec;                         // CK*KK*BM/4
     int vec_epi;                       // 1: LDS-transposed epilogue with 16-byte global accesses
     int lstride, gstep;                // LDS-coordinate stride of the fragment reads / global step between staged elements
+    int total;                         // blocks with work (the grid is padded to a multiple of 8 for the XCD renumbering)
     int ksplit, cin_per;               // split-K: ksplit channel ranges of cin_per (multiple of CK) channels, raw partial sums into p.ws
                                        // (stride-2 1x1 convs gather only the pixels they use: lstride 1, gstep 2)
 };
@@ -69,8 +70,11 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
     const int KK = p.KH * p.KW;
     const int TW = 1 << L.tw_log2, TH = 1 << L.th_log2;
 
-    // ---- block -> (sample group, tile, channel block) ----
-    int bid = blockIdx.x;
+    // ---- block -> (sample group, tile, channel block).  Blocks are dealt round-robin to the 8 XCDs: renumber them so that the channel
+    //      blocks of one pixel tile (and its neighbours) run back to back on ONE XCD and find the input tile in its L2 (round 1 measured
+    //      1.41x the algorithmic HBM bytes on the conv kernels: every XCD fetched every tile) ----
+    int bid = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (bid >= L.total) return;
     const int mblk = bid % L.mblocks; bid /= L.mblocks;
     const int tx = bid % L.tiles_x; bid /= L.tiles_x;
     const int ty = bid % L.tiles_y; bid /= L.tiles_y;
@@ -691,7 +695,10 @@ static bool plan_tile(const l2i_conv_params& p, int wm, int wn, ConvLaunch& L, b
                  al16(p.y) && al16(p.residual) && al16(p.res_mask) && al16(p.res_sub) && al16(p.out_mask) && al16(p.noise)) ? 1 : 0;
     if (L.vec_epi && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);      // 8 KiB transpose strip per wave
     grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks * L.ksplit;
-    return lds <= 64 * 1024 && grid > 0 && grid <= 0x7fffffffL;
+    if (!(lds <= 64 * 1024 && grid > 0 && grid <= 0x7ffffff0L)) return false;
+    L.total = (int)grid;
+    grid = (grid + 7) & ~7L;
+    return true;
 }
 
 extern "C" int l2i_conv2d_family(const l2i_conv_params* pp) {

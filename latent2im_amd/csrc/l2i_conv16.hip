@@ -488,7 +488,7 @@ extern "C" int l2i_conv_transpose2d_bf16x3_f32(const l2i_conv_params* pp, void* 
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
     const int nat = (p.H - 1) * 2 - 2 * p.pad_y + 3, natw = (p.W - 1) * 2 - 2 * p.pad_x + 3;
     if (p.KH != 3 || p.KW != 3 || p.stride != 2 || p.pad_y != p.pad_x || p.pad_x < 0 || p.pad_x > 1 || (p.Cin % 16) != 0 || (p.W % 4) != 0 || p.W < 32 ||
-        !al16(p.x) || !al16(p.in_mask) || !al16(p.w_hi) || !al16(p.w_lo) || p.ksplit > 1 || p.OHf < nat || p.OHf > nat + 1 || p.OWf < natw || p.OWf > natw + 1 ||
+        !al16(p.x) || !al16(p.in_mask) || !al16(p.w_hi) || !al16(p.w_lo) || p.ksplit > 1 || p.OHf < nat || p.OHf > nat + 8 || p.OWf < natw || p.OWf > natw + 8 ||
         p.OH != (p.OHf + 1) / 2 || p.OW != (p.OWf + 1) / 2 || p.noise || p.bias || p.residual || p.out_mask || p.accumulate || p.act != L2I_ACT_NONE ||
         (size_t)p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d_bf16x3: needs a 3x3 stride-2 layer (pad 0 or 1), Cin % 16 == 0, W % 4 == 0, W >= 32, natural output size, "

@@ -31,6 +31,7 @@ struct ConvTLaunch {
     int CK, IH, IW, IWp, planeS, plane, rows_c;
     unsigned magic_iw, magic_rc, magic_ih;
     int in_elems, w_vec;
+    int total;                         // blocks with work (grid padded to a multiple of 8)
 };
 
 __device__ __forceinline__ unsigned fast_div_t(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
@@ -56,7 +57,9 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const int TW = L.TW, TH = L.TH;
-    int bid = blockIdx.x;
+    // XCD-aware block order (see l2i_conv.hip): the channel blocks of one position tile share an XCD and its L2
+    int bid = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (bid >= L.total) return;
     const int mblk = bid % L.mblocks; bid /= L.mblocks;
     const int tx = bid % L.tiles_x; bid /= L.tiles_x;
     const int ty = bid % L.tiles_y; bid /= L.tiles_y;
@@ -435,8 +438,10 @@ static int launch_convt(const l2i_conv_params& p, hipStream_t st) {
     L.magic_ih = magic_of((unsigned)L.IH);
     size_t lds = 2 * (per_c * ck + (size_t)(((ck << L.tb_log2) + 3) & ~3) * sizeof(float));
     if (lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
-    const long grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks * L.ksplit;
-    if (grid <= 0 || grid > 0x7fffffffL) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: grid too large");
+    long grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks * L.ksplit;
+    if (grid <= 0 || grid > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: grid too large");
+    L.total = (int)grid;
+    grid = (grid + 7) & ~7L;
     if (p.in_mask) hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, true>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
     else hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, false>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
     L2I_CHECK_LAUNCH();
@@ -457,8 +462,10 @@ extern "C" int l2i_conv_transpose2d_f32(const l2i_conv_params* pp, void* stream)
     if (p.KH != p.KW || p.pad_y != p.pad_x) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: square kernels / symmetric padding only");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: CoutP must be Cout rounded up to 32");
     const int full_h = (p.H - 1) * 2 - 2 * p.pad_y + p.KH, full_w = (p.W - 1) * 2 - 2 * p.pad_x + p.KW;
-    if (p.OHf < full_h || p.OWf < full_w || p.OHf > full_h + 1 || p.OWf > full_w + 1)
-        return l2i_set_error(L2I_E_ARG, "conv_transpose2d: output must be the natural size (or one larger: output_padding)");
+    // larger than natural: the extra rows / columns (no input reaches them) are written as zeros — output_padding, and the discriminator's
+    // blur maps padded to whole 16-byte rows (latent2im_amd/discriminator.py)
+    if (p.OHf < full_h || p.OWf < full_w || p.OHf > full_h + 8 || p.OWf > full_w + 8)
+        return l2i_set_error(L2I_E_ARG, "conv_transpose2d: output must be the natural size (or up to 8 larger: zero rows / columns)");
     if (p.bias || p.noise || p.residual || p.res_mask || p.res_sub || p.out_mask || p.act != L2I_ACT_NONE || p.accumulate)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: only in_scale / in_mask / out_scale / out_gain are fused here");
     if ((((uintptr_t)p.w) % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: packed weights must be 16-byte aligned");

@@ -98,11 +98,17 @@ class _DBodyFn(torch.autograd.Function):
         cur = y0
         for blk in net.blocks:
             y1 = blk['c1'].forward(cur, bias=blk['b1'], act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
-            t = K.upfirdn2d(y1, blk['k'], pad=(2, 2, 2, 2))                    # Blur before the stride-2 3x3
-            y2 = blk['c2'].forward(t, bias=blk['b2'], act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
+            b_, _, h, _ = cur.shape
+            # Blur before the stride-2 3x3 (networks.py:530-536: pad (2,2), an (h+1)^2 map).  The map is produced (h+4)^2 instead — three
+            # more zero-padded rows / columns at the far edge that the stride-2 conv never reads — so that its rows are whole 16-byte
+            # vectors: the conv kernels stage aligned 4-pixel vectors (an odd 1025-float pitch cannot be staged that way)
+            t = K.upfirdn2d(y1, blk['k'], pad=(2, 5, 2, 5))
+            y2 = torch.empty(b_, blk['c2'].cout, h // 2, h // 2, device=cur.device, dtype=torch.float32)
+            blk['c2'].forward(t, out=y2, bias=blk['b2'], act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
             del t
-            ts = K.upfirdn2d(cur, blk['k'], pad=(1, 1, 1, 1))                  # Blur before the stride-2 1x1 skip
-            out = blk['sk'].forward(ts, residual=y2, out_gain=1.0 / SQRT2)     # (conv2 + skip) / sqrt2
+            ts = K.upfirdn2d(cur, blk['k'], pad=(1, 2, 1, 2))                  # Blur before the stride-2 1x1 skip: (h-1)^2 -> h^2 likewise
+            out = torch.empty(b_, blk['sk'].cout, h // 2, h // 2, device=cur.device, dtype=torch.float32)
+            blk['sk'].forward(ts, out=out, residual=y2, out_gain=1.0 / SQRT2)  # (conv2 + skip) / sqrt2
             del ts
             if keep:
                 saved.append((y1, y2, (cur.shape[2], cur.shape[3])))
@@ -119,14 +125,15 @@ class _DBodyFn(torch.autograd.Function):
         for blk, (y1, y2, in_hw) in zip(reversed(net.blocks), reversed(saved[1:])):
             h = in_hw[0]
             # conv2 path: lrelu' * 1/sqrt2 folded into the prologue mask
-            g_t = blk['c2'].dgrad(g, (h + 1, h + 1), in_mask=y2, mask=(1.0, 0.2))
-            g_y1 = K.upfirdn2d(g_t, blk['kf'], pad=(1, 1, 1, 1))
+            # (gradients of the padded blur maps of the forward: the extra rows / columns receive zeros and are cropped by the negative far pad)
+            g_t = blk['c2'].dgrad(g, (h + 4, h + 4), in_mask=y2, mask=(1.0, 0.2))
+            g_y1 = K.upfirdn2d(g_t, blk['kf'], pad=(1, -2, 1, -2))
             del g_t
             g_a = blk['c1'].dgrad(g_y1, in_hw, in_mask=y1, mask=LRELU_MASK)
             del g_y1
             # skip path
-            g_ts = blk['sk'].dgrad(g, (h - 1, h - 1), out_gain=1.0 / SQRT2)
-            g = K.upfirdn2d(g_ts, blk['kf'], pad=(2, 2, 2, 2), addend=g_a)
+            g_ts = blk['sk'].dgrad(g, (h, h), out_gain=1.0 / SQRT2)
+            g = K.upfirdn2d(g_ts, blk['kf'], pad=(2, 1, 2, 1), addend=g_a)
             del g_ts, g_a
         g_img = net.conv0.dgrad(g, ctx.in_hw, in_mask=saved[0], mask=LRELU_MASK)
         ctx.saved = None

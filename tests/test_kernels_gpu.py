@@ -533,3 +533,67 @@ def test_bf16x3_transposed_conv(cin, cout, pad, tr, h, w, b):
     assert [q[4] for q in launched] == ['l2i_conv_transpose2d_bf16x3_f32'], [q[4] for q in launched]
     err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
     assert err < 2e-5, err
+
+
+def test_half_precision_entry_points_of_the_reference_ops():
+    """l2i_fused_bias_act_f16 / l2i_upfirdn2d_f16 (the reference dispatches both ops for half too: fused_bias_act_kernel.cu:79,
+    upfirdn2d_kernel.cu:225) against a scalar numpy float16 execution of the reference kernel bodies: every c10::Half binary op is the
+    float op rounded to half, so the expected values are computed op by op in np.float16 — bit-exact comparison."""
+    import ctypes
+    from latent2im_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(0)
+    f16, f32 = np.float16, np.float32
+    hr = lambda a: np.asarray(a, dtype=f32).astype(f16).astype(f32)
+    x = rs.randn(2, 5, 6, 7).astype(f16)
+    b = rs.randn(5).astype(f16)
+    ref = rs.randn(2, 5, 6, 7).astype(f16)
+    xd, bd, rd = (torch.from_numpy(a).to(DEV) for a in (x, b, ref))
+    ah, sh = hr(0.2), hr(2 ** 0.5)
+    for act in (1, 3):
+        for grad in (0, 1, 2):
+            y = torch.empty_like(xd)
+            _lib.check(lib.l2i_fused_bias_act_f16(_lib.ptr(y), _lib.ptr(xd), _lib.ptr(bd) if grad == 0 else None, _lib.ptr(rd) if grad == 1 else None,
+                                                  x.size, 6 * 7, 5, act, grad, 0.2, 2 ** 0.5, _lib.stream_ptr()), 'l2i_fused_bias_act_f16')
+            v = x.astype(f32)
+            if grad == 0:
+                v = hr(v + b.astype(f32)[None, :, None, None])
+            code = act * 10 + grad
+            if code in (10, 11):
+                o = v
+            elif code in (12, 32):
+                o = np.zeros_like(v)
+            elif code == 30:
+                o = np.where(v > 0, v, hr(v * ah))
+            else:
+                o = np.where(ref.astype(f32) > 0, v, hr(v * ah))
+            want = hr(o * sh).astype(f16)
+            assert np.array_equal(y.cpu().numpy().view(np.uint16), want.view(np.uint16)), code
+    # upfirdn2d: the three modes of the path (blur, upsample-by-2, downsample-by-2) + a padded / cropped case
+    k = (np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0).astype(f16)
+    for (h, w, up, down, p0, p1, gain) in ((9, 9, 1, 1, 1, 1, 4.0), (8, 6, 2, 1, 2, 1, 4.0), (8, 8, 1, 2, 1, 1, 1.0), (7, 10, 1, 1, 2, -1, 1.0)):
+        kk = (k.astype(f32) * gain).astype(f16)
+        xi = rs.randn(3, h, w).astype(f16)
+        oh, ow = (h * up + p0 + p1 - 4) // down + 1, (w * up + p0 + p1 - 4) // down + 1
+        y = torch.empty(3, oh, ow, dtype=torch.float16, device=DEV)
+        _lib.check(lib.l2i_upfirdn2d_f16(_lib.ptr(y), _lib.ptr(torch.from_numpy(xi).to(DEV)), _lib.ptr(torch.from_numpy(kk).to(DEV)), 3, h, w, 4, 4,
+                                         up, up, down, down, p0, p1, p0, p1, _lib.stream_ptr()), 'l2i_upfirdn2d_f16')
+        kf = kk[::-1, ::-1].astype(f32)                               # sk[ky][kx] = kernel[kh-1-ky][kw-1-kx]
+        want = np.zeros((3, oh, ow), dtype=f16)
+        for m in range(3):
+            for oy in range(oh):
+                for ox in range(ow):
+                    v = f32(0)
+                    for ky in range(4):
+                        uy = oy * down - p0 + ky
+                        if uy < 0 or uy % up:
+                            continue
+                        for kx in range(4):
+                            ux = ox * down - p0 + kx
+                            if ux < 0 or ux % up:
+                                continue
+                            iy, ix = uy // up, ux // up
+                            xv = f32(xi[m, iy, ix]) if (iy < h and ix < w) else f32(0)
+                            v = f32(f16(v + xv * kf[ky, kx]))
+                    want[m, oy, ox] = f16(v)
+        assert np.array_equal(y.cpu().numpy().view(np.uint16), want.view(np.uint16)), (h, w, up, down)
