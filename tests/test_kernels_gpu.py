@@ -576,7 +576,8 @@ def test_half_precision_entry_points_of_the_reference_ops():
         xi = rs.randn(3, h, w).astype(f16)
         oh, ow = (h * up + p0 + p1 - 4) // down + 1, (w * up + p0 + p1 - 4) // down + 1
         y = torch.empty(3, oh, ow, dtype=torch.float16, device=DEV)
-        _lib.check(lib.l2i_upfirdn2d_f16(_lib.ptr(y), _lib.ptr(torch.from_numpy(xi).to(DEV)), _lib.ptr(torch.from_numpy(kk).to(DEV)), 3, h, w, 4, 4,
+        xi_d, kk_d = torch.from_numpy(xi).to(DEV), torch.from_numpy(kk).to(DEV)          # (named: the caller owns the buffers until the kernel ran)
+        _lib.check(lib.l2i_upfirdn2d_f16(_lib.ptr(y), _lib.ptr(xi_d), _lib.ptr(kk_d), 3, h, w, 4, 4,
                                          up, up, down, down, p0, p1, p0, p1, _lib.stream_ptr()), 'l2i_upfirdn2d_f16')
         kf = kk[::-1, ::-1].astype(f32)                               # sk[ky][kx] = kernel[kh-1-ky][kw-1-kx]
         want = np.zeros((3, oh, ow), dtype=f16)
