@@ -204,7 +204,9 @@ class _SynthesisFn(torch.autograd.Function):
             x = rec['x']
             hw = (x.shape[2], x.shape[3])
             if L.up:
-                dt = K.upfirdn2d(dz, L.blur_k_flip, pad=(2, 2, 2, 2))
+                # gradient of the (2H+1)^2 map under the blur, produced (2H+4)^2: three more rows / columns at the far edge that the
+                # stride-2 gradient conv never reads, so that its rows are whole 16-byte vectors (see discriminator.py)
+                dt = K.upfirdn2d(dz, L.blur_k_flip, pad=(2, 5, 2, 5))
                 del dz
                 dxmod = L.conv.dgrad(dt, hw, in_scale=demod)
                 del dt
