@@ -98,3 +98,29 @@ def test_shard_is_strided_and_checks_divisibility():
     with pytest.raises(ValueError):
         dist.shard(6, 0, 4)
     assert dist.world_size() == 1 and dist.rank() == 0
+
+
+def test_spawn_local_starts_one_fresh_process_per_rank(tmp_path):
+    """dist.spawn_local (what `python bench.py --gpus N` uses when no launcher set WORLD_SIZE): N child processes with the torchrun
+    environment, rank 0's stdout relayed, every exit code reported; the ranks form a gloo group and all-reduce."""
+    from latent2im_amd import dist
+    script = tmp_path / 'rank.py'
+    script.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from latent2im_amd import dist\n"
+        "rk, world, local = dist.init_from_env(backend='gloo')\n"
+        "t = torch.tensor([float(rk + 1)])\n"
+        "torch.distributed.all_reduce(t)\n"
+        "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and local == rk\n"
+        "if rk == 0: print('{\"sum\": %%g, \"world\": %%d}' %% (float(t), world), flush=True)\n"
+        "dist.shutdown()\n"
+        "sys.exit(3 if (len(sys.argv) > 1 and rk == 1) else 0)\n" % ROOT)
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    codes, out0 = dist.spawn_local(2, [sys.executable, str(script)], env=env, timeout=120)
+    lines = [l for l in out0.splitlines() if l.startswith('{')]      # (gloo prints a connection banner on stdout; bench.py filters the same way)
+    assert codes == [0, 0] and lines == ['{"sum": 3, "world": 2}'], out0
+    codes, _ = dist.spawn_local(2, [sys.executable, str(script), 'fail'], env=env, timeout=120)
+    assert codes == [0, 3]                                          # a failing rank is reported (bench.py then exits non-zero)

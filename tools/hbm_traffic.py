@@ -9,15 +9,42 @@ FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes 
 doubled; both factors are checked on a streaming kernel of known byte count in the same run (maxpool2x2_bwd_add_diff_kernel:
 9.25 B read, 4 B written per element; an earlier build's axpby_kernel gave 2.00 and 1.00).
 
-    python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_conv_hbm_traffic.json
+    python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_c3_hbm_traffic.json [c3|c5]
+
+Round 2: the summary also carries the bytes per launch of every conv kernel FAMILY (the unit bench.py's roofline.traffic reports for the
+dominant family), the sha256 of the libl2i_hip.so that was profiled and the workload key; bench.py drops the figure when either differs.
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
 
 CONV = ('conv_wino_kernel', 'conv_mfma_kernel', 'gemm1x1_kernel', 'convt_mfma_kernel', 'conv_direct_small_kernel',
-        'conv16_kernel', 'conv_cin3_kernel', 'splitk_epilogue_kernel')
+        'conv_bf16x3_pipe_kernel', 'conv_cin3_kernel', 'splitk_epilogue_kernel')
+WORKLOADS = {'c3': [1024, 8, ['Smiling'], 'f32', False],
+             'c5': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'bf16x3', False]}
+
+
+def family_of(kernel):
+    """rocprof kernel name -> the family names of latent2im_amd.conv.FAMILY_INFO."""
+    if kernel.startswith('conv_wino_kernel'):
+        return 'winograd_f32'
+    if kernel.startswith('conv_mfma_kernel') or kernel.startswith('splitk_epilogue'):
+        return 'implicit_gemm_f32'
+    if kernel.startswith('gemm1x1_kernel'):
+        return 'gemm1x1_f32'
+    if kernel.startswith('convt_mfma_kernel'):
+        return 'transposed_f32'
+    if kernel.startswith('conv_cin3_kernel'):
+        return 'cin3_f32'
+    if kernel.startswith('conv_direct_small_kernel'):
+        return 'direct_small_valu'
+    if kernel.startswith('conv_bf16x3_pipe_kernel'):
+        args = kernel[kernel.index('<') + 1:kernel.rindex('>')].split(',')
+        return 'transposed_bf16x3' if len(args) > 5 and args[5].strip() not in ('0',) else 'implicit_gemm_bf16x3'
+    return None
 
 
 def load(d, name):
@@ -28,7 +55,7 @@ def load(d, name):
     return out
 
 
-def main(df, dw, dst, steps=2, cal_elems=8 * 64 * 1024 * 1024):
+def main(df, dw, dst, tag='c3', steps=2, cal_elems=8 * 64 * 1024 * 1024):
     f, w = load(df, 'FETCH_SIZE'), load(dw, 'WRITE_SIZE')
     fam = collections.defaultdict(lambda: dict(launches=0, fetch_raw=0.0, write_raw=0.0))
     for i, (k, g, v) in f.items():
@@ -55,7 +82,17 @@ def main(df, dw, dst, steps=2, cal_elems=8 * 64 * 1024 * 1024):
         if any(k.startswith(c) for c in CONV):
             conv['launches'] += 0 if k.startswith('splitk_epilogue') else a['launches']      # the second pass of a split-K call is not a call
             conv['bytes'] += b
-    out = dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --serial_streams, %d steps' % steps,
+    per_family = collections.defaultdict(lambda: dict(launches=0, bytes=0.0))
+    for k, a in fam.items():
+        f_ = family_of(k)
+        if f_:
+            per_family[f_]['launches'] += 0 if k.startswith('splitk_epilogue') else a['launches']
+            per_family[f_]['bytes'] += fr * a['fetch_raw'] + fw * a['write_raw']
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'latent2im_amd', 'libl2i_hip.so')
+    out = dict(lib_sha256_16=hashlib.sha256(open(lib, 'rb').read()).hexdigest()[:16], workload=WORKLOADS[tag],
+               per_family={k: dict(launches_per_step=v['launches'] / steps, bytes_per_launch=v['bytes'] / max(v['launches'], 1),
+                                   GB_per_step=round(v['bytes'] / steps / 1e9, 3)) for k, v in per_family.items()},
+               source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --serial_streams, %d steps' % steps,
                corrections=dict(unit='KiB -> bytes', fetch_factor=fr, write_factor=fw,
                                 calibration=dict(kernel='maxpool2x2_bwd_add_diff_kernel', read_factor_measured=cal_r, write_factor_measured=cal_w,
                                                        note='known bytes / reported bytes on that kernel in the same run')),
@@ -68,4 +105,4 @@ def main(df, dw, dst, steps=2, cal_elems=8 * 64 * 1024 * 1024):
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
