@@ -197,6 +197,25 @@ int l2i_axpby_f32(float* y, const float* a, const float* b, float alpha, float b
 /* relu-masked copy: y = g * (ref > 0 ? 1 : 0) */
 int l2i_relu_mask_f32(float* y, const float* g, const float* ref, int64_t n, void* stream);
 
+/* ---- training a conv net (scene_regressor_256.py:118-171 trains the ResNet-50 regressor; the walk path never needs these) ----
+ * Weight gradient of a correlation: dw[co,ci,ky,kx] += sum_{b,oy,ox} gy[b,co,oy,ox] * x[b,ci,oy*stride+ky-pad_y,ox*stride+kx-pad_x]
+ * (out-of-range x reads as zero).  dw [Cout,Cin,KH,KW] must be zeroed (or hold the value to accumulate into) by the caller; partial sums
+ * meet by fp32 atomics, so the summation order is not fixed.  Built for KW in {1,3,7}. */
+int l2i_conv2d_wgrad_f32(float* dw, const float* x, const float* gy, int B, int Cin, int H, int W, int Cout, int OH, int OW,
+                         int KH, int KW, int stride, int pad_y, int pad_x, void* stream);
+/* BatchNorm2d in training mode on [B,C,HW] maps.  stats: sum[c] += sum x, sumsq[c] += sum x^2 in float64 (caller zeroes them).
+ * apply: y = relu?(x*scale[c] + shift[c] (+ residual)).  bwd_reduce: with dy = gy * (out_mask > 0 if given), xhat = (x-mean[c])*invstd[c]:
+ * sum_dy[c] += sum dy, sum_dyxh[c] += sum dy*xhat (float64, caller zeroes).  bwd_apply: dx = gamma[c]*invstd[c] * (dy - mean_dy[c] -
+ * xhat*mean_dyxh[c]) with mean_* = the sums / (B*HW); dy_masked (optional) receives dy (the gradient a residual branch takes). */
+int l2i_bn_stats_f32(double* sum, double* sumsq, const float* x, int B, int C, int64_t HW, void* stream);
+int l2i_bn_apply_f32(float* y, const float* x, const float* scale, const float* shift, const float* residual, int relu, int B, int C,
+                     int64_t HW, void* stream);
+int l2i_bn_bwd_reduce_f32(double* sum_dy, double* sum_dyxh, const float* gy, const float* out_mask, const float* x, const float* mean,
+                          const float* invstd, int B, int C, int64_t HW, void* stream);
+int l2i_bn_bwd_apply_f32(float* dx, float* dy_masked, const float* gy, const float* out_mask, const float* x, const float* mean,
+                         const float* invstd, const float* gamma, const float* mean_dy, const float* mean_dyxh, int B, int C, int64_t HW,
+                         void* stream);
+
 const char* l2i_last_error(void);
 int l2i_abi_version(void);
 

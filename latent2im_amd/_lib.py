@@ -58,6 +58,11 @@ _SIGNATURES = {
     'l2i_sqdiff_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p]),
     'l2i_axpby_f32': (c_i, [c_p, c_p, c_p, c_f, c_f, c_l, c_p]),
     'l2i_relu_mask_f32': (c_i, [c_p, c_p, c_p, c_l, c_p]),
+    'l2i_conv2d_wgrad_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'l2i_bn_stats_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
+    'l2i_bn_apply_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_p]),
+    'l2i_bn_bwd_reduce_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
+    'l2i_bn_bwd_apply_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
     'l2i_last_error': (ctypes.c_char_p, []),
     'l2i_abi_version': (c_i, []),
 }

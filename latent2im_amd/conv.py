@@ -42,7 +42,7 @@ def pack_weight(w):
     w = torch.as_tensor(w, dtype=torch.float32)
     cout, cin, kh, kw = w.shape
     coutp = (cout + 31) // 32 * 32
-    p = torch.zeros(cin, kh * kw, coutp, dtype=torch.float32)
+    p = torch.zeros(cin, kh * kw, coutp, dtype=torch.float32, device=w.device)      # packs where the weight lives (trainable nets repack on the GPU)
     p[:, :, :cout] = w.permute(1, 2, 3, 0).reshape(cin, kh * kw, cout)
     return p.contiguous()
 
@@ -55,7 +55,7 @@ def pack_weight_bf16x3(w):
     cout, cin, kh, kw = w.shape
     assert cin % 16 == 0
     coutp = (cout + 31) // 32 * 32
-    full = torch.zeros(coutp, cin, kh, kw, dtype=torch.float32)
+    full = torch.zeros(coutp, cin, kh, kw, dtype=torch.float32, device=w.device)
     full[:cout] = w
     hi = full.to(torch.bfloat16)
     lo = (full - hi.float()).to(torch.bfloat16)
@@ -75,10 +75,10 @@ def pack_weight_wino(w):
     w = torch.as_tensor(w, dtype=torch.float64)
     cout, cin, kh, kw = w.shape
     assert kh == 3 and kw == 3
-    G = torch.as_tensor(_WINO_G)
+    G = torch.as_tensor(_WINO_G, device=w.device)
     U = torch.einsum('ik,ockl,jl->ocij', G, w, G)                 # [Cout, Cin, 4, 4]
     coutp = (cout + 31) // 32 * 32
-    p = torch.zeros(cin, 4, coutp, 4, dtype=torch.float32)
+    p = torch.zeros(cin, 4, coutp, 4, dtype=torch.float32, device=w.device)
     p[:, :, :cout, :] = U.permute(1, 2, 0, 3).float()
     return p.contiguous()
 
@@ -360,7 +360,9 @@ class FrozenConv2d:
     y[co, 2i+k-pad] += x[ci, i] * weight[co, ci, k]  (F.conv_transpose2d(x, weight.transpose(0,1), stride=2))."""
 
     def __init__(self, weight, stride=1, padding=0, transposed=False, device='cuda'):
-        w = torch.as_tensor(np.asarray(weight) if not torch.is_tensor(weight) else weight, dtype=torch.float32).cpu()
+        w = torch.as_tensor(np.asarray(weight) if not torch.is_tensor(weight) else weight, dtype=torch.float32)
+        if not (torch.is_tensor(weight) and weight.is_cuda):        # frozen nets: numpy / CPU weights, packed once on the host
+            w = w.cpu()                                             # (a CUDA weight — a net that is being trained — is packed where it lives)
         self.cout, self.cin, self.k, _ = w.shape
         self.stride, self.padding, self.transposed = stride, padding, transposed
         wt = w.transpose(0, 1).contiguous()                       # [Cin, Cout, K, K]: roles swapped for the gradient

@@ -51,3 +51,49 @@ def vgg19_taps(P, img):
     c3 = F.conv2d(F.max_pool2d(F.relu(c2), 2, 2), P['5.weight'], P['5.bias'], padding=1)
     c4 = F.conv2d(F.relu(c3), P['7.weight'], P['7.bias'], padding=1)
     return [c1, c2, c3, c4]
+
+
+def resnet50_train_forward(P, x, momentum=0.1):
+    """The same network with BatchNorm in TRAINING mode (scene_regressor_256.py:111-153 never calls ``model.eval()``): batch statistics
+    normalise, ``running_mean`` / ``running_var`` of ``P`` are updated in place (momentum 0.1, unbiased variance), differentiable w.r.t.
+    every floating-point entry of ``P``."""
+    def bn(prefix, t):
+        return F.batch_norm(t, P[prefix + '.running_mean'], P[prefix + '.running_var'], P[prefix + '.weight'], P[prefix + '.bias'],
+                            training=True, momentum=momentum, eps=1e-5)
+    x = F.conv2d(x, P['conv1.weight'], stride=2, padding=3)
+    x = F.relu(bn('bn1', x))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, (planes, blocks, stride) in enumerate(RESNET50_LAYERS):
+        for b in range(blocks):
+            p = 'layer%d.%d' % (li + 1, b)
+            s = stride if b == 0 else 1
+            idt = x
+            o = F.relu(bn(p + '.bn1', F.conv2d(x, P[p + '.conv1.weight'])))
+            o = F.relu(bn(p + '.bn2', F.conv2d(o, P[p + '.conv2.weight'], stride=s, padding=1)))
+            o = bn(p + '.bn3', F.conv2d(o, P[p + '.conv3.weight']))
+            if b == 0:
+                idt = bn(p + '.downsample.1', F.conv2d(x, P[p + '.downsample.0.weight'], stride=s))
+            x = F.relu(o + idt)
+    x = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    return F.linear(x, P['fc.weight'], P['fc.bias'])
+
+
+def resnet50_train_step(P, data, label, lr=1e-4, steps=1):
+    """scene_regressor_256.py:147-153 restated: preds = model(data); loss = MSELoss()(preds, label).mean(); backward; Adam(lr).step() over every
+    parameter.  ``P`` (tensors) is updated in place; returns (losses, gradients of the LAST step by name)."""
+    names = [k for k, v in P.items() if v.dtype.is_floating_point and not k.endswith('running_mean') and not k.endswith('running_var')]
+    for k in names:
+        P[k].requires_grad_(True)
+    opt = torch.optim.Adam([P[k] for k in names], lr=lr)
+    losses, grads = [], {}
+    for _ in range(steps):
+        preds = resnet50_train_forward(P, data)
+        opt.zero_grad()
+        loss = F.mse_loss(preds, label).mean()
+        loss.backward()
+        grads = {k: P[k].grad.detach().clone() for k in names}
+        opt.step()
+        losses.append(loss.detach())
+    for k in names:
+        P[k].requires_grad_(False)
+    return losses, grads

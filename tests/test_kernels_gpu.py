@@ -598,3 +598,46 @@ def test_half_precision_entry_points_of_the_reference_ops():
                             v = f32(f16(v + xv * kf[ky, kx]))
                     want[m, oy, ox] = f16(v)
         assert np.array_equal(y.cpu().numpy().view(np.uint16), want.view(np.uint16)), (h, w, up, down)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,h,w,b', [(64, 64, 3, 1, 1, 16, 16, 4), (3, 64, 7, 2, 3, 64, 64, 2), (256, 64, 1, 1, 0, 8, 8, 4),
+                                                         (40, 72, 3, 2, 1, 17, 19, 3), (128, 256, 1, 2, 0, 16, 16, 2), (512, 512, 3, 1, 1, 2, 2, 8)])
+def test_conv_weight_gradient(cin, cout, k, stride, pad, h, w, b):
+    """l2i_conv2d_wgrad_f32 against torch autograd (float64): every conv shape class of ResNet-50 (7x7 stem on 3 channels, 1x1, 3x3, strides
+    1 / 2, channel counts that are not multiples of 32, tiny maps), and accumulation into a non-zero dw."""
+    from latent2im_amd import regressor_train as RT
+    rs = np.random.RandomState(cin + cout + k)
+    x = T(rs.randn(b, cin, h, w))
+    wt = T(rs.randn(cout, cin, k, k)).double().requires_grad_(True)
+    y = F.conv2d(x.double(), wt, stride=stride, padding=pad)
+    gy = T(rs.randn(*y.shape))
+    ref, = torch.autograd.grad(y, wt, gy.double())
+    dw = RT.conv_wgrad(x.to(DEV), gy.to(DEV), k, stride, pad)
+    err = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+
+
+def test_batchnorm_training_kernels():
+    """l2i_bn_stats / apply / bwd_reduce / bwd_apply through regressor_train._BN against torch's training-mode batch_norm + relu (+ residual)
+    and autograd, including the running-statistics update."""
+    from latent2im_amd import regressor_train as RT
+    rs = np.random.RandomState(1)
+    B, Cn, H, W = 4, 24, 9, 7
+    x, res, gy = T(rs.randn(B, Cn, H, W) * 2 + 0.5), T(rs.randn(B, Cn, H, W)), T(rs.randn(B, Cn, H, W))
+    P = {'bn.weight': rs.rand(Cn).astype(np.float32) + 0.5, 'bn.bias': rs.randn(Cn).astype(np.float32), 'bn.running_mean': rs.randn(Cn).astype(np.float32),
+         'bn.running_var': rs.rand(Cn).astype(np.float32) + 0.5}
+    bn = RT._BN(P, 'bn', DEV)
+    xr = x.double().requires_grad_(True)
+    gam, bet = T(P['bn.weight']).double().requires_grad_(True), T(P['bn.bias']).double().requires_grad_(True)
+    rm, rv = T(P['bn.running_mean']).double(), T(P['bn.running_var']).double()
+    yr = torch.relu(F.batch_norm(xr, rm, rv, gam, bet, training=True, momentum=0.1, eps=1e-5) + res.double())
+    gx_r, gg_r, gb_r = torch.autograd.grad(yr, (xr, gam, bet), gy.double())
+    y, saved = bn.forward(x.to(DEV), residual=res.to(DEV), relu=True)
+    close(y, yr, 1e-5, 1e-5)
+    close(bn.running_mean, rm, 1e-5, 1e-6)
+    close(bn.running_var, rv, 1e-5, 1e-6)
+    dx, dg, db, gm = bn.backward(gy.to(DEV), saved, out_mask=y, want_masked=True)
+    close(dx, gx_r, 1e-4, 1e-5)
+    close(dg, gg_r, 1e-4, 1e-4)
+    close(db, gb_r, 1e-4, 1e-4)
+    close(gm, gy.double() * (yr > 0), 0, 0)

@@ -713,3 +713,64 @@ def test_hipgraph_captured_step_matches_eager(precision):
         assert relmax(eager[0]['grad'], o['grad']) < 2e-2
     finally:
         constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
+def test_regressor_training_step_vs_oracle(tmp_path):
+    """SURVEY 8(f-4), scene_regressor_256.py:118-171: two optimiser steps of the ResNet-50 regressor (BatchNorm in training mode, MSE loss,
+    Adam over every parameter) on the HIP kernels — weight gradients by l2i_conv2d_wgrad_f32, BatchNorm by l2i_bn_* — against the CPU
+    oracle (torch autograd on the restated network): loss, every parameter gradient, the running statistics and the parameters after Adam;
+    then the checkpoint round trip in the reference's {'model', 'optm'} format, loaded as the frozen regressor of the walk path."""
+    from latent2im_amd import regressor_train as RT
+    rs = np.random.RandomState(5)
+    st = synth.resnet50_state(seed=300)
+    data = T(rs.randn(4, 3, 64, 64).astype(np.float32) * 0.5)
+    label = T(rs.rand(4, 40).astype(np.float32))
+    model = RT.TrainableResNet50(st, device=DEV)
+    opt = RT.make_optimizer(model, lr=1e-4)
+    P = ostep.to_torch(st)
+    P = {k: v.clone() for k, v in P.items()}
+    lo1, g1 = onets.resnet50_train_step(P, data, label, lr=1e-4, steps=1)
+    # step 1 on the GPU, gradients captured before Adam consumes them
+    preds = model(data.to(DEV))
+    loss, g = RT.mse_loss_and_grad(preds, label.to(DEV))
+    grads = model.backward(g)
+    close(loss, lo1[0], 1e-4, 1e-6)
+    worst = 0.0
+    for k, want in g1.items():
+        got = grads[k].detach().cpu().double()
+        scale = float(want.abs().max()) + 1e-12
+        worst = max(worst, float((got - want.double()).abs().max()) / scale)
+        assert float((got - want.double()).abs().max()) <= 2e-3 * scale + 1e-7, (k, float((got - want.double()).abs().max()) / scale)
+    print('regressor training: worst parameter-gradient error relative to the largest entry of that parameter: %.2e' % worst)
+    # the whole step through train_step (a fresh model: the statistics above were already updated once)
+    model = RT.TrainableResNet50(st, device=DEV)
+    opt = RT.make_optimizer(model, lr=1e-4)
+    l1 = RT.train_step(model, opt, data.to(DEV), label.to(DEV))
+    close(l1, lo1[0], 1e-4, 1e-6)
+    sd = model.state_dict()
+    for k in ('bn1.running_mean', 'bn1.running_var', 'layer2.0.downsample.1.running_var', 'layer4.2.bn3.running_mean'):
+        close(sd[k], P[k], 1e-3, 1e-5)
+    assert int(sd['bn1.num_batches_tracked']) == 1
+    # Adam's first step moves every entry by ~lr * sign(g): compare where the gradient is clearly non-zero
+    for k in ('conv1.weight', 'layer1.0.conv2.weight', 'layer3.5.conv3.weight', 'layer4.0.downsample.0.weight', 'fc.weight', 'layer2.1.bn2.weight'):
+        w0 = T(np.asarray(st[k])).double()
+        moved_ref, moved = P[k].detach().double() - w0, sd[k].cpu().double() - w0
+        gk = g1[k].double()
+        clear = gk.abs() > 0.05 * gk.abs().max()
+        assert float((moved - moved_ref)[clear].abs().max()) < 0.05e-4 and float(moved_ref[clear].abs().min()) > 0.5e-4, k
+    # a second step: the loss must have been computed on the updated parameters and statistics (compared with the oracle's own second
+    # forward; its Adam state restarts, which does not enter the loss)
+    lo2, _ = onets.resnet50_train_step(P, data, label, lr=1e-4, steps=1)
+    l2 = RT.train_step(model, opt, data.to(DEV), label.to(DEV))
+    close(l2, lo2[0], 2e-3, 1e-6)
+    assert int(model.state_dict()['bn1.num_batches_tracked']) == 2
+    # checkpoint in the reference's format -> the frozen regressor of the walk path
+    path = str(tmp_path / '001_dict.model')
+    RT.save_ckpt(path, model, opt)
+    ck = torch.load(path, map_location='cpu')
+    assert set(ck) == {'model', 'optm'} and 'layer4.2.bn3.running_var' in ck['model'] and ck['model']['fc.weight'].shape == (40, 2048)
+    frozen = ResNet50({k: v.numpy() for k, v in ck['model'].items()}, device=DEV)
+    close(frozen(data.to(DEV)), onets.resnet50_forward({k: v.float() for k, v in ck['model'].items()}, data))      # eval-mode use by the walk path
+    fresh = RT.TrainableResNet50(st, device=DEV)
+    m2, _ = RT.load_ckpt(path, fresh, RT.make_optimizer(fresh))
+    assert torch.equal(m2.state_dict()['layer1.0.conv1.weight'].cpu(), ck['model']['layer1.0.conv1.weight'])
