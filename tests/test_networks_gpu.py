@@ -723,25 +723,29 @@ def test_regressor_training_step_vs_oracle(tmp_path):
     from latent2im_amd import regressor_train as RT
     rs = np.random.RandomState(5)
     st = synth.resnet50_state(seed=300)
-    data = T(rs.randn(4, 3, 64, 64).astype(np.float32) * 0.5)
-    label = T(rs.rand(4, 40).astype(np.float32))
+    data = T(rs.randn(8, 3, 128, 128).astype(np.float32) * 0.5)
+    label = T(rs.rand(8, 40).astype(np.float32))
     model = RT.TrainableResNet50(st, device=DEV)
-    opt = RT.make_optimizer(model, lr=1e-4)
-    P = ostep.to_torch(st)
-    P = {k: v.clone() for k, v in P.items()}
+    # the exact value: the oracle in float64; the yardstick: the oracle's own float32 run.  A random-init ResNet-50 with batch statistics
+    # over a handful of values per channel is badly conditioned — the float32 oracle is up to ~7 % of the largest entry away from
+    # float64 on some conv3 / bn3 gradients — so each parameter gets the bar of tests/test_oracle_golden.py: max(2 x oracle32, 5e-3)
+    P64 = {k: v.clone() for k, v in ostep.to_torch(st, torch.float64).items()}
+    _, g64 = onets.resnet50_train_step(P64, data.double(), label.double(), lr=1e-4, steps=1)
+    P = {k: v.clone() for k, v in ostep.to_torch(st).items()}
     lo1, g1 = onets.resnet50_train_step(P, data, label, lr=1e-4, steps=1)
     # step 1 on the GPU, gradients captured before Adam consumes them
     preds = model(data.to(DEV))
     loss, g = RT.mse_loss_and_grad(preds, label.to(DEV))
     grads = model.backward(g)
     close(loss, lo1[0], 1e-4, 1e-6)
-    worst = 0.0
-    for k, want in g1.items():
-        got = grads[k].detach().cpu().double()
-        scale = float(want.abs().max()) + 1e-12
-        worst = max(worst, float((got - want.double()).abs().max()) / scale)
-        assert float((got - want.double()).abs().max()) <= 2e-3 * scale + 1e-7, (k, float((got - want.double()).abs().max()) / scale)
-    print('regressor training: worst parameter-gradient error relative to the largest entry of that parameter: %.2e' % worst)
+    worst = (0.0, 0.0, '')
+    for k, want in g64.items():
+        scale = float(want.abs().max()) + 1e-300
+        e_hip = float((grads[k].detach().cpu().double() - want).abs().max()) / scale
+        e_o32 = float((g1[k].double() - want).abs().max()) / scale
+        worst = max(worst, (e_hip, e_o32, k))
+        assert e_hip <= max(2 * e_o32, 5e-3), (k, e_hip, e_o32)
+    print('regressor training: worst parameter-gradient error vs the float64 oracle, relative to the largest entry: %.2e (float32 oracle: %.2e) at %s' % worst)
     # the whole step through train_step (a fresh model: the statistics above were already updated once)
     model = RT.TrainableResNet50(st, device=DEV)
     opt = RT.make_optimizer(model, lr=1e-4)
