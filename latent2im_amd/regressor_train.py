@@ -209,36 +209,44 @@ class TrainableResNet50:
         grads = {'fc.weight': torch.mm(g_preds.t(), sv['feat']), 'fc.bias': g_preds.sum(0)}
         b, c, h, w = sv['last']
         g = (torch.mm(g_preds, self.fc_w) * (1.0 / (h * w))).reshape(b, c, 1, 1).expand(b, c, h, w).contiguous()
-        for blk, (cur, y1, s1, y2, s2, s3, sd, out) in zip(reversed(self.blocks), reversed(sv['blocks'])):
-            in_hw = (cur.shape[2], cur.shape[3])
-            # out = relu(bn3(z3) + idt): the masked gradient feeds bn3 and the identity branch
-            g_z3, dw, db, gm = blk['b3'].backward(g, s3, out_mask=out, want_masked=True)
-            grads[blk['b3'].name + '.weight'], grads[blk['b3'].name + '.bias'] = dw, db
-            grads[blk['c3'].name + '.weight'] = blk['c3'].wgrad(y2, g_z3)
-            g_y2 = blk['c3'].dgrad(g_z3, (y2.shape[2], y2.shape[3]))
-            g_z2, dw, db, _ = blk['b2'].backward(g_y2, s2, out_mask=y2)
-            grads[blk['b2'].name + '.weight'], grads[blk['b2'].name + '.bias'] = dw, db
-            grads[blk['c2'].name + '.weight'] = blk['c2'].wgrad(y1, g_z2)
-            g_y1 = blk['c2'].dgrad(g_z2, (y1.shape[2], y1.shape[3]))
-            g_z1, dw, db, _ = blk['b1'].backward(g_y1, s1, out_mask=y1)
-            grads[blk['b1'].name + '.weight'], grads[blk['b1'].name + '.bias'] = dw, db
-            grads[blk['c1'].name + '.weight'] = blk['c1'].wgrad(cur, g_z1)
-            g_in = blk['c1'].dgrad(g_z1, in_hw)
-            if blk['cd'] is not None:
-                g_zd, dw, db, _ = blk['bd'].backward(gm, sd)
-                grads[blk['bd'].name + '.weight'], grads[blk['bd'].name + '.bias'] = dw, db
-                grads[blk['cd'].name + '.weight'] = blk['cd'].wgrad(cur, g_zd)
-                g_in = K.axpby(g_in, blk['cd'].dgrad(g_zd, in_hw))
-            else:
-                g_in = K.axpby(g_in, gm)
-            g = g_in
+        for blk, saved in zip(reversed(self.blocks), reversed(sv['blocks'])):
+            g = self.block_backward(blk, saved, g, grads)
+        self.stem_backward(sv, g, grads)
+        self._saved = None
+        return grads
+
+    @staticmethod
+    def block_backward(blk, saved, g, grads):
+        """One bottleneck block: g = dL/d(block output) -> dL/d(block input); parameter gradients are added to ``grads`` by name."""
+        cur, y1, s1, y2, s2, s3, sd, out = saved
+        in_hw = (cur.shape[2], cur.shape[3])
+        # out = relu(bn3(z3) + idt): the masked gradient feeds bn3 and the identity branch
+        g_z3, dw, db, gm = blk['b3'].backward(g, s3, out_mask=out, want_masked=True)
+        grads[blk['b3'].name + '.weight'], grads[blk['b3'].name + '.bias'] = dw, db
+        grads[blk['c3'].name + '.weight'] = blk['c3'].wgrad(y2, g_z3)
+        g_y2 = blk['c3'].dgrad(g_z3, (y2.shape[2], y2.shape[3]))
+        g_z2, dw, db, _ = blk['b2'].backward(g_y2, s2, out_mask=y2)
+        grads[blk['b2'].name + '.weight'], grads[blk['b2'].name + '.bias'] = dw, db
+        grads[blk['c2'].name + '.weight'] = blk['c2'].wgrad(y1, g_z2)
+        g_y1 = blk['c2'].dgrad(g_z2, (y1.shape[2], y1.shape[3]))
+        g_z1, dw, db, _ = blk['b1'].backward(g_y1, s1, out_mask=y1)
+        grads[blk['b1'].name + '.weight'], grads[blk['b1'].name + '.bias'] = dw, db
+        grads[blk['c1'].name + '.weight'] = blk['c1'].wgrad(cur, g_z1)
+        g_in = blk['c1'].dgrad(g_z1, in_hw)
+        if blk['cd'] is not None:
+            g_zd, dw, db, _ = blk['bd'].backward(gm, sd)
+            grads[blk['bd'].name + '.weight'], grads[blk['bd'].name + '.bias'] = dw, db
+            grads[blk['cd'].name + '.weight'] = blk['cd'].wgrad(cur, g_zd)
+            return K.axpby(g_in, blk['cd'].dgrad(g_zd, in_hw))
+        return K.axpby(g_in, gm)
+
+    def stem_backward(self, sv, g, grads):
+        """maxpool <- relu <- bn1 <- conv1: g = dL/d(pooled map); the image itself gets no gradient."""
         a0 = sv['a0']
         g_a0 = K.maxpool2d_bwd(g, sv['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1)
         g_z0, dw, db, _ = self.stem_bn.backward(g_a0, sv['s0'], out_mask=a0)
         grads['bn1.weight'], grads['bn1.bias'] = dw, db
         grads['conv1.weight'] = self.stem.wgrad(sv['img'], g_z0)
-        self._saved = None
-        return grads
 
 
 def mse_loss_and_grad(preds, label):

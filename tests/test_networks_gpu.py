@@ -716,36 +716,73 @@ def test_hipgraph_captured_step_matches_eager(precision):
 
 
 def test_regressor_training_step_vs_oracle(tmp_path):
-    """SURVEY 8(f-4), scene_regressor_256.py:118-171: two optimiser steps of the ResNet-50 regressor (BatchNorm in training mode, MSE loss,
+    """SURVEY 8(f-4), scene_regressor_256.py:118-171: optimiser steps of the ResNet-50 regressor (BatchNorm in training mode, MSE loss,
     Adam over every parameter) on the HIP kernels — weight gradients by l2i_conv2d_wgrad_f32, BatchNorm by l2i_bn_* — against the CPU
-    oracle (torch autograd on the restated network): loss, every parameter gradient, the running statistics and the parameters after Adam;
-    then the checkpoint round trip in the reference's {'model', 'optm'} format, loaded as the frozen regressor of the walk path."""
+    oracle (torch autograd on the restated network).
+
+    Gradients are checked at two levels.  (1) EXACTLY, block by block: the stem and three bottleneck blocks (with / without downsample,
+    stride 1 / 2) are back-propagated on the GPU from their saved inputs and a random incoming gradient, and compared with float64 autograd
+    of the same block on the same inputs: every parameter gradient and the input gradient to 1e-4 of its largest entry.  (2) END TO END
+    against the float64 oracle.  With batch statistics over 128 values per channel in the last layer a single ReLU flipped by float32
+    rounding moves that channel's gradients by ~1 % (the float32 CPU oracle itself is up to 7 % away from float64 on some tensors), so the
+    whole-network comparison is in norms: cosine similarity >= 0.999 and relative L2 error <= 5 % per parameter tensor."""
+    import torch.nn.functional as F
     from latent2im_amd import regressor_train as RT
     rs = np.random.RandomState(5)
     st = synth.resnet50_state(seed=300)
     data = T(rs.randn(8, 3, 128, 128).astype(np.float32) * 0.5)
     label = T(rs.rand(8, 40).astype(np.float32))
     model = RT.TrainableResNet50(st, device=DEV)
-    # the exact value: the oracle in float64; the yardstick: the oracle's own float32 run.  A random-init ResNet-50 with batch statistics
-    # over a handful of values per channel is badly conditioned — the float32 oracle is up to ~7 % of the largest entry away from
-    # float64 on some conv3 / bn3 gradients — so each parameter gets the bar of tests/test_oracle_golden.py: max(2 x oracle32, 5e-3)
     P64 = {k: v.clone() for k, v in ostep.to_torch(st, torch.float64).items()}
     _, g64 = onets.resnet50_train_step(P64, data.double(), label.double(), lr=1e-4, steps=1)
     P = {k: v.clone() for k, v in ostep.to_torch(st).items()}
     lo1, g1 = onets.resnet50_train_step(P, data, label, lr=1e-4, steps=1)
-    # step 1 on the GPU, gradients captured before Adam consumes them
     preds = model(data.to(DEV))
+    sv = model._saved
     loss, g = RT.mse_loss_and_grad(preds, label.to(DEV))
-    grads = model.backward(g)
     close(loss, lo1[0], 1e-4, 1e-6)
-    worst = (0.0, 0.0, '')
+    D = lambda t: t.detach().double().cpu()
+    rel = lambda a, b: float((D(a) - b.detach()).abs().max() / b.detach().abs().max())
+    # (1) block-level exactness
+    for bi in (0, 3, 4, 15):
+        blk, saved = model.blocks[bi], sv['blocks'][bi]
+        cur, y1, s1, y2, s2, s3, sd, out = saved
+        gin = torch.randn(out.shape, generator=torch.Generator().manual_seed(bi)).to(DEV)
+        grads = {}
+        gx = RT.TrainableResNet50.block_backward(blk, saved, gin, grads)
+        x = D(cur).requires_grad_(True)
+        prm = {}
+        for c_, b_ in (('c1', 'b1'), ('c2', 'b2'), ('c3', 'b3'), ('cd', 'bd')):
+            if blk[c_] is not None:
+                prm[blk[c_].name + '.weight'] = D(blk[c_].weight).requires_grad_(True)
+                prm[blk[b_].name + '.weight'], prm[blk[b_].name + '.bias'] = D(blk[b_].weight).requires_grad_(True), D(blk[b_].bias).requires_grad_(True)
+        bn = lambda t, b_: F.batch_norm(t, None, None, prm[blk[b_].name + '.weight'], prm[blk[b_].name + '.bias'], training=True, eps=1e-5)
+        cv = lambda t, c_: F.conv2d(t, prm[blk[c_].name + '.weight'], stride=blk[c_].stride, padding=blk[c_].padding)
+        o = bn(cv(F.relu(bn(cv(F.relu(bn(cv(x, 'c1'), 'b1')), 'c2'), 'b2')), 'c3'), 'b3')
+        o = F.relu(o + (bn(cv(x, 'cd'), 'bd') if blk['cd'] is not None else x))
+        assert int((D(out) > 0).ne(o > 0).sum()) == 0                            # same ReLU pattern: the comparison below is exact arithmetic
+        ref = torch.autograd.grad(o, [x] + list(prm.values()), D(gin))
+        assert rel(gx, ref[0]) < 1e-4, (bi, 'input', rel(gx, ref[0]))
+        for k, r in zip(prm, ref[1:]):
+            assert rel(grads[k], r) < 1e-4, (bi, k, rel(grads[k], r))
+    gpool = torch.randn(sv['blocks'][0][0].shape, generator=torch.Generator().manual_seed(99)).to(DEV)
+    grads = {}
+    model.stem_backward(sv, gpool, grads)
+    w0, gam, bet = D(model.stem.weight).requires_grad_(True), D(model.stem_bn.weight).requires_grad_(True), D(model.stem_bn.bias).requires_grad_(True)
+    o = F.max_pool2d(F.relu(F.batch_norm(F.conv2d(D(data), w0, stride=2, padding=3), None, None, gam, bet, training=True, eps=1e-5)), 3, 2, 1)
+    for k, r in zip(('conv1.weight', 'bn1.weight', 'bn1.bias'), torch.autograd.grad(o, (w0, gam, bet), D(gpool))):
+        assert rel(grads[k], r) < 1e-4, (k, rel(grads[k], r))
+    # (2) end to end against the float64 oracle, in norms
+    grads = model.backward(g)
+    worst = (1.0, 0.0, '')
     for k, want in g64.items():
-        scale = float(want.abs().max()) + 1e-300
-        e_hip = float((grads[k].detach().cpu().double() - want).abs().max()) / scale
-        e_o32 = float((g1[k].double() - want).abs().max()) / scale
-        worst = max(worst, (e_hip, e_o32, k))
-        assert e_hip <= max(2 * e_o32, 5e-3), (k, e_hip, e_o32)
-    print('regressor training: worst parameter-gradient error vs the float64 oracle, relative to the largest entry: %.2e (float32 oracle: %.2e) at %s' % worst)
+        got = D(grads[k]).reshape(-1)
+        w_ = want.reshape(-1)
+        cos = float(torch.dot(got, w_) / (got.norm() * w_.norm() + 1e-300))
+        l2 = float((got - w_).norm() / (w_.norm() + 1e-300))
+        worst = min(worst, (cos, l2, k))
+        assert cos >= 0.999 and l2 <= 5e-2, (k, cos, l2)
+    print('regressor training: lowest cosine similarity with the float64 oracle gradient %.6f (relative L2 error %.2e) at %s' % worst)
     # the whole step through train_step (a fresh model: the statistics above were already updated once)
     model = RT.TrainableResNet50(st, device=DEV)
     opt = RT.make_optimizer(model, lr=1e-4)
