@@ -303,14 +303,12 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         planes = L.bf16x3_planes()
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
         entry, name = lib.l2i_conv2d_bf16x3_f32, 'l2i_conv2d_bf16x3_f32'
-    elif L.kh * L.kw > 1 and L.cout > 4:
-        _split_k(p, B * OH * OW, cin, y)
-    if name != 'l2i_conv2d_f32':
-        pass
     elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
           and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise, res_sub)):
         p.w = _lib.fptr(L.wino_pack())
         entry, name = lib.l2i_conv2d_wino_f32, 'l2i_conv2d_wino_f32'
+    elif L.kh * L.kw > 1 and L.cout > 4:
+        _split_k(p, B * OH * OW, cin, y)                  # small maps of the generic kernel (the Winograd / split-precision kernels take maps >= 32 wide)
     if PROFILE is not None:
         family = {'l2i_conv2d_wino_f32': 'winograd_f32', 'l2i_conv2d_bf16x3_f32': 'implicit_gemm_bf16x3'}.get(name)
         if family is None:

@@ -645,7 +645,10 @@ def test_data_parallel_product_graph_matches_single_process(tmp_path, no_gan):
     assert codes == [0, 0], codes
     a, b = np.load(single), np.load(multi)
     assert int(a['world']) == 1 and int(b['world']) == 2
-    close(b['losses'], a['losses'], 1e-4, 1e-6)                       # total, reg, content (, gan): mean of shard means == global mean
+    close(b['losses'][0], a['losses'][0], 1e-4, 1e-6)                 # total, reg, content (, gan): mean of shard means == global mean
+    # the second step starts from the walk Adam produced: ~ lr * sign(g) per entry, so entries whose gradient is within rounding of
+    # zero may have stepped the other way (see below) and the small content term sees it at the 1e-4 level
+    close(b['losses'][1], a['losses'][1], 1e-3, 1e-6)
     for s in range(2):
         grad_ok(T(b['grads'][s]), T(a['grads'][s]))                   # same samples, different tile shapes: a few flipped masks at most
         assert relmax(T(b['grads'][s]), T(a['grads'][s])) < 2e-2
