@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "l2i.h"
 #include "l2i_internal.h"
 
@@ -22,8 +23,8 @@ namespace gm {
 constexpr int CK = 16, CKh = 8, BN = 256;              // channels per chunk, pixels per block (4 waves x 64)
 }
 
-template <int WM, bool MASK>
-__global__ __launch_bounds__(256, MASK ? 2 : 3) void gemm1x1_kernel(const l2i_conv_params p, int tiles, int mblocks, int total) {
+template <int WM, bool MASK, int NOPS>
+__global__ __launch_bounds__(256, (MASK || NOPS > 0) ? 2 : 3) void gemm1x1_kernel(const l2i_conv_params p, int tiles, int mblocks, int total) {
     using namespace gm;
     constexpr int BM = WM * 32;
     constexpr int XS = CK * BN, MS = MASK ? CK * BN : 0, WS = CK * BM, STAGE = XS + MS + WS;     // floats per stage: x | gradient mask | w
@@ -117,60 +118,118 @@ __global__ __launch_bounds__(256, MASK ? 2 : 3) void gemm1x1_kernel(const l2i_co
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (null-descriptor DMA of the last chunk)
     __syncthreads();                                       // the stages become the transpose strips
 
-    // ---- epilogue (as l2i_conv.hip, epilogue A): per-wave LDS transpose -> 16-byte global accesses ----
+    // ---- epilogue (as l2i_conv.hip, epilogue A): per-wave LDS transpose -> 16-byte global accesses.  NOPS > 0: the global operands of
+    // the fused terms (up to NOPS of: output mask, residual, res_sub, residual mask, the old y of an accumulating launch; the host picks
+    // the instantiation by counting them) are fetched one group of four channel rows AHEAD of the group being finished.  With Cin =
+    // 64 .. 256 this kernel is a streaming kernel whose K loop is shorter than its epilogue, and the load -> use -> store chain of the
+    // plain loop (NOPS = 0: launches without such operands, or with more than two) exposes one HBM round trip per row pair ----
     float* reg = smem + wave * (32 * 64);                  // [32 channels][64 pixels] of this wave
     const int ch_l = lane >> 4, px = (lane & 15) * 4;
     const size_t pix = (size_t)px0 + wave * 64 + px;
     const bool pok = pix < HW;
-#pragma unroll
-    for (int m = 0; m < WM; ++m) {
+    const float rc = p.res_sub ? p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) : 1.f;
+    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pok && p.noise) {
+        nz = *reinterpret_cast<const float4*>(p.noise + (size_t)b * HW + pix);
+        nz.x *= p.noise_w; nz.y *= p.noise_w; nz.z *= p.noise_w; nz.w *= p.noise_w;
+    }
+    // one output vector: v = 4 pixels of channel co straight from the accumulators; om / rv / sb / rm / yo = the operand vectors (only read
+    // when the operand exists)
+    auto apply = [&](float4 v, int co, size_t oidx, const float4& om, float4 rv, const float4& sb, const float4& rm, const float4& yo) {
+        if (p.out_scale) { const float sc = p.out_scale[(size_t)b * p.Cout + co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+        if (p.out_mask) { v.x = om.x > 0.f ? v.x : 0.f; v.y = om.y > 0.f ? v.y : 0.f; v.z = om.z > 0.f ? v.z : 0.f; v.w = om.w > 0.f ? v.w : 0.f; }
+        v.x += nz.x; v.y += nz.y; v.z += nz.z; v.w += nz.w;
+        if (p.bias) { const float bv = p.bias[co]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
+        if (p.residual) {
+            if (p.res_sub) { rv.x = rc * (rv.x - sb.x); rv.y = rc * (rv.y - sb.y); rv.z = rc * (rv.z - sb.z); rv.w = rc * (rv.w - sb.w); }   // res_coef * (residual - res_sub)
+            if (p.res_mask) { rv.x = rm.x > 0.f ? rv.x : 0.f; rv.y = rm.y > 0.f ? rv.y : 0.f; rv.z = rm.z > 0.f ? rv.z : 0.f; rv.w = rm.w > 0.f ? rv.w : 0.f; }
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (p.act == L2I_ACT_LRELU) {
+            v.x = (v.x > 0.f ? v.x : v.x * p.act_slope) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.act_slope) * p.act_gain;
+            v.z = (v.z > 0.f ? v.z : v.z * p.act_slope) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.act_slope) * p.act_gain;
+        } else if (p.act == L2I_ACT_RELU) {
+            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        }
+        v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain;
+        if (p.accumulate) { v.x += yo.x; v.y += yo.y; v.z += yo.z; v.w += yo.w; }
+        *reinterpret_cast<float4*>(p.y + oidx) = v;
+    };
+    auto to_strip = [&](int m) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) reg[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + q * 32 + j] = acc[m][q][r];
+    };
+    if constexpr (NOPS == 0) {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            to_strip(m);
 #pragma unroll 2
-        for (int i = 0; i < 8; ++i) {
-            const int chn = i * 4 + ch_l;
-            const int co = m0 + m * 32 + chn;
-            float4 v = *reinterpret_cast<const float4*>(&reg[chn * 64 + px]);
-            if (pok && co < p.Cout) {
-                if (p.out_scale) { const float sc = p.out_scale[(size_t)b * p.Cout + co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
-                const size_t oidx = ((size_t)b * p.Cout + co) * HW + pix;
-                if (p.out_mask) {
-                    const float4 mk = *reinterpret_cast<const float4*>(p.out_mask + oidx);
-                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+            for (int i = 0; i < 8; ++i) {
+                const int chn = i * 4 + ch_l;
+                const int co = m0 + m * 32 + chn;
+                const float4 v = *reinterpret_cast<const float4*>(&reg[chn * 64 + px]);
+                if (pok && co < p.Cout) {
+                    const size_t oidx = ((size_t)b * p.Cout + co) * HW + pix;
+                    apply(v, co, oidx, p.out_mask ? *reinterpret_cast<const float4*>(p.out_mask + oidx) : z4,
+                          p.residual ? *reinterpret_cast<const float4*>(p.residual + oidx) : z4,
+                          p.res_sub ? *reinterpret_cast<const float4*>(p.res_sub + oidx) : z4,
+                          p.res_mask ? *reinterpret_cast<const float4*>(p.res_mask + oidx) : z4,
+                          p.accumulate ? *reinterpret_cast<const float4*>(p.y + oidx) : z4);
                 }
-                if (p.noise) {
-                    const float4 nz = *reinterpret_cast<const float4*>(p.noise + (size_t)b * HW + pix);
-                    v.x += nz.x * p.noise_w; v.y += nz.y * p.noise_w; v.z += nz.z * p.noise_w; v.w += nz.w * p.noise_w;
-                }
-                if (p.bias) { const float bv = p.bias[co]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
-                if (p.residual) {
-                    float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
-                    if (p.res_sub) {                                   // residual term = res_coef * (residual - res_sub)
-                        const float4 sb = *reinterpret_cast<const float4*>(p.res_sub + oidx);
-                        const float rc = p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f);
-                        rv.x = rc * (rv.x - sb.x); rv.y = rc * (rv.y - sb.y); rv.z = rc * (rv.z - sb.z); rv.w = rc * (rv.w - sb.w);
-                    }
-                    if (p.res_mask) {
-                        const float4 mk = *reinterpret_cast<const float4*>(p.res_mask + oidx);
-                        rv.x = mk.x > 0.f ? rv.x : 0.f; rv.y = mk.y > 0.f ? rv.y : 0.f; rv.z = mk.z > 0.f ? rv.z : 0.f; rv.w = mk.w > 0.f ? rv.w : 0.f;
-                    }
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                }
-                if (p.act == L2I_ACT_LRELU) {
-                    v.x = (v.x > 0.f ? v.x : v.x * p.act_slope) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.act_slope) * p.act_gain;
-                    v.z = (v.z > 0.f ? v.z : v.z * p.act_slope) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.act_slope) * p.act_gain;
-                } else if (p.act == L2I_ACT_RELU) {
-                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-                }
-                v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain;
-                if (p.accumulate) {
-                    const float4 o = *reinterpret_cast<const float4*>(p.y + oidx);
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                }
-                *reinterpret_cast<float4*>(p.y + oidx) = v;
             }
+        }
+    } else {
+        // operand slots in canonical order; the host guarantees that at most NOPS exist
+        const float* cand[5] = {p.out_mask, p.residual, p.res_sub, p.res_mask, p.accumulate ? p.y : nullptr};
+        int slot[5];
+        const float* sp0 = nullptr;
+        const float* sp1 = nullptr;
+        int k = 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            slot[c] = cand[c] ? k++ : -1;
+            if (slot[c] == 0) sp0 = cand[c];
+            if (slot[c] == 1) sp1 = cand[c];
+        }
+        const int s_om = slot[0], s_rv = slot[1], s_sb = slot[2], s_rm = slot[3], s_yo = slot[4];
+        struct Ops { float4 s[NOPS][4]; };
+        auto fetch = [&](int g, Ops& o) {                  // group g = channel rows ((g & 1) * 4 + i) * 4 + ch_l of channel block g >> 1
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = m0 + (g >> 1) * 32 + ((g & 1) * 4 + i) * 4 + ch_l;
+                const size_t oidx = ((size_t)b * p.Cout + co) * HW + pix;
+#pragma unroll
+                for (int t = 0; t < NOPS; ++t) {
+                    const float* sp = t == 0 ? sp0 : sp1;
+                    o.s[t][i] = (pok && co < p.Cout && sp) ? *reinterpret_cast<const float4*>(sp + oidx) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        auto finish = [&](int g, const Ops& o) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int chn = ((g & 1) * 4 + i) * 4 + ch_l;
+                const int co = m0 + (g >> 1) * 32 + chn;
+                const float4 v = *reinterpret_cast<const float4*>(&reg[chn * 64 + px]);
+                if (pok && co < p.Cout) {
+                    const size_t oidx = ((size_t)b * p.Cout + co) * HW + pix;
+                    auto pick = [&](int sl) -> float4 { return (NOPS > 1 && sl == 1) ? o.s[NOPS - 1][i] : o.s[0][i]; };
+                    apply(v, co, oidx, pick(s_om), pick(s_rv), pick(s_sb), pick(s_rm), pick(s_yo));
+                }
+            }
+        };
+        Ops oa, ob;
+        fetch(0, oa);
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            to_strip(m);
+            fetch(2 * m + 1, ob);
+            finish(2 * m, oa);
+            if (m + 1 < WM) fetch(2 * m + 2, oa);
+            finish(2 * m + 1, ob);
         }
     }
 }
@@ -187,7 +246,12 @@ bool l2i_gemm1x1_eligible(const l2i_conv_params& p) {
 
 int l2i_launch_gemm1x1(const l2i_conv_params& p, hipStream_t st) {
     const int tiles = (int)(((size_t)p.H * p.W) / gm::BN);
-    const bool wide = (p.CoutP % 128) == 0 && (long)p.B * tiles * (p.CoutP / 128) >= 512;     // small grids: 64-channel blocks fill more CUs
+    bool wide = (p.CoutP % 128) == 0 && (long)p.B * tiles * (p.CoutP / 128) >= 512;     // small grids: 64-channel blocks fill more CUs
+    // expanding layers of the forward pass (ResNet-50 conv3: Cin = Cout / 4, residual + ReLU epilogue): the K loop is shorter than the
+    // epilogue, and four 64-channel blocks per CU overlap one block's stores with three K loops better than three 128-channel blocks
+    // (measured per shape: 0.185 / 0.210 / 0.304 ms against 0.209 / 0.236 / 0.317 at 256->1024 @64^2, 128->512 @128^2, 64->256 @256^2)
+    if (!p.in_mask && p.Cin * 4 <= p.Cout) wide = false;
+    if (const char* e = getenv("L2I_GEMM_BM")) wide = (p.CoutP % 128) == 0 && atoi(e) == 128;          // tuning override (tools/bench_layers.py)
     const int BM = wide ? 128 : 64;
     const int mblocks = p.CoutP / BM;
     const long total = (long)p.B * tiles * mblocks;
@@ -195,21 +259,29 @@ int l2i_launch_gemm1x1(const l2i_conv_params& p, hipStream_t st) {
     const unsigned grid = (unsigned)((total + 7) & ~7L);
     const bool mask = p.in_mask != nullptr;
     const size_t lds = (size_t)2 * (gm::CK * gm::BN * (mask ? 2 : 1) + gm::CK * BM) * sizeof(float);
-    if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            done = true;
-        }
-    }
+    // epilogue operands that are read from global memory: up to two are prefetched (NOPS), otherwise the plain loop
+    int nops = (p.out_mask ? 1 : 0) + (p.residual ? 1 : 0) + (p.res_sub ? 1 : 0) + (p.res_mask ? 1 : 0) + (p.accumulate ? 1 : 0);
+    if (nops > 2 || (!mask && nops > 1)) nops = 0;
+    const dim3 g(grid), t(256);
+#define L2I_GEMM_LAUNCH(WM_, MASK_, NOPS_)                                                                                              \
+    do {                                                                                                                                \
+        if (lds > 64 * 1024) {                                                                                                          \
+            static bool done = false;                                                                                                   \
+            if (!done) {                                                                                                                \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel<WM_, MASK_, NOPS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+                done = true;                                                                                                            \
+            }                                                                                                                           \
+        }                                                                                                                               \
+        hipLaunchKernelGGL((gemm1x1_kernel<WM_, MASK_, NOPS_>), g, t, lds, st, p, tiles, mblocks, (int)total);                           \
+    } while (0)
     if (wide) {
-        if (mask) hipLaunchKernelGGL((gemm1x1_kernel<4, true>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
-        else hipLaunchKernelGGL((gemm1x1_kernel<4, false>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
+        if (mask) { if (nops == 2) L2I_GEMM_LAUNCH(4, true, 2); else if (nops == 1) L2I_GEMM_LAUNCH(4, true, 1); else L2I_GEMM_LAUNCH(4, true, 0); }
+        else { if (nops == 1) L2I_GEMM_LAUNCH(4, false, 1); else L2I_GEMM_LAUNCH(4, false, 0); }
     } else {
-        if (mask) hipLaunchKernelGGL((gemm1x1_kernel<2, true>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
-        else hipLaunchKernelGGL((gemm1x1_kernel<2, false>), dim3(grid), dim3(256), lds, st, p, tiles, mblocks, (int)total);
+        if (mask) { if (nops == 2) L2I_GEMM_LAUNCH(2, true, 2); else if (nops == 1) L2I_GEMM_LAUNCH(2, true, 1); else L2I_GEMM_LAUNCH(2, true, 0); }
+        else { if (nops == 1) L2I_GEMM_LAUNCH(2, false, 1); else L2I_GEMM_LAUNCH(2, false, 0); }
     }
+#undef L2I_GEMM_LAUNCH
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }

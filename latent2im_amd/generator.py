@@ -148,8 +148,15 @@ class _SynthesisFn(torch.autograd.Function):
             res = h * 2 if L.up else h
             nz = _noise_for(gen, noise, li, B, res, dev)
             if L.up:
-                t = L.conv.forward(x, in_scale=s, out_scale=demod)
-                y = K.upfirdn2d(t, L.blur_k, pad=(1, 1, 1, 1), noise=nz, noise_w=L.noise_w, bias=L.bias,
+                # the (2H+1)^2 map of the transposed conv is produced (2H+4)^2 (three zero rows / columns at the far edge, cropped by the
+                # blur's negative far pad): whole 16-byte rows for the conv's stores and the FIR's row vectors
+                if h >= 32 and L.conv.fwd_fused is not None:
+                    t = L.conv.forward(x, out=torch.empty(B, L.cout, 2 * h + 4, 2 * h + 4, device=dev, dtype=torch.float32), in_scale=s, out_scale=demod)
+                    fpad = (1, -2, 1, -2)
+                else:
+                    t = L.conv.forward(x, in_scale=s, out_scale=demod)
+                    fpad = (1, 1, 1, 1)
+                y = K.upfirdn2d(t, L.blur_k, pad=fpad, noise=nz, noise_w=L.noise_w, bias=L.bias,
                                 act=K.ACT_LRELU, slope=0.2, gain=SQRT2)
                 del t
             else:
