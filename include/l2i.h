@@ -216,6 +216,18 @@ int l2i_bn_bwd_apply_f32(float* dx, float* dy_masked, const float* gy, const flo
                          const float* invstd, const float* gamma, const float* mean_dy, const float* mean_dyxh, int B, int C, int64_t HW,
                          void* stream);
 
+/* ---- PGGAN-256 generator (BASELINE config 1; reference graphs/pggan/model_256.py) ----
+ * PixelNorm fused with the LeakyReLU that follows it (model_256.py:78-84, 128-150) on [B,C,HW] maps:
+ *   y = lrelu(x / sqrt(mean_c x^2 + eps), slope)      (slope = 1: the plain PixelNorm of the latent code, model_256.py:230)
+ * and its backward given gy = dL/dy and the forward INPUT x. */
+int l2i_pixelnorm_act_f32(float* y, const float* x, int B, int C, int64_t HW, float eps, float slope, void* stream);
+int l2i_pixelnorm_act_bwd_f32(float* dx, const float* gy, const float* x, int B, int C, int64_t HW, float eps, float slope, void* stream);
+/* F.upsample(scale_factor=2) (nearest, model_256.py:240) on [planes,H,W] -> [planes,2H,2W], times `scale` (scale 0.25 = the adjoint of the
+ * 2x2 mean below); and y[i,j] = scale * sum of the 2x2 window of x [planes,2*OH,2*OW] (scale 0.25 = F.upsample(size=half, bilinear) of
+ * graphs/pggan/transform_base.py:320; scale 1 = the adjoint of the nearest upsample).  Even widths only. */
+int l2i_upsample2x_nearest_f32(float* y, const float* x, int64_t planes, int H, int W, float scale, void* stream);
+int l2i_pool2x2_f32(float* y, const float* x, int64_t planes, int OH, int OW, float scale, void* stream);
+
 const char* l2i_last_error(void);
 int l2i_abi_version(void);
 

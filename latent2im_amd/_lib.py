@@ -63,6 +63,10 @@ _SIGNATURES = {
     'l2i_bn_apply_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_p]),
     'l2i_bn_bwd_reduce_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
     'l2i_bn_bwd_apply_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
+    'l2i_pixelnorm_act_f32': (c_i, [c_p, c_p, c_i, c_i, c_l, c_f, c_f, c_p]),
+    'l2i_pixelnorm_act_bwd_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_l, c_f, c_f, c_p]),
+    'l2i_upsample2x_nearest_f32': (c_i, [c_p, c_p, c_l, c_i, c_i, c_f, c_p]),
+    'l2i_pool2x2_f32': (c_i, [c_p, c_p, c_l, c_i, c_i, c_f, c_p]),
     'l2i_last_error': (ctypes.c_char_p, []),
     'l2i_abi_version': (c_i, []),
 }

@@ -16,6 +16,9 @@ reg_json = None
 reg_path = '/path/003_dict.model'
 g_path = '/path/550000.pt'
 vgg_path = ''
+# BASELINE config 1 (graphs/pggan): the in-repo PGGAN-256 generator checkpoint ({'G': state_dict}, transform_base.py:578-590) and its resolution
+pg_path = '/path/280000_dict.model'
+PG_RESOLUTION = 256
 
 SYNTH_SEED_G, SYNTH_SEED_D, SYNTH_SEED_R, SYNTH_SEED_V = 100, 200, 300, 400
 # per-layer NoiseInjection weights of the synthetic generator: 0 like a fresh reference Generator (networks.py:279; parity tests), > 0

@@ -565,8 +565,11 @@ faceGraph = _make_graph('faceGraph', FaceTransform)
 
 
 def get_transform_graphs(model):
+    if model == 'pggan':                                   # BASELINE config 1: z-space walk on the in-repo PGGAN-256 generator
+        from . import pggan
+        return [pggan.SceneGraph, pggan.faceGraph]
     if model != 'stylegan_v2_real':
-        raise ImportError("No module named 'graphs.%s' in this build (only the StyleGAN2 path is MI355X-native)" % model)
+        raise ImportError("No module named 'graphs.%s' in this build (stylegan_v2_real and pggan are MI355X-native)" % model)
     return [SceneGraph, faceGraph]
 
 

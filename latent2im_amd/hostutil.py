@@ -58,6 +58,8 @@ def set_graph_kwargs(opt):
             kw['N_f'] = opt.nn.num_steps
     if 'stylegan' in opt.model:
         kw['stylegan_opts'] = opt.stylegan
+    if opt.model == 'pggan':
+        kw['pgan_opts'] = opt.pggan
     return kw
 
 

@@ -148,3 +148,45 @@ def relu_mask(g, ref):
     _lib.check(lib.l2i_relu_mask_f32(_lib.fptr(y), _lib.fptr(g), _lib.fptr(ref), g.numel(), _lib.stream_ptr()),
                'l2i_relu_mask_f32')
     return y
+
+
+def pixelnorm_act(x, slope=0.2, eps=1e-8):
+    """lrelu(x / sqrt(mean_c x^2 + eps), slope) on [B,C,...] (model_256.py:78-84 + the LeakyReLU(0.2) that follows; slope 1: PixelNorm alone)."""
+    lib = _lib.load()
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    hw = x.numel() // (x.shape[0] * x.shape[1])
+    _lib.check(lib.l2i_pixelnorm_act_f32(_lib.fptr(y), _lib.fptr(x), x.shape[0], x.shape[1], hw, float(eps), float(slope), _lib.stream_ptr()),
+               'l2i_pixelnorm_act_f32')
+    return y
+
+
+def pixelnorm_act_bwd(gy, x, slope=0.2, eps=1e-8):
+    lib = _lib.load()
+    gy, x = gy.contiguous(), x.contiguous()
+    assert gy.shape == x.shape
+    dx = torch.empty_like(x)
+    hw = x.numel() // (x.shape[0] * x.shape[1])
+    _lib.check(lib.l2i_pixelnorm_act_bwd_f32(_lib.fptr(dx), _lib.fptr(gy), _lib.fptr(x), x.shape[0], x.shape[1], hw, float(eps), float(slope),
+                                             _lib.stream_ptr()), 'l2i_pixelnorm_act_bwd_f32')
+    return dx
+
+
+def upsample2x_nearest(x, scale=1.0):
+    lib = _lib.load()
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = torch.empty(n, c, 2 * h, 2 * w, device=x.device, dtype=torch.float32)
+    _lib.check(lib.l2i_upsample2x_nearest_f32(_lib.fptr(y), _lib.fptr(x), n * c, h, w, float(scale), _lib.stream_ptr()), 'l2i_upsample2x_nearest_f32')
+    return y
+
+
+def pool2x2(x, scale=0.25):
+    """scale * (sum of every 2x2 window): 0.25 = bilinear halving (align_corners=False), 1 = adjoint of the nearest 2x upsample."""
+    lib = _lib.load()
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    assert h % 2 == 0 and w % 2 == 0
+    y = torch.empty(n, c, h // 2, w // 2, device=x.device, dtype=torch.float32)
+    _lib.check(lib.l2i_pool2x2_f32(_lib.fptr(y), _lib.fptr(x), n * c, h // 2, w // 2, float(scale), _lib.stream_ptr()), 'l2i_pool2x2_f32')
+    return y

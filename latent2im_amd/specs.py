@@ -176,3 +176,20 @@ def vgg19_prefix_spec():
         spec['%d.weight' % idx] = (cout, cin, 3, 3)
         spec['%d.bias' % idx] = (cout,)
     return spec
+
+
+def pggan_generator_spec():
+    """name -> shape of ``model_256.Generator(511, 1).state_dict()`` (graphs/pggan/model_256.py:188-227; EqualLR keeps ``weight_orig``)."""
+    from collections import OrderedDict
+    chans = ((512, 512), (512, 512), (512, 512), (512, 512), (512, 256), (256, 128), (128, 64), (64, 32), (32, 16))
+    spec = OrderedDict()
+    spec['label_embed.weight'] = (1, 1)
+    for i, (cin, cout) in enumerate(chans):
+        spec['progression.%d.conv.0.conv.bias' % i] = (cout,)
+        spec['progression.%d.conv.0.conv.weight_orig' % i] = (cout, cin, 4, 4) if i == 0 else (cout, cin, 3, 3)
+        spec['progression.%d.conv.3.conv.bias' % i] = (cout,)
+        spec['progression.%d.conv.3.conv.weight_orig' % i] = (cout, cout, 3, 3)
+    for i, (cin, cout) in enumerate(chans):
+        spec['to_rgb.%d.weight' % i] = (3, cout, 1, 1)
+        spec['to_rgb.%d.bias' % i] = (3,)
+    return spec

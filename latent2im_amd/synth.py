@@ -135,3 +135,19 @@ def noise_maps(size, batch, seed=500):
         res = 2 ** ((l + 5) // 2)
         maps.append(_rs('noise.%d' % l, seed).randn(batch, 1, res, res).astype(np.float32))
     return maps
+
+
+def pggan_generator_state(seed=100):
+    """name -> float32 ndarray for ``model_256.Generator(511, 1)``: N(0,1) ``weight_orig`` like EqualConv2d's constructor
+    (model_256.py:99-100; the sqrt(2/fan_in) scale is applied at run time), small biases, N(0,1) label embedding."""
+    out = OrderedDict()
+    for name, shape in specs.pggan_generator_spec().items():
+        r = _rs('PG.' + name, seed)
+        if name.endswith('weight_orig') or name == 'label_embed.weight':
+            v = r.randn(*shape)
+        elif name.endswith('.weight'):
+            v = r.randn(*shape) / math.sqrt(shape[1])               # to_rgb: plain nn.Conv2d
+        else:
+            v = 0.1 * r.randn(*shape)
+        out[name] = v.astype(np.float32)
+    return out
