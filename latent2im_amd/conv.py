@@ -204,6 +204,54 @@ class FusedTransposed:
         return self
 
 
+class SmallTransposed:
+    """Stride-2 transposed 7x7 / pad 3 conv onto <= 3 channels in one launch (csrc/l2i_convt_small.hip: the ResNet-50 stem's input-gradient):
+    weights [Cin][49][4] (three output channels + pad)."""
+    __slots__ = ('w', 'cin', 'cout', 'k', 'pad')
+
+    def __init__(self, w_oihw, pad):
+        w = torch.as_tensor(w_oihw, dtype=torch.float32)
+        self.cout, self.cin, self.k, _ = w.shape
+        assert self.k == 7 and pad == 3 and self.cout <= 3
+        self.pad = pad
+        pk = torch.zeros(self.cin, 49, 4, dtype=torch.float32)
+        pk[:, :, :self.cout] = w.permute(1, 2, 3, 0).reshape(self.cin, 49, self.cout)
+        self.w = pk.contiguous()
+
+    def to(self, device):
+        self.w = self.w.to(device)
+        return self
+
+
+def run_small_transposed(F, x, y, in_mask=None, mask=(1.0, 0.0), out_gain=1.0):
+    lib = _lib.load()
+    B, cin, H, W = x.shape
+    assert cin == F.cin and y.shape[0] == B and y.shape[1] == F.cout
+    p = ConvParams()
+    p.x, p.w, p.y = _lib.fptr(x), _lib.fptr(F.w), _lib.fptr(y)
+    p.B, p.Cin, p.H, p.W, p.Cout, p.CoutP = B, cin, H, W, F.cout, 4
+    p.KH = p.KW = F.k
+    p.stride, p.pad_y, p.pad_x = 2, F.pad, F.pad
+    p.OHf, p.OWf = y.shape[2], y.shape[3]
+    p.OH, p.OW = (p.OHf + 1) // 2, (p.OWf + 1) // 2
+    p.oy_step = p.ox_step = 2
+    p.in_mask = _lib.fptr(in_mask)
+    p.mask_pos, p.mask_neg = mask
+    p.act_gain, p.out_gain = 1.0, out_gain
+    if in_mask is not None:
+        assert in_mask.shape == x.shape
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.l2i_conv_transpose2d_f32(p, _lib.stream_ptr()), 'l2i_conv_transpose2d_f32')
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * B * F.cout * cin * F.k * F.k * H * W,
+                        (B, cin, F.cout, F.k, F.k, 2, H, W, int(p.OHf), int(p.OWf), 2, in_mask is not None, False), 'l2i_conv_transpose2d_f32', 'direct_small_valu'))
+        return y
+    _lib.check(lib.l2i_conv_transpose2d_f32(p, _lib.stream_ptr()), 'l2i_conv_transpose2d_f32')
+    return y
+
+
 def _split_k(p, px, cin, y):
     """Small maps (<= 2048 positions per launch) with many input channels: cut Cin into ranges computed by separate blocks."""
     if not (SPLIT_K and px <= 2048 and cin >= 256):
@@ -364,7 +412,7 @@ class FrozenConv2d:
         self.cout, self.cin, self.k, _ = w.shape
         self.stride, self.padding, self.transposed = stride, padding, transposed
         wt = w.transpose(0, 1).contiguous()                       # [Cin, Cout, K, K]: roles swapped for the gradient
-        self.fwd_fused = self.bwd_fused = None
+        self.fwd_fused = self.bwd_fused = self.bwd_small = None
         fusable = (self.k, padding) in FUSED_TRANSPOSED_SHAPES
         if transposed:
             assert stride == 2
@@ -379,8 +427,10 @@ class FrozenConv2d:
             else:
                 assert stride == 2
                 self.bwd = transposed_plan(wt, padding)           # dx[ci, 2o+k-pad] += gy[co,o] w[co,ci,k]
-                if fusable and self.cin > 4 and self.cout % 4 == 0:          # <= 4 output channels: per-parity launches take the direct VALU kernel
+                if fusable and self.cin > 4 and self.cout % 4 == 0:          # <= 4 output channels: the VALU kernels
                     self.bwd_fused = FusedTransposed(wt, padding).to(device)
+                elif (self.k, padding) == (7, 3) and self.cin <= 3:          # ResNet-50 stem: all four parities in one launch
+                    self.bwd_small = SmallTransposed(wt, padding).to(device)
         for L in self.fwd + self.bwd:
             if L is not None:
                 L.to(device)
@@ -404,4 +454,7 @@ class FrozenConv2d:
             out = torch.empty(gy.shape[0], self.cin, in_hw[0], in_hw[1], device=gy.device, dtype=torch.float32)
         if self.bwd_fused is not None and USE_FUSED_TRANSPOSED and set(kw) <= _FUSED_KW:
             return run_fused_transposed(self.bwd_fused, gy, out, **kw)
+        if (self.bwd_small is not None and USE_FUSED_TRANSPOSED and set(kw) <= {'in_mask', 'mask', 'out_gain'} and gy.shape[3] % 4 == 0 and out.shape[3] % 4 == 0
+                and gy.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and (kw.get('in_mask') is None or kw['in_mask'].data_ptr() % 16 == 0)):
+            return run_small_transposed(self.bwd_small, gy, out, **kw)
         return run_plan(self.bwd, gy, out, **kw)

@@ -460,6 +460,13 @@ extern "C" int l2i_conv_transpose2d_f32(const l2i_conv_params* pp, void* stream)
     if (!p.x || !p.w || !p.y) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: null tensor");
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: non-positive dimension");
     if (p.KH != p.KW || p.pad_y != p.pad_x) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: square kernels / symmetric padding only");
+    if (p.CoutP == 4 && p.Cout <= 3) {                   // <= 3 output channels, [Cin][K*K][4] weight pack: the fused VALU kernel (l2i_convt_small.hip)
+        if (p.bias || p.noise || p.residual || p.res_mask || p.res_sub || p.out_mask || p.act != L2I_ACT_NONE)
+            return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: only in_mask / out_gain / accumulate are fused in the small-output kernel");
+        if (!l2i_convt_small_eligible(p)) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d(small): 7x7 / pad 3, W % 4 == 0, OWf % 4 == 0, aligned tensors, no scales");
+        if (p.OHf > 2 * p.H + 8 || p.OWf > 2 * p.W + 8) return l2i_set_error(L2I_E_ARG, "conv_transpose2d(small): output window too large for the input");
+        return l2i_launch_convt_small(p, (hipStream_t)stream);
+    }
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: CoutP must be Cout rounded up to 32");
     const int full_h = (p.H - 1) * 2 - 2 * p.pad_y + p.KH, full_w = (p.W - 1) * 2 - 2 * p.pad_x + p.KW;
     // larger than natural: the extra rows / columns (no input reaches them) are written as zeros — output_padding, and the discriminator's

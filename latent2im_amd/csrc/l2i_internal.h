@@ -10,6 +10,8 @@ bool l2i_gemm1x1_eligible(const l2i_conv_params& p);              // l2i_gemm.hi
 int l2i_launch_gemm1x1(const l2i_conv_params& p, hipStream_t st);
 bool l2i_cin3_eligible(const l2i_conv_params& p);                 // l2i_cin3.hip: 3x3 convs of <= 3-channel images as one 27-long contraction
 int l2i_launch_cin3(const l2i_conv_params& p, hipStream_t st);
+bool l2i_convt_small_eligible(const l2i_conv_params& p);          // l2i_convt_small.hip: 7x7 / pad 3 stride-2 transposed conv onto <= 3 channels
+int l2i_launch_convt_small(const l2i_conv_params& p, hipStream_t st);
 int l2i_launch_splitk_epilogue(const l2i_conv_params& q, hipStream_t st);     // l2i_conv.hip: y = epilogue(sum of q.ksplit partials in q.ws)
 
 #define L2I_CHECK_LAUNCH()                                                      \
