@@ -85,7 +85,7 @@ def pack_weight_wino(w):
 
 class Launch:
     """One call of the kernel: a stride-1/2 correlation writing every (oy_step, ox_step)-th output pixel."""
-    __slots__ = ('w', 'cin', 'cout', 'kh', 'kw', 'stride', 'pad_y', 'pad_x', 'step', 'off_y', 'off_x', 'w16', 'w_src', 'wino')
+    __slots__ = ('w', 'cin', 'cout', 'kh', 'kw', 'stride', 'pad_y', 'pad_x', 'step', 'off_y', 'off_x', 'w16', 'w_src', 'wino', 'w4')
 
     def __init__(self, w_oihw, stride, pad_y, pad_x, step=1, off_y=0, off_x=0, device=None):
         self.cout, self.cin, self.kh, self.kw = w_oihw.shape
@@ -93,6 +93,10 @@ class Launch:
         self.stride, self.pad_y, self.pad_x = stride, pad_y, pad_x
         self.step, self.off_y, self.off_x = step, off_y, off_x
         self.w16 = None                                        # (hi, lo) planes, built on first bf16x3 use
+        self.w4 = None                                         # <= 4 output channels: dense [Cin][KH*KW][4] pack for the direct VALU kernel
+        if self.cout <= 4 and stride == 1:
+            self.w4 = torch.zeros(self.cin, self.kh * self.kw, 4, dtype=torch.float32, device=self.w.device)
+            self.w4[:, :, :self.cout] = self.w[:, :, :self.cout]
         self.wino = None                                       # Winograd pack, built on first use
         self.w_src = torch.as_tensor(w_oihw, dtype=torch.float32) if (self.cin % 8 == 0 and self.kh <= 3 and self.kw <= 3) else None
 
@@ -109,6 +113,8 @@ class Launch:
 
     def to(self, device):
         self.w = self.w.to(device)
+        if self.w4 is not None:
+            self.w4 = self.w4.to(device)
         return self
 
 
@@ -347,6 +353,9 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
     if out_mask is not None:
         assert out_mask.shape == y.shape
     entry, name = lib.l2i_conv2d_f32, 'l2i_conv2d_f32'
+    if (L.w4 is not None and tile_hint == 0 and out_scale is None and noise is None and bias is None and residual is None and out_mask is None
+            and act == ACT_NONE):                          # the launch takes the direct VALU kernel (l2i_conv2d_family): hand it the dense pack
+        p.w, p.CoutP = _lib.fptr(L.w4), 4
     if PRECISION == 'bf16x3' and tile_hint == 0 and _bf16x3_eligible(L, x, in_mask, OW):
         planes = L.bf16x3_planes()
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])

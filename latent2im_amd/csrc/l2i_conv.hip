@@ -407,7 +407,6 @@ __global__ __launch_bounds__(256) void conv_direct_small_kernel(const l2i_conv_p
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int KK = p.KH * p.KW;
     float* tile = smem;                                  // [CK][IH][IWp]
-    float4* wl = reinterpret_cast<float4*>(smem + ((CK * IH * IWp + 3) & ~3));      // [CK][KK] float4 (4 output channels)
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y; bid /= tiles_y;
@@ -480,15 +479,16 @@ __global__ __launch_bounds__(256) void conv_direct_small_kernel(const l2i_conv_p
                 }
             }
         }
-        for (int e = threadIdx.x; e < CK * KK; e += 256) {
-            float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c0 + e / KK < p.Cin) w4 = *reinterpret_cast<const float4*>(p.w + ((size_t)c0 * KK + e) * p.CoutP);
-            wl[e] = w4;
-        }
         __syncthreads();
-        for (int c = 0; c < CK; ++c) {
+        // the taps are the same for every lane: they come through the scalar cache into SGPRs (constant address space -> s_load; one SGPR
+        // operand per FMA) instead of LDS broadcasts, which cost 8 LDS cycles per 16 FMAs and bounded this kernel (see l2i_convt_small.hip)
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(4))) const f32x4v cfloat4;
+        const int cn = p.Cin - c0 < CK ? p.Cin - c0 : CK;
+        for (int c = 0; c < cn; ++c) {
             const float* tc = tile + (c * IH + r0) * IWp + col;
-            const float4* wc = wl + c * KK;
+            const float* wbase = p.w + (size_t)(c0 + c) * KK * p.CoutP;
+            auto tap = [&](int t) -> f32x4v { return *(cfloat4*)(uintptr_t)(wbase + (size_t)t * p.CoutP); };
             if constexpr (TKH > 0) {
                 float win[TKH + 3][TKW];
 #pragma unroll
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void conv_direct_small_kernel(const l2i_conv_p
                 for (int ky = 0; ky < TKH; ++ky) {
 #pragma unroll
                     for (int kx = 0; kx < TKW; ++kx) {
-                        const float4 w4 = wc[ky * TKW + kx];
+                        const f32x4v w4 = tap(ky * TKW + kx);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float x = win[r + ky][kx];
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void conv_direct_small_kernel(const l2i_conv_p
             } else {
                 for (int ky = 0; ky < p.KH; ++ky) {
                     for (int kx = 0; kx < p.KW; ++kx) {
-                        const float4 w4 = wc[ky * p.KW + kx];
+                        const f32x4v w4 = tap(ky * p.KW + kx);
                         const float* tr = tc + ky * IWp + kx;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {                   // static register indexing only (no scratch)
@@ -720,7 +720,10 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
         return l2i_set_error(L2I_E_ARG, "conv2d: non-positive dimension");
     if (p.KH <= 0 || p.KW <= 0 || p.KH > 16 || p.KW > 16 || (p.stride != 1 && p.stride != 2))
         return l2i_set_error(L2I_E_ARG, "conv2d: kernel size must be 1..16 and stride 1 or 2");
-    if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv2d: CoutP must be Cout rounded up to 32");
+    const bool dense4 = p.CoutP == 4 && p.Cout <= 4;      // [Cin][KH*KW][4] pack of a <= 4-channel layer: the direct VALU kernel only (its taps travel through the
+                                                           // 16 KiB scalar cache: a 32-float pitch would spend a cache line per tap)
+    if (!dense4 && (p.CoutP < p.Cout || (p.CoutP % 32) != 0)) return l2i_set_error(L2I_E_ARG, "conv2d: CoutP must be Cout rounded up to 32 (or 4 for the direct kernel of <= 4 channels)");
+    if (dense4 && l2i_conv2d_family(pp) != L2I_FAMILY_DIRECT_SMALL) return l2i_set_error(L2I_E_ARG, "conv2d: the [Cin][K*K][4] pack is for launches of the direct <= 4-channel kernel only");
     if (p.res_sub && !p.residual) return l2i_set_error(L2I_E_ARG, "conv2d: res_sub needs residual");
     if (p.oy_step <= 0 || p.ox_step <= 0 || (p.OH - 1) * p.oy_step + p.oy_off >= p.OHf || (p.OW - 1) * p.ox_step + p.ox_off >= p.OWf ||
         p.oy_off < 0 || p.ox_off < 0)
