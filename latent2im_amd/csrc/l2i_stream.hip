@@ -498,9 +498,60 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(float* __restrict__ gx
     }
 }
 
+// The two geometries on the walk-training path, four outputs of one row per thread from 16-byte loads (the generic kernel reads every
+// window element as a stride-2 scalar: 3.3 TB/s).  Same arg-max rule as above: taps in (ky, kx) order, first maximum, NaN propagates.
+// K = 2: 2x2 / stride 2 / pad 0 (VGG-19 pool1), W == 2 OW.   K = 3: 3x3 / stride 2 / pad 1 (ResNet-50 stem pool), W == 2 OW.
+template <int K>
+__global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(float* __restrict__ y, uint8_t* __restrict__ idx, const float* __restrict__ x,
+                                                              long long n4, int H, int W, int OH, int OW) {
+    const int W4 = OW >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const long long row = i / W4;                          // (plane, output row)
+        const int ox0 = (int)(i - row * W4) * 4;
+        const long long pl = row / OH;
+        const int oy = (int)(row - pl * OH);
+        const float* xp = x + pl * H * (long long)W;
+        float best[4];
+        int bi[4];
+        bool found[4] = {false, false, false, false};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { best[q] = -INFINITY; bi[q] = 0; }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = 2 * oy - (K == 3 ? 1 : 0) + ky;
+            if (iy < 0 || iy >= H) continue;
+            const float* rp = xp + (long long)iy * W + 2 * ox0;
+            const float4 a = *reinterpret_cast<const float4*>(rp);
+            const float4 b = *reinterpret_cast<const float4*>(rp + 4);
+            float v[9];                                        // columns 2 ox0 - 1 .. 2 ox0 + 7
+            v[0] = (K == 3 && ox0 > 0) ? rp[-1] : 0.f;
+            v[1] = a.x; v[2] = a.y; v[3] = a.z; v[4] = a.w; v[5] = b.x; v[6] = b.y; v[7] = b.z; v[8] = b.w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    if (K == 3 && kx == 0 && ox0 + q == 0) continue;          // column -1: padding
+                    const float t = v[2 * q + kx + (K == 3 ? 0 : 1)];
+                    if (!found[q] || t > best[q] || (t != t)) { best[q] = t; bi[q] = ky * K + kx; found[q] = true; }
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(y + row * OW + ox0) = make_float4(best[0], best[1], best[2], best[3]);
+        *reinterpret_cast<uint32_t*>(idx + row * OW + ox0) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    }
+}
+
 extern "C" int l2i_maxpool2d_fwd_f32(float* y, uint8_t* idx, const float* x, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, void* stream) {
     if (!y || !idx || !x) return l2i_set_error(L2I_E_ARG, "maxpool_fwd: null tensor");
     if (planes <= 0 || H <= 0 || W <= 0 || k <= 0 || k > 15 || s <= 0 || OH <= 0 || OW <= 0) return l2i_set_error(L2I_E_ARG, "maxpool_fwd: bad geometry");
+    const bool vec_ok = s == 2 && W == 2 * OW && (OW % 4) == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0 && (((uintptr_t)idx) % 4) == 0;
+    if (vec_ok && ((k == 2 && pad == 0 && H == 2 * OH) || (k == 3 && pad == 1 && (H + 1) / 2 == OH))) {
+        const long long n4 = (long long)planes * OH * (OW / 4);
+        if (k == 2) hipLaunchKernelGGL((maxpool_fwd_vec_kernel<2>), dim3(l2i_grid_for(n4, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, y, idx, x, n4, H, W, OH, OW);
+        else hipLaunchKernelGGL((maxpool_fwd_vec_kernel<3>), dim3(l2i_grid_for(n4, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, y, idx, x, n4, H, W, OH, OW);
+        L2I_CHECK_LAUNCH();
+        return L2I_OK;
+    }
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(l2i_grid_for(planes * OH * OW, 256)), dim3(256), 0, (hipStream_t)stream, y, idx, x, (long long)planes, H, W, k, s, pad, OH, OW);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
@@ -523,6 +574,45 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k2s2_kernel(float* __restrict
     }
 }
 
+// k = 3, s = 2, pad = 1 with W == 2 OW (ResNet-50 stem pool): four consecutive input pixels of one row per thread.  Column 2m belongs to
+// window m only (kx = 1), column 2m + 1 to windows m (kx = 2) and m + 1 (kx = 0); rows alike: the thread reads gy / idx of windows
+// 2t .. 2t + 2 of one or two window rows (8-byte + 4-byte loads) instead of up to 16 scalar pairs.
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s2p1_vec_kernel(float* __restrict__ gx, const float* __restrict__ gy, const uint8_t* __restrict__ idx,
+                                                                     long long n4, int H, int W, int OH, int OW) {
+    const int W4 = W >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const long long row = i / W4;                          // (plane, input row)
+        const int t = (int)(i - row * W4);                     // columns 4t .. 4t + 3; windows 2t, 2t + 1, 2t + 2
+        const long long pl = row / H;
+        const int iy = (int)(row - pl * H);
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        // window rows: iy even -> iy / 2 (ky = 1); iy odd -> (iy - 1) / 2 (ky = 2) and (iy + 1) / 2 (ky = 0)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            int oy, ky;
+            if ((iy & 1) == 0) { if (c) continue; oy = iy >> 1; ky = 1; }
+            else { oy = (iy >> 1) + c; ky = c ? 0 : 2; }
+            if (oy >= OH) continue;
+            const long long o = (pl * OH + oy) * OW + 2 * t;
+            const float2 ga = *reinterpret_cast<const float2*>(gy + o);
+            const unsigned ia = *reinterpret_cast<const uint16_t*>(idx + o);
+            const bool third = 2 * t + 2 < OW;
+            const float gc = third ? gy[o + 2] : 0.f;
+            const int ic = third ? (int)idx[o + 2] : -1;
+            const int i0 = (int)(ia & 0xff), i1 = (int)(ia >> 8);
+            // column 4t = 2 (2t): window 2t, kx = 1.   4t + 1: windows 2t (kx = 2), 2t + 1 (kx = 0).   4t + 2: window 2t + 1 (kx = 1).
+            // 4t + 3: windows 2t + 1 (kx = 2), 2t + 2 (kx = 0)
+            if (i0 == ky * 3 + 1) g[0] += ga.x;
+            if (i0 == ky * 3 + 2) g[1] += ga.x;
+            if (i1 == ky * 3 + 0) g[1] += ga.y;
+            if (i1 == ky * 3 + 1) g[2] += ga.y;
+            if (i1 == ky * 3 + 2) g[3] += ga.y;
+            if (ic == ky * 3 + 0) g[3] += gc;
+        }
+        *reinterpret_cast<float4*>(gx + row * W + 4 * t) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
 extern "C" int l2i_maxpool2d_bwd_f32(float* gx, const float* gy, const uint8_t* idx, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, void* stream) {
     if (!gx || !gy || !idx) return l2i_set_error(L2I_E_ARG, "maxpool_bwd: null tensor");
     if (planes <= 0 || H <= 0 || W <= 0 || k <= 0 || k > 15 || s <= 0 || OH <= 0 || OW <= 0) return l2i_set_error(L2I_E_ARG, "maxpool_bwd: bad geometry");
@@ -532,6 +622,13 @@ extern "C" int l2i_maxpool2d_bwd_f32(float* gx, const float* gy, const uint8_t* 
         return L2I_OK;
     }
     if ((long long)H * W >= 0x7fffffffLL) return l2i_set_error(L2I_E_ARG, "maxpool_bwd: plane too large");
+    if (k == 3 && s == 2 && pad == 1 && W == 2 * OW && (H + 1) / 2 == OH && (W % 4) == 0 && (((uintptr_t)gx) % 16) == 0 && (((uintptr_t)gy) % 8) == 0 &&
+        (((uintptr_t)idx) % 2) == 0) {
+        const long long n4 = (long long)planes * H * (W / 4);
+        hipLaunchKernelGGL(maxpool_bwd_k3s2p1_vec_kernel, dim3(l2i_grid_for(n4, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, gx, gy, idx, n4, H, W, OH, OW);
+        L2I_CHECK_LAUNCH();
+        return L2I_OK;
+    }
     if (k == 3 && s == 2 && pad == 1)
         hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2, 1>), dim3(l2i_grid_for(planes * H * W, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, gx, gy, idx, (long long)planes, H, W, k, s, pad, OH, OW);
     else

@@ -356,7 +356,7 @@ def test_torgb_and_act_bwd_and_reductions():
     close(kernels.axpby(x.to(DEV), y.to(DEV), 0.5, -2.0), 0.5 * x - 2 * y, 1e-6, 1e-6)
 
 
-@pytest.mark.parametrize('k,s,pad,h', [(3, 2, 1, 16), (2, 2, 0, 16), (3, 2, 1, 15)])
+@pytest.mark.parametrize('k,s,pad,h', [(3, 2, 1, 16), (2, 2, 0, 16), (3, 2, 1, 15), (3, 2, 1, 72), (2, 2, 0, 40), (3, 2, 1, 8), (2, 2, 0, 6)])      # W = 2 OW with OW % 4 == 0: the vectorised kernels
 def test_maxpool(k, s, pad, h):
     rs = np.random.RandomState(k + h)
     x = torch.relu(T(rs.randn(2, 5, h, h))).requires_grad_(True)      # zeros create ties, as after a ReLU
