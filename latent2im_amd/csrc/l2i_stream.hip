@@ -238,6 +238,70 @@ __global__ __launch_bounds__(256) void upfirdn2d_k4_kernel(const UfdParams p) {
     }
 }
 
+// up = 2, down = 1, 4x4 FIR, pad0 = 2 (the ToRGB skip upsample, networks.py:35-43 / :353-356, on 3-channel images): a thread owns a 2 x 4
+// patch of outputs (rows 2i, 2i + 1; columns 4j .. 4j + 3) = input rows i - 1 .. i + 1, columns 2j - 1 .. 2j + 2.  Every output sums its
+// 2 x 2 live taps in the generic kernel's (ky, kx) order (bit-identical results); 16-byte stores, addend read as 16-byte vectors.
+__global__ __launch_bounds__(256) void upfirdn2d_up2k4_kernel(const UfdParams p) {
+    float kf[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) kf[t] = p.k[15 - t];                 // flipped taps (true convolution)
+    const int W4 = p.out_w >> 2, H2 = p.out_h >> 1;
+    const long long n = p.major * H2 * W4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i % W4);
+        const int r = (int)((i / W4) % H2);
+        const long long mj = i / ((long long)W4 * H2);
+        const float* xin = p.x + mj * (long long)p.in_h * p.in_w;
+        float win[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int iy = r - 1 + a, ix = 2 * j - 1 + b;
+                win[a][b] = (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) ? xin[(long long)iy * p.in_w + ix] : 0.f;
+            }
+        const float bia = p.bias ? p.bias[mj % p.channels] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {                                  // output row 2r + a: taps ky = a, a + 2 on input rows r - 1 + a, r + a
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                              // output column 4j + q: taps kx = (q & 1), (q & 1) + 2 on input columns 2j + (q >> 1) - 1 + (q & 1) ...
+                const int c = q & 1, cb = (q >> 1) + c;                //   ... = window columns cb, cb + 1
+                float v = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int iy = r - 1 + a + t, ix = 2 * j - 1 + cb + s2;
+                        if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v += win[a + t][cb + s2] * kf[(a + 2 * t) * 4 + c + 2 * s2];
+                    }
+                o[q] = v;
+            }
+            const int oy = 2 * r + a, ox = 4 * j;
+            const long long obase = (mj * p.out_h + oy) * p.out_w + ox;
+            if (p.noise) {
+                const long long nbase = ((mj / p.channels) * p.out_h + oy) * p.out_w + ox;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] += p.noise[nbase + q] * p.noise_w;
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] += bia;
+            }
+            if (p.addend) {
+                const float4 ad = *reinterpret_cast<const float4*>(p.addend + obase);
+                o[0] += ad.x; o[1] += ad.y; o[2] += ad.z; o[3] += ad.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (p.act == L2I_ACT_LRELU) o[q] = (o[q] > 0.f ? o[q] : o[q] * p.slope) * p.gain;
+                else if (p.act == L2I_ACT_RELU) o[q] = o[q] > 0.f ? o[q] : 0.f;
+            }
+            *reinterpret_cast<float4*>(p.y + obase) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 extern "C" int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw,
                                  int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                                  int channels, const float* noise, float noise_w, const float* bias, const float* addend,
@@ -257,6 +321,13 @@ extern "C" int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64
     if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4) {
         const long long nt = major * ((p.out_w + 63) / 64) * ((p.out_h + 31) / 32);
         hipLaunchKernelGGL(upfirdn2d_k4_kernel, dim3(l2i_grid_for(nt, 1, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p);
+        L2I_CHECK_LAUNCH();
+        return L2I_OK;
+    }
+    if (up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 && pad_x0 == 2 && pad_y0 == 2 && p.out_h == 2 * in_h && p.out_w == 2 * in_w &&
+        (p.out_w % 4) == 0 && (((uintptr_t)y | (uintptr_t)addend) % 16) == 0) {
+        const long long n = major * (p.out_h / 2) * (p.out_w / 4);
+        hipLaunchKernelGGL(upfirdn2d_up2k4_kernel, dim3(l2i_grid_for(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p);
         L2I_CHECK_LAUNCH();
         return L2I_OK;
     }

@@ -329,6 +329,12 @@ def test_upfirdn2d_fused_epilogue():
                           act=kernels.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
     ref = F.leaky_relu(sg2.upfirdn2d(x, k, pad=(1, 1)) + 0.4 * nz + b[None, :, None, None] + add, 0.2) * 2 ** 0.5
     close(y, ref, 1e-5, 1e-6)
+    # the ToRGB skip upsample (up = 2, pad (2, 1), addend = the new rgb; networks.py:353-356): the 2x4-patch kernel (output width % 4 == 0)
+    # and, for an odd input width, the generic one
+    for h, w in ((8, 6), (33, 64), (5, 7)):
+        x, add = T(rs.randn(2, 3, h, w)), T(rs.randn(2, 3, 2 * h, 2 * w))
+        y = kernels.upfirdn2d(x.to(DEV), k.to(DEV), up=(2, 2), pad=(2, 1, 2, 1), addend=add.to(DEV))
+        close(y, sg2.upfirdn2d(x, k, up=2, pad=(2, 1)) + add, 1e-5, 1e-6)
 
 
 def test_torgb_and_act_bwd_and_reductions():
