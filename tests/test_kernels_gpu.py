@@ -329,6 +329,17 @@ def test_upfirdn2d_fused_epilogue():
                           act=kernels.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
     ref = F.leaky_relu(sg2.upfirdn2d(x, k, pad=(1, 1)) + 0.4 * nz + b[None, :, None, None] + add, 0.2) * 2 ** 0.5
     close(y, ref, 1e-5, 1e-6)
+    # wide maps: the register-streaming 4x4 kernel (>= 192 output columns, whole 16-byte rows) with every epilogue operand, pads (1, -2) /
+    # (2, 1) / (2, 5) as the generator / discriminator use them, a ragged last band and a partial last strip
+    for (h, w, pad) in ((70, 264, (1, -2, 1, -2)), (40, 512, (2, 1, 2, 1)), (19, 200, (2, 5, 2, 5)), (130, 196, (1, 1, 1, 1))):
+        oh, ow = kernels.upfirdn2d_out_hw(h, w, 4, 4, (1, 1), (1, 1), pad)
+        x, nz, add = T(rs.randn(2, 5, h, w)), T(rs.randn(2, 1, oh, ow)), T(rs.randn(2, 5, oh, ow))
+        y = kernels.upfirdn2d(x.to(DEV), k.to(DEV), pad=pad, noise=nz.to(DEV), noise_w=0.4, bias=b.to(DEV), addend=add.to(DEV), act=kernels.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+        xp = F.pad(x, [max(pad[0], 0), max(pad[1], 0), max(pad[2], 0), max(pad[3], 0)])
+        xp = xp[:, :, max(-pad[2], 0):xp.shape[2] - max(-pad[3], 0), max(-pad[0], 0):xp.shape[3] - max(-pad[1], 0)]
+        ref = F.conv2d(xp.reshape(-1, 1, xp.shape[2], xp.shape[3]), torch.flip(k, [0, 1])[None, None]).reshape(2, 5, oh, ow)
+        close(y, F.leaky_relu(ref + 0.4 * nz + b[None, :, None, None] + add, 0.2) * 2 ** 0.5, 1e-5, 1e-5)
+        close(kernels.upfirdn2d(x.to(DEV), k.to(DEV), pad=pad), ref, 1e-5, 1e-5)
     # the ToRGB skip upsample (up = 2, pad (2, 1), addend = the new rgb; networks.py:353-356): the 2x4-patch kernel (output width % 4 == 0)
     # and, for an odd input width, the generic one
     for h, w in ((8, 6), (33, 64), (5, 7)):

@@ -7,8 +7,8 @@ if os.environ.get('L2I_LIB_PATH'):
 k1 = torch.tensor([1., 3., 3., 1.])
 k = (k1[:, None] * k1[None, :]); k = (k / k.sum() * 4).cuda()
 out = []
-for c, res in ((32, 1025), (64, 513), (128, 257), (256, 129), (32, 1024), (64, 512)):
-    pad = (1, 1, 1, 1) if res % 2 else (2, 1, 2, 1)
+for c, res in ((32, 1025), (64, 513), (128, 257), (256, 129), (32, 1024), (64, 512), (32, 1028), (64, 516), (128, 260), (256, 132)):
+    pad = (1, 1, 1, 1) if res % 2 else ((2, 1, 2, 1) if res % 8 == 0 else (1, -2, 1, -2))     # (2H+1)^2 natural / blur before a stride-2 conv / (2H+4)^2 padded up-layer map
     x = torch.randn(8, c, res, res, device='cuda')
     y = kernels.upfirdn2d(x, k, pad=pad)
     torch.cuda.synchronize()
