@@ -53,7 +53,10 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic) { retur
 template <int BM> struct WSlots { static constexpr int value = (BM == 128) ? 10 : (BM == 64 ? 8 : 4); };
 
 // NIN: input slots per thread per chunk (floats, or float4 when VEC); NWV: weight float4 slots per thread per chunk
-template <int WM, int WN, bool VEC, bool MASK>
+// KT > 0: square KT x KT kernel known at compile time (the 3x3 stride-2 / small-map layers and the strided 1x1s on the hot tile): the tap loop
+// unrolls into immediate LDS offsets, its address arithmetic and loop control leave the MFMA stream and hipcc fetches the next taps'
+// fragments ahead of the MFMAs that use them (round-1 finding: 3.3 VALU per MFMA and 55 % matrix-pipe busy with run-time tap loops)
+template <int WM, int WN, bool VEC, bool MASK, int KT = 0>
 __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2 : 1)) void conv_mfma_kernel(const l2i_conv_params p, const ConvLaunch L) {
     constexpr int BM = WM * 32;
     constexpr int NIN = VEC ? (MASK ? 4 : 8) : 12;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
     const int wave = tid >> 6;
     const int half = lane >> 5;
     const int j = lane & 31;
-    const int KK = p.KH * p.KW;
+    const int KK = KT ? KT * KT : p.KH * p.KW;
     const int TW = 1 << L.tw_log2, TH = 1 << L.th_log2;
 
     // ---- block -> (sample group, tile, channel block).  Blocks are dealt round-robin to the 8 XCDs: renumber them so that the channel
@@ -227,20 +230,43 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
             float sv[WN];
 #pragma unroll
             for (int n = 0; n < WN; ++n) sv[n] = lds_sc[sbase[n] + cc];
-            for (int ky = 0; ky < p.KH; ++ky) {
-                for (int kx = 0; kx < p.KW; ++kx) {
-                    float a[WM], bb[WN];
-                    const int toff = ky * L.IWp + kx;
+            if constexpr (KT > 0) {
+                const float* ib[WN];
 #pragma unroll
-                    for (int m = 0; m < WM; ++m) a[m] = wr[m * 32];
+                for (int n = 0; n < WN; ++n) ib[n] = ir + pixoff[n];
 #pragma unroll
-                    for (int n = 0; n < WN; ++n) bb[n] = ir[pixoff[n] + toff] * sv[n];
+                for (int ky = 0; ky < KT; ++ky) {
+                    const int roff = ky * L.IWp;
 #pragma unroll
-                    for (int m = 0; m < WM; ++m)
+                    for (int kx = 0; kx < KT; ++kx) {
+                        float a[WM], bb[WN];
 #pragma unroll
-                        for (int n = 0; n < WN; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[n], acc[m][n], 0, 0, 0);
-                    wr += BM;
+                        for (int m = 0; m < WM; ++m) a[m] = wr[(ky * KT + kx) * BM + m * 32];
+#pragma unroll
+                        for (int n = 0; n < WN; ++n) bb[n] = ib[n][roff + kx] * sv[n];
+#pragma unroll
+                        for (int m = 0; m < WM; ++m)
+#pragma unroll
+                            for (int n = 0; n < WN; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[n], acc[m][n], 0, 0, 0);
+                    }
+                }
+            } else {
+                for (int ky = 0; ky < p.KH; ++ky) {
+                    for (int kx = 0; kx < p.KW; ++kx) {
+                        float a[WM], bb[WN];
+                        const int toff = ky * L.IWp + kx;
+#pragma unroll
+                        for (int m = 0; m < WM; ++m) a[m] = wr[m * 32];
+#pragma unroll
+                        for (int n = 0; n < WN; ++n) bb[n] = ir[pixoff[n] + toff] * sv[n];
+#pragma unroll
+                        for (int m = 0; m < WM; ++m)
+#pragma unroll
+                            for (int n = 0; n < WN; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[n], acc[m][n], 0, 0, 0);
+                        wr += BM;
+                    }
                 }
             }
         }
@@ -624,9 +650,23 @@ static hipError_t launch_one(const l2i_conv_params& p, const ConvLaunch& L, int 
     return hipGetLastError();
 }
 
+template <int WM, int WN, bool MASK, int KT>
+static hipError_t launch_one_kt(const l2i_conv_params& p, const ConvLaunch& L, int grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, false, MASK, KT>), dim3(grid), dim3(256), lds, st, p, L);
+    return hipGetLastError();
+}
+
 template <int WM, int WN>
 static hipError_t launch_cfg(const l2i_conv_params& p, const ConvLaunch& L, int grid, size_t lds, bool vec, hipStream_t st) {
     const bool mask = p.in_mask != nullptr;
+    if constexpr (WM == 2 && WN == 2) {                 // the hot tile of the stride-2 / small-map layers: compile-time tap loops
+        if (!vec && p.KH == p.KW && (p.KH == 3 || p.KH == 1)) {
+            hipError_t (*fn)(const l2i_conv_params&, const ConvLaunch&, int, size_t, hipStream_t) = nullptr;
+            if (p.KH == 3) fn = mask ? &launch_one_kt<2, 2, true, 3> : &launch_one_kt<2, 2, false, 3>;
+            else fn = mask ? &launch_one_kt<2, 2, true, 1> : &launch_one_kt<2, 2, false, 1>;
+            return fn(p, L, grid, lds, st);
+        }
+    }
     if (vec) return mask ? launch_one<WM, WN, true, true>(p, L, grid, lds, st) : launch_one<WM, WN, true, false>(p, L, grid, lds, st);
     return mask ? launch_one<WM, WN, false, true>(p, L, grid, lds, st) : launch_one<WM, WN, false, false>(p, L, grid, lds, st);
 }

@@ -480,7 +480,7 @@ extern "C" int l2i_conv_transpose2d_f32(const l2i_conv_params* pp, void* stream)
     hipStream_t st = (hipStream_t)stream;
     // 128 positions per block (three blocks per CU) on maps up to 33 positions wide, where 256-position tiles leave a CU with one
     // or two blocks for most of the launch; 256 positions (two per CU, half the weight traffic per MFMA) above.  tile_hint 1 / 2 force.
-    const bool narrow = p.tile_hint == 1 || (p.tile_hint != 2 && (p.OWf + 1) / 2 <= 33);
+    const bool narrow = p.tile_hint == 1 || (p.tile_hint != 2 && ((p.OWf + 1) / 2 <= 33 || p.W <= 33));     // (outputs may be up to 8 larger than natural)
     if (p.KH == 3 && p.pad_y == 0) return narrow ? launch_convt<3, 0, 1>(p, st) : launch_convt<3, 0, 2>(p, st);
     if (p.KH == 3 && p.pad_y == 1) return narrow ? launch_convt<3, 1, 1>(p, st) : launch_convt<3, 1, 2>(p, st);
     if (p.KH == 7 && p.pad_y == 3) return launch_convt<7, 3, 2>(p, st);
