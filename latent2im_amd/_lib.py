@@ -34,7 +34,11 @@ class ConvParams(ctypes.Structure):
         ('accumulate', c_i), ('tile_hint', c_i),
         ('w_hi', c_p), ('w_lo', c_p),
         ('ws', c_p), ('ksplit', c_i), ('res_sub', c_p), ('res_coef', c_f), ('res_coef_dev', c_p),
+        ('sq_ref', c_p), ('sq_out', c_p),
     ]
+
+
+SQ_SLOTS = 1024          # L2I_SQ_SLOTS
 
 
 _SIGNATURES = {

@@ -316,7 +316,7 @@ def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), 
 
 def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0), out_scale=None, noise=None,
                noise_w=0.0, bias=None, residual=None, res_mask=None, out_mask=None, act=ACT_NONE, slope=0.2, gain=1.0,
-               out_gain=1.0, accumulate=False, tile_hint=0, res_sub=None, res_coef=1.0, res_coef_dev=None):
+               out_gain=1.0, accumulate=False, tile_hint=0, res_sub=None, res_coef=1.0, res_coef_dev=None, sq=None):
     """Enqueue one kernel call on the current stream.  ``y`` is the full output tensor [B, Cout, OHf, OWf]."""
     lib = _lib.load()
     B, cin, H, W = x.shape
@@ -364,6 +364,10 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
           and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise, res_sub)):
         p.w = _lib.fptr(L.wino_pack())
         entry, name = lib.l2i_conv2d_wino_f32, 'l2i_conv2d_wino_f32'
+        if sq is not None and sq[0].data_ptr() % 16 == 0:    # sq = (reference like y, [SQ_SLOTS] zeroed accumulator, [fused flag]): sum (y - ref)^2 in the epilogue
+            assert sq[0].shape == y.shape and sq[1].numel() == _lib.SQ_SLOTS
+            p.sq_ref, p.sq_out = _lib.fptr(sq[0]), _lib.fptr(sq[1])
+            sq[2][0] = True
     elif L.kh * L.kw > 1 and L.cout > 4:
         _split_k(p, B * OH * OW, cin, y)                  # small maps of the generic kernel (the Winograd / split-precision kernels take maps >= 32 wide)
     if PROFILE is not None:

@@ -485,6 +485,7 @@ extern "C" int l2i_conv_transpose2d_bf16x3_f32(const l2i_conv_params* pp, void* 
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OHf <= 0 || p.OWf <= 0)
         return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: non-positive dimension");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: CoutP must be Cout rounded up to 32");
+    if (p.sq_ref || p.sq_out) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d_bf16x3: sq_ref / sq_out are fused in l2i_conv2d_wino_f32 only");
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
     const int nat = (p.H - 1) * 2 - 2 * p.pad_y + 3, natw = (p.W - 1) * 2 - 2 * p.pad_x + 3;
     if (p.KH != 3 || p.KW != 3 || p.stride != 2 || p.pad_y != p.pad_x || p.pad_x < 0 || p.pad_x > 1 || (p.Cin % 16) != 0 || (p.W % 4) != 0 || p.W < 32 ||
@@ -522,6 +523,7 @@ extern "C" int l2i_conv2d_bf16x3_f32(const l2i_conv_params* pp, void* stream) {
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0)
         return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: non-positive dimension");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: CoutP must be Cout rounded up to 32");
+    if (p.sq_ref || p.sq_out) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_bf16x3: sq_ref / sq_out are fused in l2i_conv2d_wino_f32 only");
     if (p.res_sub && !p.residual) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: res_sub needs residual");
     if (p.oy_off < 0 || p.ox_off < 0 || p.OH + p.oy_off > p.OHf || p.OW + p.ox_off > p.OWf)
         return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: output window exceeds the output tensor");

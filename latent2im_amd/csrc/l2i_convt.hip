@@ -460,6 +460,7 @@ extern "C" int l2i_conv_transpose2d_f32(const l2i_conv_params* pp, void* stream)
     if (!p.x || !p.w || !p.y) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: null tensor");
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: non-positive dimension");
     if (p.KH != p.KW || p.pad_y != p.pad_x) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: square kernels / symmetric padding only");
+    if (p.sq_ref || p.sq_out) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: sq_ref / sq_out are fused in l2i_conv2d_wino_f32 only");
     if (p.CoutP == 4 && p.Cout <= 3) {                   // <= 3 output channels, [Cin][K*K][4] weight pack: the fused VALU kernel (l2i_convt_small.hip)
         if (p.bias || p.noise || p.residual || p.res_mask || p.res_sub || p.out_mask || p.act != L2I_ACT_NONE)
             return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: only in_mask / out_gain / accumulate are fused in the small-output kernel");

@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
         nz = *reinterpret_cast<const float4*>(p.noise + (size_t)b * plane_o + poff);
         nz.x *= p.noise_w; nz.y *= p.noise_w; nz.z *= p.noise_w; nz.w *= p.noise_w;
     }
+    float sq = 0.f;
 #pragma unroll 2
     for (int it = 0; it < 8; ++it) {
         const int chn = 4 * it + chl;
@@ -322,7 +323,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
             *reinterpret_cast<float4*>(p.y + oidx) = v;
+            if (p.sq_ref) {                                        // ContentLoss value of a VGG tap: sum (y - reference)^2 while y is in registers
+                const float4 rf = *reinterpret_cast<const float4*>(p.sq_ref + oidx);
+                const float d0 = v.x - rf.x, d1 = v.y - rf.y, d2 = v.z - rf.z, d3 = v.w - rf.w;
+                sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
         }
+    }
+    if (p.sq_ref) {                                                // (kernel argument: uniform branch) one atomic per block, 1024 slots
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+        __syncthreads();                                           // every lane is past its reads of the epilogue tables
+        if (lane == 0) tab[wave] = sq;
+        __syncthreads();
+        if (tid == 0) atomicAdd(p.sq_out + (blockIdx.x & (L2I_SQ_SLOTS - 1)), (tab[0] + tab[1]) + (tab[2] + tab[3]));
     }
 }
 
@@ -361,5 +375,6 @@ extern "C" int l2i_conv2d_wino_f32(const l2i_conv_params* pp, void* stream) {
     if ((size_t)p.Cin * p.H * p.W * sizeof(float) >= 0xFFFFFFF0ull || (size_t)p.Cin * 16 * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino: one sample / the weight pack must stay below 4 GiB (32-bit buffer offsets)");
     if (p.tile_hint != 0) return l2i_set_error(L2I_E_ARG, "conv2d_wino: tile_hint must be 0 (one configuration)");
+    if ((p.sq_ref != nullptr) != (p.sq_out != nullptr) || (((uintptr_t)p.sq_ref) % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv2d_wino: sq_ref (16-byte aligned) and sq_out go together");
     return launch_wino(p, (hipStream_t)stream);
 }

@@ -30,15 +30,26 @@ class VGG19Prefix:
                        for i in (0, 2, 5, 7)]
         self.neg_mean = (-torch.tensor(VGG_MEAN, dtype=torch.float32)).to(device)
 
-    def taps(self, img):
-        """[B,3,H,W] -> (c1, c2, p, c3, c4, pool_idx): pre-ReLU conv outputs conv_1..conv_4, p = maxpool(c2)."""
+    def taps(self, img, org=None):
+        """[B,3,H,W] -> (c1, c2, p, c3, c4, pool_idx): pre-ReLU conv outputs conv_1..conv_4, p = maxpool(c2).
+        ``org`` = the four taps of the original image: returns a seventh element, the four sums of (c_k - org_k)^2 as 1-element tensors.
+        Where a tap's conv runs on the Winograd kernel the sum is formed in its epilogue (the map is still in registers: no second pass
+        over it); otherwise by ``sqdiff``."""
         xc = K.fused_bias_act(img.contiguous(), self.neg_mean, None, 1, 0, 0.0, 1.0)        # x - mean
-        c1 = self.convs[0].forward(xc, bias=self.biases[0])
-        c2 = self.convs[1].forward(c1, in_mask=c1, mask=(1.0, 0.0), bias=self.biases[1])
+        sq = [None] * 4
+        if org is not None:
+            acc = torch.zeros(4, C._lib.SQ_SLOTS, device=img.device, dtype=torch.float32)
+            sq = [(org[k], acc[k], [False]) for k in range(4)]
+        c1 = self.convs[0].forward(xc, bias=self.biases[0], sq=sq[0])
+        c2 = self.convs[1].forward(c1, in_mask=c1, mask=(1.0, 0.0), bias=self.biases[1], sq=sq[1])
         p, idx = K.maxpool2d_fwd(c2, 2, 2, 0)                     # relu(maxpool(.)) == maxpool(relu(.))
-        c3 = self.convs[2].forward(p, in_mask=p, mask=(1.0, 0.0), bias=self.biases[2])
-        c4 = self.convs[3].forward(c3, in_mask=c3, mask=(1.0, 0.0), bias=self.biases[3])
-        return c1, c2, p, c3, c4, idx
+        c3 = self.convs[2].forward(p, in_mask=p, mask=(1.0, 0.0), bias=self.biases[2], sq=sq[2])
+        c4 = self.convs[3].forward(c3, in_mask=c3, mask=(1.0, 0.0), bias=self.biases[3], sq=sq[3])
+        if org is None:
+            return c1, c2, p, c3, c4, idx
+        mine = (c1, c2, c3, c4)
+        sums = [acc[k].sum().reshape(1) if sq[k][2][0] else K.sqdiff(org[k], mine[k])[0] for k in range(4)]
+        return c1, c2, p, c3, c4, idx, sums
 
     def content_losses(self, org, shifted):
         """Four mse(feat_k(org).detach(), feat_k(shifted)) scalars as one [4] tensor, differentiable w.r.t. shifted."""
@@ -50,9 +61,8 @@ class VGG19Prefix:
 class _ContentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, net, org_taps):
-        c1, c2, p, c3, c4, idx = net.taps(img.detach())
+        c1, c2, p, c3, c4, idx, sums = net.taps(img.detach(), org=org_taps)
         mine = (c1, c2, c3, c4)
-        sums = [K.sqdiff(a, b)[0] for a, b in zip(org_taps, mine)]
         losses = torch.cat([s / float(b.numel()) for s, b in zip(sums, mine)])
         if img.requires_grad:
             ctx.net, ctx.org, ctx.acts, ctx.in_hw = net, org_taps, (c1, c2, p, c3, c4, idx), (img.shape[2], img.shape[3])

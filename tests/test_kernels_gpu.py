@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from latent2im_amd import conv, kernels, synth
+from latent2im_amd import _lib, conv, kernels, synth
 from oracle import sg2
 
 pytestmark = pytest.mark.gpu
@@ -214,10 +214,18 @@ def test_winograd_3x3_conv(cin, cout, h, w, b):
             continue
         err = float((got.double().cpu() - want).abs().max() / want.abs().max())
         assert err < 5e-6, err
+    # ContentLoss value fused into the epilogue (VGG taps): sum (y - reference)^2 over the launch, partial tiles and padded channels excluded
+    sq_acc, fused = torch.zeros(_lib.SQ_SLOTS, device=DEV), [False]
+    y4 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.0), bias=g(bias), sq=(g(res), sq_acc, fused))
+    want_sq = float(((y4.double().cpu() - D(res)) ** 2).sum())
+    assert fused[0] and abs(float(sq_acc.double().sum()) - want_sq) <= 1e-5 * want_sq
     # the direct kernel on the same problem, for scale (and as a cross-check of the dispatch switch)
     conv.USE_WINOGRAD = False
     try:
         y0 = fc.forward(g(x), in_scale=g(s), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+        fused = [False]
+        fc.forward(g(x), bias=g(bias), sq=(g(res), sq_acc, fused))
+        assert not fused[0]                                        # other kernels leave the sum to the caller (perceptual.taps falls back to sqdiff)
     finally:
         conv.USE_WINOGRAD = True
     e0 = float((y0.double().cpu() - ref1).abs().max() / ref1.abs().max())

@@ -193,7 +193,7 @@ def test_pggan_graph_gradient_strong_walk_vs_float64_oracle(golden):
     oloss = opg.total_loss(oreg, ocont, None, no_content_loss=False, no_gan_loss=True)
     ograd, = torch.autograd.grad(oloss, walk)
     assert float((ox1 - ox0).detach().abs().max()) > 0.05 * float(ox0.abs().max())           # the edit is visible: this test has signal
-    np.testing.assert_allclose(x1.detach().cpu().numpy(), ox1.detach().numpy(), rtol=1e-3, atol=1e-4 * float(ox1.abs().max()))
+    np.testing.assert_allclose(x1.detach().cpu().numpy(), ox1.detach().numpy(), rtol=1e-3, atol=1e-4 * float(ox1.detach().abs().max()))
     np.testing.assert_allclose(float(graph.last_terms['reg'].detach()), float(oreg), rtol=1e-4)
     np.testing.assert_allclose(float(graph.last_terms['cont'].detach()), float(ocont), rtol=1e-3)
     np.testing.assert_allclose(float(loss.detach()), float(oloss), rtol=1e-4)
