@@ -370,6 +370,11 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
             sq[2][0] = True
     elif L.kh * L.kw > 1 and L.cout > 4:
         _split_k(p, B * OH * OW, cin, y)                  # small maps of the generic kernel (the Winograd / split-precision kernels take maps >= 32 wide)
+    if (sq is not None and name == 'l2i_conv2d_f32' and tile_hint == 0 and sq[0].data_ptr() % 16 == 0 and p.ksplit <= 1
+            and lib.l2i_conv2d_family(p) == 2):           # L2I_FAMILY_CIN3: the <= 3-input-channel kernel sums (y - ref)^2 in its epilogue too
+        assert sq[0].shape == y.shape and sq[1].numel() == _lib.SQ_SLOTS
+        p.sq_ref, p.sq_out = _lib.fptr(sq[0]), _lib.fptr(sq[1])
+        sq[2][0] = True
     if PROFILE is not None:
         family = {'l2i_conv2d_wino_f32': 'winograd_f32', 'l2i_conv2d_bf16x3_f32': 'implicit_gemm_bf16x3'}.get(name)
         if family is None:

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256, 3) void conv_cin3_kernel(const l2i_conv_params
     const size_t plane_o = (size_t)p.OHf * p.OWf;
     const int q8 = lane & 7, chl = lane >> 3;                  // wide pass: lane = (channel within 8, 4-pixel group)
     // a wave walks 4 strips of 32 pixels: rows 2*wave, 2*wave+1, column halves 0 / 1
+    float sq = 0.f;
 #pragma unroll 1
     for (int st = 0; st < 4; ++st) {
         const int row = 2 * wave + (st >> 1), cx = (st & 1) * 32;
@@ -107,9 +108,23 @@ __global__ __launch_bounds__(256, 3) void conv_cin3_kernel(const l2i_conv_params
                     v.x = __builtin_fmaxf(v.x, 0.f); v.y = __builtin_fmaxf(v.y, 0.f); v.z = __builtin_fmaxf(v.z, 0.f); v.w = __builtin_fmaxf(v.w, 0.f);
                 }
                 v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain;
-                *reinterpret_cast<float4*>(p.y + ((size_t)b * p.Cout + co) * plane_o + (size_t)oy * p.OWf + ox) = v;
+                const size_t oidx = ((size_t)b * p.Cout + co) * plane_o + (size_t)oy * p.OWf + ox;
+                *reinterpret_cast<float4*>(p.y + oidx) = v;
+                if (p.sq_ref) {                                    // ContentLoss value of VGG conv_1 (see l2i.h: sq_ref / sq_out)
+                    const float4 rf = *reinterpret_cast<const float4*>(p.sq_ref + oidx);
+                    const float d0 = v.x - rf.x, d1 = v.y - rf.y, d2 = v.z - rf.z, d3 = v.w - rf.w;
+                    sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
             }
         }
+    }
+    if (p.sq_ref) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+        __syncthreads();                                           // the staged tile is no longer read
+        if (lane == 0) tile[wave] = sq;
+        __syncthreads();
+        if (tid == 0) atomicAdd(p.sq_out + (blockIdx.x & (L2I_SQ_SLOTS - 1)), (tile[0] + tile[1]) + (tile[2] + tile[3]));
     }
 }
 

@@ -765,7 +765,8 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
     if (!dense4 && (p.CoutP < p.Cout || (p.CoutP % 32) != 0)) return l2i_set_error(L2I_E_ARG, "conv2d: CoutP must be Cout rounded up to 32 (or 4 for the direct kernel of <= 4 channels)");
     if (dense4 && l2i_conv2d_family(pp) != L2I_FAMILY_DIRECT_SMALL) return l2i_set_error(L2I_E_ARG, "conv2d: the [Cin][K*K][4] pack is for launches of the direct <= 4-channel kernel only");
     if (p.res_sub && !p.residual) return l2i_set_error(L2I_E_ARG, "conv2d: res_sub needs residual");
-    if (p.sq_ref || p.sq_out) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d: sq_ref / sq_out are fused in l2i_conv2d_wino_f32 only");
+    if ((p.sq_ref || p.sq_out) && !(p.sq_ref && p.sq_out && (((uintptr_t)p.sq_ref) % 16) == 0 && p.tile_hint == 0 && l2i_cin3_eligible(p)))
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d: sq_ref / sq_out are fused in l2i_conv2d_wino_f32 and in the <= 3-input-channel kernel only");
     if (p.oy_step <= 0 || p.ox_step <= 0 || (p.OH - 1) * p.oy_step + p.oy_off >= p.OHf || (p.OW - 1) * p.ox_step + p.ox_off >= p.OWf ||
         p.oy_off < 0 || p.ox_off < 0)
         return l2i_set_error(L2I_E_ARG, "conv2d: output window exceeds the output tensor");

@@ -232,6 +232,20 @@ def test_winograd_3x3_conv(cin, cout, h, w, b):
     assert e0 < 5e-6, e0
 
 
+def test_content_loss_sum_fused_into_the_three_channel_conv():
+    """VGG conv_1 (3 -> 64, 3x3) runs on the <= 3-input-channel kernel, which also sums (y - reference)^2 in its epilogue."""
+    rs = np.random.RandomState(3)
+    wt, bias = T(rs.randn(64, 3, 3, 3) / 5.0), T(rs.randn(64))
+    x, ref = T(rs.randn(2, 3, 40, 72)), T(rs.randn(2, 64, 40, 72))
+    fc = conv.FrozenConv2d(wt, 1, 1, device=DEV)
+    acc, fused = torch.zeros(_lib.SQ_SLOTS, device=DEV), [False]
+    y = fc.forward(x.to(DEV), bias=bias.to(DEV), sq=(ref.to(DEV), acc, fused))
+    want = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    close(y, want.float(), 1e-4, 2e-5)
+    assert fused[0]
+    np.testing.assert_allclose(float(acc.double().sum()), float(((want - ref.double()) ** 2).sum()), rtol=1e-5)
+
+
 @pytest.mark.parametrize('cin,cout,h,w,b', [(64, 256, 32, 32, 2), (256, 64, 16, 64, 1), (1024, 256, 16, 16, 2), (128, 512, 16, 32, 3), (16, 64, 64, 64, 1)])
 def test_gemm_1x1_conv(cin, cout, h, w, b):
     """Unmasked 1x1 stride-1 layers take the DMA-fed GEMM kernel (l2i_gemm.hip) inside l2i_conv2d_f32; same results as the generic
