@@ -238,6 +238,60 @@ __global__ __launch_bounds__(256) void upfirdn2d_k4_kernel(const UfdParams p) {
     }
 }
 
+// 4x4 FIR with down = 2, pad0 = 1 on wide maps: the Blur in front of the discriminator's stride-2 1x1 skip conv (networks.py:530-536, :586-590),
+// evaluated only at the pixels that conv samples.  Register-streaming like upfirdn2d_k4_stream_kernel: a lane owns two output columns
+// (input columns 4l - 1 .. 4l + 4: one aligned 16-byte load + one value from each neighbour lane) and walks RS output rows, two new input rows
+// per output row.  Taps in (ky, kx) order: the same sums as the generic kernel.
+__global__ __launch_bounds__(256) void upfirdn2d_k4_down2_stream_kernel(const UfdParams p, int bands, int strips) {
+    constexpr int RS = 8;
+    float kf[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) kf[t] = p.k[15 - t];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long bid = blockIdx.x;
+    const int strip = (int)(bid % strips); bid /= strips;
+    const int band = (int)(bid % bands);
+    const long long mj = bid / bands;
+    const int ox = strip * 128 + lane * 2;                             // output columns ox, ox + 1; input vector at column 2 ox
+    const int oy0 = (band * 4 + wave) * RS;
+    if (oy0 >= p.out_h) return;
+    const float* xin = p.x + mj * (long long)p.in_h * p.in_w;
+    float win[4][6];
+    auto load_row = [&](int iy, float (&w)[6]) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool rok = iy >= 0 && iy < p.in_h;
+        const float* row = xin + (long long)iy * p.in_w;
+        const int ix = 2 * ox;
+        if (rok && ix < p.in_w) v = *reinterpret_cast<const float4*>(row + ix);
+        float l1 = __shfl_up(v.w, 1), r1 = __shfl_down(v.x, 1);
+        if (lane == 0) l1 = (rok && ix - 1 >= 0 && ix - 1 < p.in_w) ? row[ix - 1] : 0.f;
+        if (lane == 63) r1 = (rok && ix + 4 < p.in_w) ? row[ix + 4] : 0.f;
+        w[0] = l1; w[1] = v.x; w[2] = v.y; w[3] = v.z; w[4] = v.w; w[5] = r1;
+    };
+    const int iy0 = 2 * oy0 - 1;                                       // pad_y0 = 1
+    load_row(iy0, win[0]);
+    load_row(iy0 + 1, win[1]);
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        // window rows of output row oy0 + r: input rows iy0 + 2r .. iy0 + 2r + 3 in slots (2r + ky) & 3
+        load_row(iy0 + 2 * r + 2, win[(2 * r + 2) & 3]);
+        load_row(iy0 + 2 * r + 3, win[(2 * r + 3) & 3]);
+        const int oy = oy0 + r;
+        if (oy >= p.out_h || ox >= p.out_w) continue;                  // out_w % 2 == 0: both columns are inside together
+        float o[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float v = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) v += win[(2 * r + ky) & 3][2 * q + kx] * kf[ky * 4 + kx];
+            o[q] = v;
+        }
+        *reinterpret_cast<float2*>(p.y + (mj * p.out_h + oy) * p.out_w + ox) = make_float2(o[0], o[1]);
+    }
+}
+
 // up = 2, down = 1, 4x4 FIR, pad0 = 2 (the ToRGB skip upsample, networks.py:35-43 / :353-356, on 3-channel images): a thread owns a 2 x 4
 // patch of outputs (rows 2i, 2i + 1; columns 4j .. 4j + 3) = input rows i - 1 .. i + 1, columns 2j - 1 .. 2j + 2.  Every output sums its
 // 2 x 2 live taps in the generic kernel's (ky, kx) order (bit-identical results); 16-byte stores, addend read as 16-byte vectors.
@@ -414,6 +468,16 @@ extern "C" int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64
         hipLaunchKernelGGL(upfirdn2d_k4_kernel, dim3(l2i_grid_for(nt, 1, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p);
         L2I_CHECK_LAUNCH();
         return L2I_OK;
+    }
+    if (up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2 && kh == 4 && kw == 4 && pad_x0 == 1 && pad_y0 == 1 && p.out_w >= 96 && (in_w % 4) == 0 &&
+        (p.out_w % 2) == 0 && !noise && !bias && !addend && act == L2I_ACT_NONE && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)y) % 8) == 0) {
+        const int strips = (p.out_w + 127) / 128, bands = (p.out_h + 31) / 32;
+        const long long grid = major * bands * strips;
+        if (grid > 0 && grid <= 0x7fffffffLL) {
+            hipLaunchKernelGGL(upfirdn2d_k4_down2_stream_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, bands, strips);
+            L2I_CHECK_LAUNCH();
+            return L2I_OK;
+        }
     }
     if (up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 && pad_x0 == 2 && pad_y0 == 2 && p.out_h == 2 * in_h && p.out_w == 2 * in_w &&
         (p.out_w % 4) == 0 && (((uintptr_t)y | (uintptr_t)addend) % 16) == 0) {

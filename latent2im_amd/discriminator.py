@@ -24,6 +24,11 @@ def _eq_conv(P, name, stride, padding, device):
     return C.FrozenConv2d(w, stride=stride, padding=padding, device=device)
 
 
+def _skip_compact(h):
+    """Maps wide enough for the down-2 streaming FIR (csrc/l2i_stream.hip) take the compact skip path."""
+    return h >= 192 and h % 8 == 0
+
+
 def _vec(P, name, device):
     return torch.as_tensor(np.asarray(P[name]), dtype=torch.float32).contiguous().to(device)
 
@@ -42,6 +47,7 @@ class Discriminator:
                 c1=_eq_conv(P, p + '.conv1.0.weight', 1, 1, device), b1=_vec(P, p + '.conv1.1.bias', device),
                 c2=_eq_conv(P, p + '.conv2.1.weight', 2, 0, device), b2=_vec(P, p + '.conv2.2.bias', device),
                 sk=_eq_conv(P, p + '.skip.1.weight', 2, 0, device),
+                sk1=_eq_conv(P, p + '.skip.1.weight', 1, 0, device),       # the same 1x1 at stride 1, for blur maps evaluated at the sampled pixels only
                 k=_vec(P, p + '.conv2.0.kernel', device)))
         for blk in self.blocks:
             blk['kf'] = torch.flip(blk['k'], [0, 1]).contiguous()
@@ -106,9 +112,16 @@ class _DBodyFn(torch.autograd.Function):
             y2 = torch.empty(b_, blk['c2'].cout, h // 2, h // 2, device=cur.device, dtype=torch.float32)
             blk['c2'].forward(t, out=y2, bias=blk['b2'], act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
             del t
-            ts = K.upfirdn2d(cur, blk['k'], pad=(1, 2, 1, 2))                  # Blur before the stride-2 1x1 skip: (h-1)^2 -> h^2 likewise
             out = torch.empty(b_, blk['sk'].cout, h // 2, h // 2, device=cur.device, dtype=torch.float32)
-            blk['sk'].forward(ts, out=out, residual=y2, out_gain=1.0 / SQRT2)  # (conv2 + skip) / sqrt2
+            if _skip_compact(h):
+                # Blur before the stride-2 1x1 skip (networks.py:586-590: pad (1,1), an (h-1)^2 map of which the conv reads every second pixel):
+                # only those pixels are computed (FIR with down = 2: a quarter of the writes), and the 1x1 runs at stride 1 on the compact
+                # map — the DMA-fed GEMM kernel instead of a strided gather.  Same taps, same sums: identical values.
+                ts = K.upfirdn2d(cur, blk['k'], down=(2, 2), pad=(1, 1, 1, 1))
+                blk['sk1'].forward(ts, out=out, residual=y2, out_gain=1.0 / SQRT2)
+            else:
+                ts = K.upfirdn2d(cur, blk['k'], pad=(1, 2, 1, 2))              # small maps: the full (h-1)^2 -> h^2 map (16-byte rows), stride-2 conv
+                blk['sk'].forward(ts, out=out, residual=y2, out_gain=1.0 / SQRT2)  # (conv2 + skip) / sqrt2
             del ts
             if keep:
                 saved.append((y1, y2, (cur.shape[2], cur.shape[3])))
@@ -132,8 +145,13 @@ class _DBodyFn(torch.autograd.Function):
             g_a = blk['c1'].dgrad(g_y1, in_hw, in_mask=y1, mask=LRELU_MASK)
             del g_y1
             # skip path
-            g_ts = blk['sk'].dgrad(g, (h, h), out_gain=1.0 / SQRT2)
-            g = K.upfirdn2d(g_ts, blk['kf'], pad=(2, 1, 2, 1), addend=g_a)
+            if _skip_compact(h):
+                # adjoint of (blur, keep every second pixel): zero-insertion FIR (up = 2) of the compact gradient (op/upfirdn2d.py:105-115: g_pad = (2, 1))
+                g_ts = blk['sk1'].dgrad(g, (h // 2, h // 2), out_gain=1.0 / SQRT2)
+                g = K.upfirdn2d(g_ts, blk['kf'], up=(2, 2), pad=(2, 1, 2, 1), addend=g_a)
+            else:
+                g_ts = blk['sk'].dgrad(g, (h, h), out_gain=1.0 / SQRT2)
+                g = K.upfirdn2d(g_ts, blk['kf'], pad=(2, 1, 2, 1), addend=g_a)
             del g_ts, g_a
         g_img = net.conv0.dgrad(g, ctx.in_hw, in_mask=saved[0], mask=LRELU_MASK)
         ctx.saved = None

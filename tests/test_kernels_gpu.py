@@ -362,6 +362,12 @@ def test_upfirdn2d_fused_epilogue():
         ref = F.conv2d(xp.reshape(-1, 1, xp.shape[2], xp.shape[3]), torch.flip(k, [0, 1])[None, None]).reshape(2, 5, oh, ow)
         close(y, F.leaky_relu(ref + 0.4 * nz + b[None, :, None, None] + add, 0.2) * 2 ** 0.5, 1e-5, 1e-5)
         close(kernels.upfirdn2d(x.to(DEV), k.to(DEV), pad=pad), ref, 1e-5, 1e-5)
+    # Blur evaluated at every second pixel (down = 2, pad (1, 1): the discriminator's skip branch): the streaming kernel on wide maps, the
+    # generic one below 96 output columns
+    for h, w in ((64, 256), (50, 200), (16, 40)):
+        x = T(rs.randn(2, 3, h, w))
+        y = kernels.upfirdn2d(x.to(DEV), (k / 4).to(DEV), down=(2, 2), pad=(1, 1, 1, 1))
+        close(y, sg2.upfirdn2d(x, k / 4, down=2, pad=(1, 1)), 1e-5, 1e-6)
     # the ToRGB skip upsample (up = 2, pad (2, 1), addend = the new rgb; networks.py:353-356): the 2x4-patch kernel (output width % 4 == 0)
     # and, for an odd input width, the generic one
     for h, w in ((8, 6), (33, 64), (5, 7)):
