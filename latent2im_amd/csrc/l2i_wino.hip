@@ -46,6 +46,13 @@ __device__ __forceinline__ f32x2 pk_mul_op(f32x2 a, f32x2 b) { f32x2 r; asm("v_p
 __device__ __forceinline__ f32x2 pk_lo_pm_hi(f32x2 a, f32x2 b) {
     f32x2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
+// the same two with the "VALU write -> MFMA read" wait states attached (layers without a style scale feed them to the MFMAs directly)
+__device__ __forceinline__ f32x2 pk_sub_op(f32x2 a, f32x2 b) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ f32x2 pk_lo_pm_hi_op(f32x2 a, f32x2 b) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
 
 struct WinoLaunch {
     int tiles_x, tiles_y, mblocks;
@@ -64,7 +71,12 @@ constexpr int LDS_FLOATS = 2 * RAWBUF + 2 * NU4 * 4 + TAB;   // raw tile and U d
                                                              // of epilogue transpose strips alias the two U stages
 }
 
-template <bool MASK>
+// SCALE: the launch has a style scale (in_scale: the generator's modulated convs).  Without one (VGG-19, ResNet-50, discriminator and every
+// gradient conv that is not the generator's) the per-channel multiply leaves the MFMA stream: a VALU instruction costs its issue cycles of
+// matrix time (ablation builds: the kernel's time is the MFMA time PLUS its other instructions' issue time, almost without overlap —
+// 0.63 ms = 0.44 (MFMA-bound) + 0.26 (everything else, MFMAs replaced by one FMA each) at 512->512 @64^2), and 16 of the 48 packed VALU
+// instructions of a chunk were that multiply
+template <bool MASK, bool SCALE>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params p, const WinoLaunch L) {
     using namespace wg;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -193,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
                 t01[2] = pk_sub(d2a, d1a); t23[2] = pk_sub(d2b, d1b);
                 t01[3] = pk_sub(d1a, d3a); t23[3] = pk_sub(d1b, d3b);
             }
-            const float sc = tab[par * CK + 4 * s + kq];
-            const f32x2 scp = {sc, sc};
+            f32x2 scp = {1.f, 1.f};
+            if constexpr (SCALE) { const float sc = tab[par * CK + 4 * s + kq]; scp = f32x2{sc, sc}; }
             if (s == 0) fetch_d(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -205,8 +217,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
                 issue_slot(2 * (4 * s + i) + 1, c0n, un, on);
                 __builtin_amdgcn_sched_barrier(0);
                 // (B^T d) B: (v0, v3) = (t0 - t2, t1 - t3);  (v1, v2) = (t2 + t1, t2 - t1); then the style scale of the channel
-                const f32x2 v03 = pk_mul_op(pk_sub(t01[i], t23[i]), scp);
-                const f32x2 v12 = pk_mul_op(pk_lo_pm_hi(t23[i], t01[i]), scp);
+                const f32x2 v03 = SCALE ? pk_mul_op(pk_sub(t01[i], t23[i]), scp) : pk_sub_op(t01[i], t23[i]);
+                const f32x2 v12 = SCALE ? pk_mul_op(pk_lo_pm_hi(t23[i], t01[i]), scp) : pk_lo_pm_hi_op(t23[i], t01[i]);
                 acc[i * 4 + 0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, v03.x, (FIRST && s == 0) ? zero : acc[i * 4 + 0][0], 0, 0, 0);
                 acc[i * 4 + 0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, v03.x, (FIRST && s == 0) ? zero : acc[i * 4 + 0][1], 0, 0, 0);
                 acc[i * 4 + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, v12.x, (FIRST && s == 0) ? zero : acc[i * 4 + 1][0], 0, 0, 0);
@@ -351,8 +363,13 @@ static int launch_wino(const l2i_conv_params& p, hipStream_t st) {
     L.nchunks = p.Cin / wg::CK;
     const size_t lds = (size_t)wg::LDS_FLOATS * sizeof(float);
     const unsigned grid = (unsigned)((total + 7) & ~7L);
-    if (p.in_mask) hipLaunchKernelGGL((conv_wino_kernel<true>), dim3(grid), dim3(256), lds, st, p, L);
-    else hipLaunchKernelGGL((conv_wino_kernel<false>), dim3(grid), dim3(256), lds, st, p, L);
+    if (p.in_scale) {
+        if (p.in_mask) hipLaunchKernelGGL((conv_wino_kernel<true, true>), dim3(grid), dim3(256), lds, st, p, L);
+        else hipLaunchKernelGGL((conv_wino_kernel<false, true>), dim3(grid), dim3(256), lds, st, p, L);
+    } else {
+        if (p.in_mask) hipLaunchKernelGGL((conv_wino_kernel<true, false>), dim3(grid), dim3(256), lds, st, p, L);
+        else hipLaunchKernelGGL((conv_wino_kernel<false, false>), dim3(grid), dim3(256), lds, st, p, L);
+    }
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }
