@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
                             const float4 mk = *reinterpret_cast<const float4*>(p.out_mask + oidx);
                             v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
                         }
-                        v.x += nz.x; v.y += nz.y; v.z += nz.z; v.w += nz.w;
+                        if (p.noise) { v.x += nz.x; v.y += nz.y; v.z += nz.z; v.w += nz.w; }
                         if (p.bias) { const float bv = p.bias[co]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
                         if (p.residual) {
                             float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 4) ? 3 : ((WM == 2 && WN == 4) ? 2
                         } else if (p.act == L2I_ACT_RELU) {
                             v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
                         }
-                        v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain;
+                        if (p.out_gain != 1.f) { v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain; }
                         if (p.accumulate) {
                             const float4 o = *reinterpret_cast<const float4*>(p.y + oidx);
                             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;

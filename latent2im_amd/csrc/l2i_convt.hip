@@ -341,9 +341,11 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
                 const int co = m0 + ch;
                 float4 v = *reinterpret_cast<const float4*>(&strip[ch * 64 + 4 * q4]);
                 if (rowok && co < p.Cout && ox < p.OWf) {
-                    float sc = p.out_gain;
-                    if (osc) sc *= osc[co];
-                    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                    if (osc || p.out_gain != 1.f) {
+                        float sc = p.out_gain;
+                        if (osc) sc *= osc[co];
+                        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                    }
                     float* dst = p.y + ((size_t)bb * p.Cout + co) * plane_o + poff;
                     if (ox + 3 < p.OWf) {
                         *reinterpret_cast<float4*>(dst) = v;                 // 4-byte aligned is enough on gfx950 (probed)

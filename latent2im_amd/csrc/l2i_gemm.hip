@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, (MASK || NOPS > 0) ? 2 : 3) void gemm1x1_kerne
     auto apply = [&](float4 v, int co, size_t oidx, const float4& om, float4 rv, const float4& sb, const float4& rm, const float4& yo) {
         if (p.out_scale) { const float sc = p.out_scale[(size_t)b * p.Cout + co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
         if (p.out_mask) { v.x = om.x > 0.f ? v.x : 0.f; v.y = om.y > 0.f ? v.y : 0.f; v.z = om.z > 0.f ? v.z : 0.f; v.w = om.w > 0.f ? v.w : 0.f; }
-        v.x += nz.x; v.y += nz.y; v.z += nz.z; v.w += nz.w;
+        if (p.noise) { v.x += nz.x; v.y += nz.y; v.z += nz.z; v.w += nz.w; }
         if (p.bias) { const float bv = p.bias[co]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
         if (p.residual) {
             if (p.res_sub) { rv.x = rc * (rv.x - sb.x); rv.y = rc * (rv.y - sb.y); rv.z = rc * (rv.z - sb.z); rv.w = rc * (rv.w - sb.w); }   // res_coef * (residual - res_sub)
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, (MASK || NOPS > 0) ? 2 : 3) void gemm1x1_kerne
         } else if (p.act == L2I_ACT_RELU) {
             v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
         }
-        v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain;
+        if (p.out_gain != 1.f) { v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain; }
         if (p.accumulate) { v.x += yo.x; v.y += yo.y; v.z += yo.z; v.w += yo.w; }
         *reinterpret_cast<float4*>(p.y + oidx) = v;
     };
