@@ -84,8 +84,9 @@ typedef struct l2i_conv_params {
     const float* res_sub;   /* like y, or NULL.  Not NULL: the residual term becomes res_coef * res_coef_dev[0] * (residual - res_sub) — the */
     float res_coef;         /* ContentLoss gradient 2/N * g * (feat - feat_org) of a VGG tap (transform_base.py:57-63) formed inside the     */
     const float* res_coef_dev;  /* gradient conv that consumes it, instead of a separate pass.  res_coef_dev: 1 float on the device or NULL */
-    const float* sq_ref;    /* like y, or NULL.  Not NULL (l2i_conv2d_wino_f32, and launches of l2i_conv2d_f32 that take the <= 3-input-channel    */
-                            /* kernel, L2I_FAMILY_CIN3; everything else refuses it): the launch also adds                                         */
+    const float* sq_ref;    /* like y, or NULL.  Not NULL (l2i_conv2d_wino_f32, l2i_conv2d_bf16x3_f32 with dense 16-byte output rows, and launches */
+                            /* of l2i_conv2d_f32 that take the <= 3-input-channel kernel, L2I_FAMILY_CIN3; everything else refuses it): the launch */
+                            /* also adds                                                                                                          */
     float* sq_out;          /* sum (y - sq_ref)^2 over its outputs into sq_out[0 .. L2I_SQ_SLOTS-1] (fp32 atomics, one slot per block id mod   */
                             /* L2I_SQ_SLOTS; the caller zeroes the slots and sums them): the ContentLoss value of a VGG tap                  */
                             /* (transform_base.py:57-63, mse = the sum / N) without re-reading the feature map in a separate pass             */

@@ -360,6 +360,11 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         planes = L.bf16x3_planes()
         p.w_hi, p.w_lo = _lib.ptr(planes[0]), _lib.ptr(planes[1])
         entry, name = lib.l2i_conv2d_bf16x3_f32, 'l2i_conv2d_bf16x3_f32'
+        if (sq is not None and L.step == 1 and OWf % 4 == 0 and OW % 4 == 0 and sq[0].data_ptr() % 16 == 0
+                and _wino_aligned(y, residual, res_mask, out_mask, noise, res_sub)):      # the vectorised epilogue (l2i_epilogue_vec_ok) sums (y - ref)^2 too
+            assert sq[0].shape == y.shape and sq[1].numel() == _lib.SQ_SLOTS
+            p.sq_ref, p.sq_out = _lib.fptr(sq[0]), _lib.fptr(sq[1])
+            sq[2][0] = True
     elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
           and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise, res_sub)):
         p.w = _lib.fptr(L.wino_pack())

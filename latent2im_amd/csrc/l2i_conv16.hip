@@ -523,7 +523,8 @@ extern "C" int l2i_conv2d_bf16x3_f32(const l2i_conv_params* pp, void* stream) {
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0)
         return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: non-positive dimension");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: CoutP must be Cout rounded up to 32");
-    if (p.sq_ref || p.sq_out) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_bf16x3: sq_ref / sq_out are fused in l2i_conv2d_wino_f32 only");
+    if ((p.sq_ref || p.sq_out) && !(p.sq_ref && p.sq_out && (((uintptr_t)p.sq_ref) % 16) == 0 && l2i_epilogue_vec_ok(p)))
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_bf16x3: sq_ref (16-byte aligned) / sq_out need the vectorised epilogue (dense 16-byte output rows)");
     if (p.res_sub && !p.residual) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: res_sub needs residual");
     if (p.oy_off < 0 || p.ox_off < 0 || p.OH + p.oy_off > p.OHf || p.OW + p.ox_off > p.OWf)
         return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: output window exceeds the output tensor");

@@ -22,6 +22,7 @@ __device__ __forceinline__ void l2i_epilogue_32x32(const l2i_conv_params& p, f32
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const size_t plane_o = (size_t)p.OHf * p.OWf;
     if (vec) {
+        float sq = 0.f;                                        // sq_ref: ContentLoss value of a VGG tap, summed while y is in registers (l2i.h)
         float* reg = smemf + wave * (32 * 64);
         const int ch_l = lane >> 4;
         const int px = (lane & 15) * 4;
@@ -88,9 +89,22 @@ __device__ __forceinline__ void l2i_epilogue_32x32(const l2i_conv_params& p, f32
                             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                         }
                         *reinterpret_cast<float4*>(p.y + oidx) = v;
+                        if (p.sq_ref) {
+                            const float4 rf = *reinterpret_cast<const float4*>(p.sq_ref + oidx);
+                            const float d0 = v.x - rf.x, d1 = v.y - rf.y, d2 = v.z - rf.z, d3 = v.w - rf.w;
+                            sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                        }
                     }
                 }
             }
+        }
+        if (p.sq_ref) {                                        // one atomic per block into L2I_SQ_SLOTS slots
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+            __syncthreads();                                   // every wave is done with its transpose strip
+            if (lane == 0) smemf[wave] = sq;
+            __syncthreads();
+            if (tid == 0) atomicAdd(p.sq_out + (blockIdx.x & (L2I_SQ_SLOTS - 1)), (smemf[0] + smemf[1]) + (smemf[2] + smemf[3]));
         }
         return;
     }

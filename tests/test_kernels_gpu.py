@@ -178,6 +178,18 @@ def test_bf16x3_split_precision_conv(cin, cout, k, stride, pad, h, w, b):
     for got, want in checks:
         err = float((got.double().cpu() - want).abs().max() / want.abs().max())
         assert err < 2e-5, err
+    # ContentLoss value fused into the shared vectorised epilogue (sq_ref): only where the output rows are whole 16-byte vectors
+    if k == 3 and stride == 1:
+        sq_acc, fused = torch.zeros(_lib.SQ_SLOTS, device=DEV), [False]
+        conv.PRECISION = 'bf16x3'
+        try:
+            y4 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.0), bias=g(bias), sq=(g(res), sq_acc, fused))
+        finally:
+            conv.PRECISION = 'f32'
+        assert fused[0] == (ow % 4 == 0)
+        if fused[0]:
+            want_sq = float(((y4.double().cpu() - res.double()) ** 2).sum())
+            assert abs(float(sq_acc.double().sum()) - want_sq) <= 1e-5 * want_sq
 
 
 @pytest.mark.parametrize('cin,cout,h,w,b', [(64, 64, 64, 64, 2), (32, 32, 40, 96, 1), (128, 96, 32, 64, 2), (16, 40, 36, 36, 1),
