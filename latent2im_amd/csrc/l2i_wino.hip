@@ -245,14 +245,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
     commit(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the chunk's U DMA has landed
     __syncthreads();
-    compute(0, std::true_type(), CK, ubuf + NU4 * 4, 1 < L.nchunks);
+    compute(0, std::true_type(), 1 < L.nchunks ? CK : 0, ubuf + NU4 * 4, true);
     for (int ch = 1; ch < L.nchunks; ++ch) {
         const int par = ch & 1;
         commit(par);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's U DMA (issued one chunk ago) has landed
         __syncthreads();                                   // raw tile of this chunk written; every wave is past the MFMAs of the previous chunk,
                                                            // so the other raw / U stage may be refilled
-        compute(par, std::false_type(), (ch + 1) * CK, ubuf + (par ^ 1) * NU4 * 4, ch + 1 < L.nchunks);
+        // (after the last chunk the staging slots re-fetch chunk 0 — valid addresses, L2 hits, never read — instead of switching every
+        //  slot's descriptor to a null one: 32 scalar selects per chunk less in the MFMA stream)
+        compute(par, std::false_type(), ch + 1 < L.nchunks ? (ch + 1) * CK : 0, ubuf + (par ^ 1) * NU4 * 4, true);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (null-descriptor DMA of the last chunk)
     __syncthreads();                                       // the U stages become the transpose strips
