@@ -351,6 +351,26 @@ class TransformGraph:
             best_im_out = self.get_logits({'z': z_new})
         return best_im_out, alpha_org
 
+    def vis_multi_image_batch_alphas(self, graph_inputs, filename, alphas_to_graph, alphas_to_target, batch_start, layers=None, name=None,
+                                     wgt=False, wmask=False, trainEmbed=False, computeL2=False, given_w=None, index_=None):
+        """:714-760: one PNG strip per sample, one panel per requested alpha (``np.uint8(clip((x + 1) / 2 * 255))`` like the reference's
+        loop, which does not use clip_ims here); file name ``<filename>_sample<i>[_wgt][_wmask].png``.  Returns the written paths."""
+        from PIL import Image
+        zs_batch = np.asarray(graph_inputs['z'])
+        ims_transformed = []
+        for ag in alphas_to_graph:
+            best_im_out, alpha_org = self.apply_alpha({'z': torch.Tensor(zs_batch).to(self.device)}, ag, name=name, layers=layers,
+                                                      trainEmbed=trainEmbed, given_w=given_w, index_=0)
+            x = best_im_out.detach().cpu().numpy()
+            ims_transformed.append(np.uint8(np.clip(((x + 1) / 2.0) * 255, 0, 255)))
+        written = []
+        for ii in range(zs_batch.shape[0]):
+            strip = np.concatenate([x[ii].transpose(1, 2, 0) for x in ims_transformed], axis=1)
+            path = filename + '_sample{}'.format(ii + batch_start) + ('_wgt' if wgt else '') + ('_wmask' if wmask else '') + '.png'
+            Image.fromarray(strip).save(path)
+            written.append(path)
+        return written
+
     def vis_image_batch(self, graph_inputs, filename, batch_start, wgt=False, wmask=False, num_panels=7):
         raise NotImplementedError('Subclass should implement vis_image_batch')
 

@@ -212,3 +212,9 @@ def test_pggan_graph_is_found_by_the_plugin_lookup_and_checkpoints_round_trip(go
         graph.walk.w.zero_()
     graph.load_multi_models(str(tmp_path / 'model_w_0_walk_module.ckpt'), None)
     assert type(graph.walk).__module__ == 'graphs.pggan.transform_base' and torch.equal(graph.walk.w.detach(), w)
+    # vis path (vis_w.py flow): alphas from vis_image_batch, one PNG strip per sample
+    zs = synth.z_sample(2, seed=4)
+    a2g, a2t = graph.vis_image_batch({'z': zs}, None, 0, num_panels=3)
+    paths = graph.vis_multi_image_batch_alphas({'z': zs}, str(tmp_path / 'vis'), a2g, a2t, 0)
+    from PIL import Image
+    assert len(paths) == 2 and Image.open(paths[0]).size == (3 * 128, 128)
