@@ -6,7 +6,6 @@ is the walk, reference transform_base.py:329-331), so weights are packed once at
 K-major layout the kernel streams (``[Cin][KH*KW][CoutP]``) — for the forward pass and, separately, for the
 input-gradient pass (transposed / flipped / split into stride-2 phases).  No weight-gradient is ever computed.
 """
-import math
 
 import numpy as np
 import torch

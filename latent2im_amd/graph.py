@@ -16,7 +16,6 @@ no graph (A.4); the VGG prefix is evaluated once per image instead of once per t
 """
 import math
 import os
-import types
 
 import numpy as np
 import torch

@@ -6,7 +6,6 @@ map, so it is folded into the preceding conv at construction; ReLU and the resid
 the backward is input-gradient only, with every ReLU mask applied in the *prologue* of the next gradient conv
 (no standalone elementwise passes).
 """
-import math
 
 import numpy as np
 import torch

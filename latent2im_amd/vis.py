@@ -3,7 +3,6 @@ options/vis_options.py).  Forward-only reuse of the training kernels (SURVEY 8f-
 import argparse
 import os
 
-import numpy as np
 import yaml
 
 from . import constants, dist, hostutil
