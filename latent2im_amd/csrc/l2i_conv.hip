@@ -568,7 +568,113 @@ __global__ __launch_bounds__(256) void conv_direct_small_kernel(const l2i_conv_p
     }
 }
 
+// 3x3 / stride 1 / pad 1 onto <= 3 channels on wide maps (the input-gradient of VGG-19's conv_1 at 1024^2: 64 -> 3), register-streaming like the
+// FIR kernels of l2i_stream.hip: a lane owns four output columns of a 4-row band (48 accumulators); per input channel it reads the band's six
+// input rows with ONE aligned 16-byte load each and takes the two halo columns from its neighbour lanes by wave shuffles (edge lanes: from
+// memory); the 27 taps of the channel come through the scalar cache ([Cin][9][4] pack) — no LDS, no barriers, 432 FMAs per 6 loads.
+template <bool MASK>
+__global__ __launch_bounds__(256) void conv3x3_small_stream_kernel(const l2i_conv_params p, int bands, int strips) {
+    constexpr int RS = 4;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(4))) const f32x4v cfloat4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long bid = blockIdx.x;
+    const int strip = (int)(bid % strips); bid /= strips;
+    const int band = (int)(bid % bands);
+    const int b = (int)(bid / bands);
+    // a wave covers 248 output columns: lanes 1 .. 62 own four columns each, lanes 0 and 63 only fetch the halo vectors of their neighbours (a
+    // divergent scalar load for the two edge lanes stalled the whole wave on its latency: twelve times per channel)
+    const int ox = strip * 248 + (lane - 1) * 4;
+    const int oy0 = (band * 4 + wave) * RS;
+    if (oy0 >= p.OH) return;
+    const size_t plane_x = (size_t)p.H * p.W;
+    float acc[RS][4][3];
+#pragma unroll
+    for (int r = 0; r < RS; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) acc[r][q][o] = 0.f;
+    // the six row vectors of channel c + 1 are in flight while channel c is on the VALU (0.91 -> 0.78 ms at 1024^2; the kernel is then bound by
+    // VALU issue: hipcc packs the FMAs into v_pk_fma_f32 but moves every scalar-cache tap into a VGPR pair first, as many v_mov as FMAs)
+    float4 raw[RS + 2], rawm[MASK ? RS + 2 : 1];
+    auto fetch = [&](int c) {
+        const float* xc = p.x + ((size_t)b * p.Cin + c) * plane_x;
+#pragma unroll
+        for (int r = 0; r < RS + 2; ++r) {
+            const int iy = oy0 - 1 + r;
+            raw[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (MASK) rawm[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < p.H && ox >= 0 && ox < p.W) {
+                raw[r] = *reinterpret_cast<const float4*>(xc + (size_t)iy * p.W + ox);
+                if constexpr (MASK) rawm[r] = *reinterpret_cast<const float4*>(p.in_mask + ((size_t)b * p.Cin + c) * plane_x + (size_t)iy * p.W + ox);
+            }
+        }
+    };
+    fetch(0);
+    for (int c = 0; c < p.Cin; ++c) {
+        float win[RS + 2][6];                                          // rows oy0 - 1 .. oy0 + RS, columns ox - 1 .. ox + 4
+#pragma unroll
+        for (int r = 0; r < RS + 2; ++r) {
+            float4 v = raw[r];
+            if constexpr (MASK) {
+                const float4 m = rawm[r];
+                v.x *= m.x > 0.f ? p.mask_pos : p.mask_neg; v.y *= m.y > 0.f ? p.mask_pos : p.mask_neg;
+                v.z *= m.z > 0.f ? p.mask_pos : p.mask_neg; v.w *= m.w > 0.f ? p.mask_pos : p.mask_neg;
+            }
+            const float l1 = __shfl_up(v.w, 1), r1 = __shfl_down(v.x, 1);
+            win[r][0] = l1; win[r][1] = v.x; win[r][2] = v.y; win[r][3] = v.z; win[r][4] = v.w; win[r][5] = r1;
+        }
+        if (c + 1 < p.Cin) fetch(c + 1);
+        cfloat4* wc = (cfloat4*)(uintptr_t)(p.w + (size_t)c * 9 * 4);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4v w4 = wc[ky * 3 + kx];
+#pragma unroll
+                for (int r = 0; r < RS; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x = win[r + ky][q + kx];
+                        acc[r][q][0] += x * w4.x; acc[r][q][1] += x * w4.y; acc[r][q][2] += x * w4.z;
+                    }
+            }
+    }
+    const size_t plane_o = (size_t)p.OHf * p.OWf;
+    if (lane == 0 || lane == 63 || ox >= p.OW) return;                 // OW % 4 == 0: the four columns are inside together
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const int oy = oy0 + r;
+        if (oy >= p.OH) continue;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            if (o < p.Cout) {
+                float* yp = p.y + ((size_t)b * p.Cout + o) * plane_o + (size_t)oy * p.OWf + ox;
+                float4 v = make_float4(acc[r][0][o] * p.out_gain, acc[r][1][o] * p.out_gain, acc[r][2][o] * p.out_gain, acc[r][3][o] * p.out_gain);
+                if (p.accumulate) { const float4 old = *reinterpret_cast<const float4*>(yp); v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+                *reinterpret_cast<float4*>(yp) = v;
+            }
+        }
+    }
+}
+
 static int launch_direct_small(const l2i_conv_params& p, hipStream_t st) {
+    {
+        auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
+        if (p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_y == 1 && p.pad_x == 1 && p.Cout <= 3 && p.CoutP == 4 && !p.in_scale && p.oy_step == 1 && p.ox_step == 1 &&
+            p.oy_off == 0 && p.ox_off == 0 && p.OH == p.H && p.OW == p.W && p.OHf == p.OH && p.OWf == p.OW && p.OW >= 192 && (p.W % 4) == 0 && al16(p.x) && al16(p.in_mask) &&
+            al16(p.y) && al16(p.w)) {
+            const int strips = (p.OW + 247) / 248, bands = (p.OH + 15) / 16;
+            const long grid = (long)p.B * bands * strips;
+            if (grid > 0 && grid <= 0x7fffffffL) {
+                if (p.in_mask) hipLaunchKernelGGL((conv3x3_small_stream_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, p, bands, strips);
+                else hipLaunchKernelGGL((conv3x3_small_stream_kernel<false>), dim3((unsigned)grid), dim3(256), 0, st, p, bands, strips);
+                L2I_CHECK_LAUNCH();
+                return L2I_OK;
+            }
+        }
+    }
     const int IH = 32 + p.KH - 1, IW = 32 + p.KW - 1, IWp = IW | 1, KK = p.KH * p.KW;
     const size_t per_c = (size_t)IH * IWp * sizeof(float) + (size_t)KK * 16;
     int ck = (int)((40 * 1024) / per_c);

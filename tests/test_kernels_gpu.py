@@ -25,6 +25,8 @@ CONV_CASES = [  # cin, cout, k, stride, pad, transposed, h, w, batch
     (16, 24, 1, 2, 0, False, 16, 16, 1), (12, 20, 3, 2, 0, True, 8, 8, 2), (32, 32, 3, 2, 0, True, 33, 33, 1),
     (512, 512, 3, 1, 1, False, 4, 4, 2), (130, 70, 3, 1, 1, False, 8, 8, 1), (5, 3, 3, 1, 1, False, 40, 40, 1),
     (64, 3, 7, 2, 3, False, 16, 16, 1),
+    # <= 3 output channels on wide maps: the register-streaming 3x3 kernel (forward of a 64 -> 3 layer; input-gradient of a 3 -> 40 layer, ragged bands / strips)
+    (64, 3, 3, 1, 1, False, 40, 256, 2), (3, 40, 3, 1, 1, False, 21, 200, 1), (16, 2, 3, 1, 1, False, 9, 516, 1),
     # tiny maps (ResNet-50 tail at small inputs): several samples per tile, 1-pixel rows
     (256, 512, 1, 2, 0, False, 2, 2, 4), (2048, 512, 1, 1, 0, False, 1, 1, 4), (512, 2048, 1, 1, 0, False, 1, 1, 3), (64, 64, 3, 1, 1, False, 1, 1, 5),
     (128, 128, 3, 2, 1, False, 3, 3, 2),
@@ -83,6 +85,14 @@ def test_conv_prologue_epilogue_fusions():
     y0 = g(res).clone()
     fc.forward(g(x), out=y0, accumulate=True)
     close(y0, res + F.conv2d(x, wt, padding=1), 1e-4, 2e-5)
+    # the streaming <= 3-channel 3x3 kernel with a gradient mask, an output gain and accumulation
+    wt3 = T(rs.randn(3, 24, 3, 3) / 15.0)
+    x3, m3, y3 = T(rs.randn(2, 24, 18, 260)), T(rs.randn(2, 24, 18, 260)), T(rs.randn(2, 3, 18, 260))
+    fc3 = conv.FrozenConv2d(wt3, 1, 1, device=DEV)
+    out = g(y3).clone()
+    fc3.forward(g(x3), out=out, in_mask=g(m3), mask=(2 ** 0.5, 0.2 * 2 ** 0.5), out_gain=0.5, accumulate=True)
+    xm3 = x3 * torch.where(m3 > 0, torch.tensor(2 ** 0.5), torch.tensor(0.2 * 2 ** 0.5))
+    close(out, y3 + 0.5 * F.conv2d(xm3, wt3, padding=1), 1e-4, 2e-5)
 
 
 @pytest.mark.parametrize('cin,cout,k,pad,tr,h,w,b', [(24, 40, 3, 0, True, 17, 17, 2), (40, 24, 3, 1, False, 34, 30, 2), (3, 64, 7, 3, False, 64, 64, 1),
