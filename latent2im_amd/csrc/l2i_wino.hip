@@ -58,6 +58,8 @@ struct WinoLaunch {
     int tiles_x, tiles_y, mblocks;
     int total;                         // work items = B * tiles_y * tiles_x * mblocks (grid is padded to a multiple of 8)
     int nchunks;                       // Cin / 8
+    int relu_in;                       // the gradient mask IS the input with a ReLU mask (in_mask == x, mask (1, 0): VGG-19's convs read the pre-ReLU tap of
+                                       // the layer below): pro(x) = max(x, 0) — the unmasked instantiation with one v_max at commit, no second tile stream
 };
 
 namespace wg {
@@ -165,8 +167,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
             const int e = tid + u * 256;
             float v = __uint_as_float(rin[u]);
             if constexpr (MASK) {
-                if (relu_mask) v = (__uint_as_float(rmk[u]) > 0.f) ? v : 0.f;      // ReLU masks (VGG-19, ResNet-50): select, no multiply
+                if (relu_mask) v = (__uint_as_float(rmk[u]) > 0.f) ? v : 0.f;      // ReLU masks (ResNet-50 gradients): select, no multiply
                 else v *= (__uint_as_float(rmk[u]) > 0.f) ? p.mask_pos : p.mask_neg;
+            } else if (L.relu_in) {
+                v = __builtin_fmaxf(v, 0.f);                                     // (x > 0 ? x : 0) for every x, NaN and -0 included
             }
             raw[(u * 256 + 255 < NRAW || e < NRAW) ? e : NRAW + lane] = v;
         }
@@ -372,11 +376,13 @@ static int launch_wino(const l2i_conv_params& p, hipStream_t st) {
     L.nchunks = p.Cin / wg::CK;
     const size_t lds = (size_t)wg::LDS_FLOATS * sizeof(float);
     const unsigned grid = (unsigned)((total + 7) & ~7L);
+    L.relu_in = (p.in_mask == p.x && p.mask_pos == 1.f && p.mask_neg == 0.f) ? 1 : 0;
+    const bool mask = p.in_mask != nullptr && !L.relu_in;
     if (p.in_scale) {
-        if (p.in_mask) hipLaunchKernelGGL((conv_wino_kernel<true, true>), dim3(grid), dim3(256), lds, st, p, L);
+        if (mask) hipLaunchKernelGGL((conv_wino_kernel<true, true>), dim3(grid), dim3(256), lds, st, p, L);
         else hipLaunchKernelGGL((conv_wino_kernel<false, true>), dim3(grid), dim3(256), lds, st, p, L);
     } else {
-        if (p.in_mask) hipLaunchKernelGGL((conv_wino_kernel<true, false>), dim3(grid), dim3(256), lds, st, p, L);
+        if (mask) hipLaunchKernelGGL((conv_wino_kernel<true, false>), dim3(grid), dim3(256), lds, st, p, L);
         else hipLaunchKernelGGL((conv_wino_kernel<false, false>), dim3(grid), dim3(256), lds, st, p, L);
     }
     L2I_CHECK_LAUNCH();

@@ -236,6 +236,11 @@ def test_winograd_3x3_conv(cin, cout, h, w, b):
             continue
         err = float((got.double().cpu() - want).abs().max() / want.abs().max())
         assert err < 5e-6, err
+    # the gradient mask IS the input (VGG-19: a conv reads the pre-ReLU tap of the layer below): pro(x) = max(x, 0) without a second tile stream
+    xg = g(x)
+    y5 = fc.forward(xg, in_mask=xg, mask=(1.0, 0.0), bias=g(bias))
+    ref5 = c64(torch.relu(D(x))) + D(bias)[None, :, None, None]
+    assert float((y5.double().cpu() - ref5).abs().max() / ref5.abs().max()) < 5e-6
     # ContentLoss value fused into the epilogue (VGG taps): sum (y - reference)^2 over the launch, partial tiles and padded channels excluded
     sq_acc, fused = torch.zeros(_lib.SQ_SLOTS, device=DEV), [False]
     y4 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.0), bias=g(bias), sq=(g(res), sq_acc, fused))
