@@ -37,32 +37,54 @@ NOISE_STRENGTH = 0.05               # per-layer NoiseInjection weights of the be
 SCENE_ATTRS = ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk']
 
 
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or 'unknown'
+
+
 def cpu_baseline(resolution, n_attr, budget_s, full_loss=True, clamp=False):
-    """The CPU oracle (plain torch on the host cores) on a bounded sample of the same workload: whole training steps at
-    the benchmark resolution with batch 1 (per-image work is identical; D's stddev group is min(B,4))."""
+    """The CPU oracle (plain torch on the host cores) on a bounded sample of the workload, two ways:
+    (1) whole training steps at the BENCHMARK resolution with batch 1 (per-image work is identical; D's stddev group is min(B,4)) — `value`;
+    (2) >= 3 whole training steps at the REFERENCE's own shape, 256^2 batch 4 (README / constants.py:1 of the reference) — `reference_shape`."""
     from latent2im_amd import synth
     from oracle import step as ostep
     # torch's CPU convs stop scaling (and collapse when oversubscribed: 256 threads on the 256-core box = 334 s per step,
     # 32 threads = 18 s), so the port is timed on at most 32 cores and `cores` reports what was actually used
     threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
-    nets = dict(G=ostep.to_torch(synth.generator_state(resolution, seed=100)), D=ostep.to_torch(synth.discriminator_state(resolution, seed=200)),
-                R=ostep.to_torch(synth.resnet50_state(seed=300)), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400)))
-    n_latent = 2 * int(np.log2(resolution)) - 2
-    walk = torch.from_numpy(synth.walk_init(n_attr, n_latent, seed=7))
-    done, t_total = 0, 0.0
-    while True:
-        z = torch.from_numpy(synth.z_sample(1, seed=done)).float()
-        t0 = time.time()
-        ostep.train_step(nets, walk, z, torch.full((1, n_attr), 0.3), list(range(n_attr)),
-                         no_content_loss=not full_loss, no_gan_loss=not full_loss, clamp_variant=clamp)
-        t_total += time.time() - t0
-        done += 1
-        if t_total >= budget_s or done >= 4:
-            break
-    return dict(value=done / t_total, unit='images/s', cores=threads, kind='port',
-                sample='%d full training step(s) of batch 1 at %d^2 (same losses), %.1f s of CPU work, torch %s CPU ops'
-                       % (done, resolution, t_total, torch.__version__))
+
+    def timed(res, batch, min_steps, max_steps, budget):
+        nets = dict(G=ostep.to_torch(synth.generator_state(res, seed=100)), D=ostep.to_torch(synth.discriminator_state(res, seed=200)),
+                    R=ostep.to_torch(synth.resnet50_state(seed=300)), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400)))
+        n_latent = 2 * int(np.log2(res)) - 2
+        walk = torch.from_numpy(synth.walk_init(n_attr, n_latent, seed=7))
+        done, t_total = 0, 0.0
+        while True:
+            z = torch.from_numpy(synth.z_sample(batch, seed=done)).float()
+            t0 = time.time()
+            ostep.train_step(nets, walk, z, torch.full((batch, n_attr), 0.3), list(range(n_attr)),
+                             no_content_loss=not full_loss, no_gan_loss=not full_loss, clamp_variant=clamp)
+            t_total += time.time() - t0
+            done += 1
+            if done >= max_steps or (done >= min_steps and t_total >= budget):
+                break
+        return done, t_total
+
+    done, t_total = timed(resolution, 1, 1, 4, budget_s)
+    out = dict(value=done / t_total, unit='images/s', cores=threads, kind='port', cpu=cpu_model(), host_threads=os.cpu_count(),
+               sample='%d full training step(s) of batch 1 at %d^2 (same losses), %.1f s of CPU work, torch %s CPU ops'
+                      % (done, resolution, t_total, torch.__version__))
+    d2, t2 = timed(256, 4, 3, 6, budget_s)
+    out['reference_shape'] = dict(value=4 * d2 / t2, unit='images/s', steps=d2, s_per_step=round(t2 / d2, 3),
+                                  sample='%d full training steps of batch 4 at 256^2 (the reference\'s own run shape), %.1f s of CPU work' % (d2, t2))
+    return out
 
 
 def lib_hash():
@@ -125,6 +147,10 @@ def main():
                     'concurrent streams the per-kernel durations rocprof reports include time shared with other kernels)')
     ap.add_argument('--dump_launches', type=str, default=None, help='write the per-launch table of the event pass (shape, family, ms, TFLOP/s) to this JSON file')
     ap.add_argument('--noise_strength', type=float, default=NOISE_STRENGTH, help='generator NoiseInjection weights (0: no noise drawn)')
+    ap.add_argument('--sweep', type=str, default='1,2,4,8,16', help="batch sweep (BASELINE metric: 'batch sweep'): per-GPU batches timed eagerly after the "
+                    "headline, reported as `batch_sweep`; '' = off")
+    ap.add_argument('--sweep_steps', type=int, default=3)
+    ap.add_argument('--rank_timeout_s', type=float, default=3600.0, help='--gpus N without a launcher: give up on the rank processes after this long')
     a = ap.parse_args()
 
     from latent2im_amd import constants, conv, dist, selfcheck, synth
@@ -132,7 +158,7 @@ def main():
         # `python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL over xGMI) BEFORE anything
         # in this process touches the GPU, relay rank 0's JSON line, fail if any rank failed.  (Under torch.distributed.run the
         # environment already carries WORLD_SIZE and this branch is skipped.)
-        codes, out0 = dist.spawn_local(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        codes, out0 = dist.spawn_local(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], timeout=a.rank_timeout_s)
         lines = [l for l in out0.splitlines() if l.startswith('{')]
         if any(codes) or len(lines) != 1:
             sys.stderr.write('bench.py: rank exit codes %s, rank 0 printed %d JSON line(s)\n%s\n' % (codes, len(lines), out0[-2000:]))
@@ -158,7 +184,7 @@ def main():
     np.random.seed(1234)
     g = selfcheck.build_graph(a.resolution, attrs, a.batch * world, lr=1e-4, transform=transform)
     if world > 1:
-        torch.distributed.broadcast(g.walk.w.data, src=0)
+        dist.broadcast_parameters(g.walk.parameters())
     flags = dict(no_content_loss=a.reg_only, no_gan_loss=a.reg_only)
     global_b = a.batch * world
     zs_all = synth.z_sample(global_b * (a.steps + a.warmup), seed=0)
@@ -194,8 +220,13 @@ def main():
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [round(t / a.steps * 1e3, 3) for t in dist.gather_floats(elapsed)]
     elapsed = dist.max_over_ranks(elapsed, dev)
     loss_value = float(r['loss'])
+    # multi-GPU evidence that reports itself: which devices the ranks really ran on, and the latency of the step's only collective
+    ranks = dist.ranks_seen()
+    wgrad = next(iter(g.walk.parameters()))
+    allreduce_us = dist.time_allreduce(wgrad.detach())
 
     # roofline of the conv kernels: the same steps again, eager, with a HIP event pair around every conv launch on the launch
     # stream.  Kept out of the timed region above because ~280 event pairs per step cost ~7 % wall on their own.
@@ -239,6 +270,41 @@ def main():
         alt = dict(precision=other, value=round(global_b * a.steps / t_alt, 3), unit='images/s', ms_per_step=round(t_alt / a.steps * 1e3, 2),
                    note='same workload and steps with the matrix path switched (see DESIGN.md section 2); not the headline value')
 
+    # batch sweep (the BASELINE metric is quoted over a batch sweep): the same eager step at other per-GPU batches, every rank
+    sweep = None
+    if a.sweep:
+        import gc
+        captured = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        sweep = []
+        for bs in [int(x) for x in a.sweep.split(',') if x]:
+            gb = bs * world
+            zs_s = synth.z_sample(gb * (a.sweep_steps + 1), seed=1)
+            sl_s = dist.shard(gb)
+
+            def sweep_step(i):
+                zs = zs_s[i * gb:(i + 1) * gb][sl_s]
+                lo = -1.0 if c5 else 0.0
+                return selfcheck.run_step(g, zs, np.ones((bs, len(attrs))) * np.random.uniform(lo, 1, len(attrs)), clamp=clamp, **flags)
+            try:
+                torch.cuda.reset_peak_memory_stats()
+                sweep_step(0)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t3 = time.perf_counter()
+                for i in range(a.sweep_steps):
+                    sweep_step(1 + i)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t_s = dist.max_over_ranks(time.perf_counter() - t3, dev)
+                sweep.append(dict(batch=bs, global_batch=gb, images_s=round(gb * a.sweep_steps / t_s, 3), ms_per_step=round(t_s / a.sweep_steps * 1e3, 2),
+                                  peak_mem_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1)))
+            except torch.OutOfMemoryError as e:
+                sweep.append(dict(batch=bs, global_batch=gb, images_s=None, error='out of memory: %s' % str(e)[:120]))
+            gc.collect()
+            torch.cuda.empty_cache()
+
     if rk != 0:
         dist.shutdown()
         return
@@ -265,7 +331,7 @@ def main():
         # HBM bytes of the dominant kernel from the PMC summary that was taken with THIS build of the library (else null)
         traffic, traffic_note = None, 'no PMC summary under profiles/ for this build of libl2i_hip.so and this workload'
         tag = 'c5' if c5 else 'c3'
-        tp = os.path.join(ROOT, 'profiles', 'r02_%s_hbm_traffic.json' % tag)
+        tp = os.path.join(ROOT, 'profiles', 'r03_%s_hbm_traffic.json' % tag)
         if os.path.isfile(tp):
             tj = json.load(open(tp))
             ent = tj.get('per_family', {}).get(dom['family'])
@@ -310,7 +376,11 @@ def main():
                            losses='reg' if a.reg_only else 'reg+content+gan', parallelism='dp%d' % world,
                            loss_branch_streams=3 if constants.CONCURRENT_LOSS_BRANCHES else 1, hip_graph=use_graph,
                            noise_strength=a.noise_strength, loss=loss_value),
-               roofline=roof, alt_precision=alt)
+               roofline=roof, alt_precision=alt, batch_sweep=sweep,
+               ranks_seen=ranks, per_rank_ms_per_step=per_rank_ms, allreduce_us=None if allreduce_us is None else round(allreduce_us, 1),
+               allreduce_note=('median of 100 synchronised all-reduces of a walk-gradient-shaped tensor (%d bytes) over the %s process group'
+                               % (wgrad.numel() * 4, torch.distributed.get_backend()) if allreduce_us is not None
+                               else 'no process group at N = 1 (L2I_FORCE_PG=1 builds a one-rank RCCL group as a rehearsal)'))
     if world == 1 and a.cpu_baseline_s > 0:
         out['cpu_baseline'] = cpu_baseline(a.resolution, len(attrs), a.cpu_baseline_s, full_loss=not a.reg_only, clamp=clamp)
     else:

@@ -54,8 +54,11 @@ class CapturedStep:
         dev = g.device
         self.z = torch.zeros(batch, g.dim_z, device=dev)
         self.alpha = torch.zeros(batch, n_attr, device=dev)
-        self._stage_z = torch.zeros(batch, g.dim_z).pin_memory()
-        self._stage_a = torch.zeros(batch, n_attr).pin_memory()
+        # pinned staging ring: the host runs several replays ahead of the GPU (no per-step sync in bench.py / trainer --no_log_sync), so a
+        # slot is rewritten only after the H2D copies that read it have run (one event per slot)
+        self._ring = [(torch.zeros(batch, g.dim_z).pin_memory(), torch.zeros(batch, n_attr).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+        self._ring_used = [False] * len(self._ring)
+        self._slot = 0
         kw = dict(no_content_loss=no_content_loss, no_gan_loss=no_gan_loss, clamp=clamp, layers=layers)
         # warm-up on a side stream (allocator pools, split-K workspaces, lazily packed weights), as stream capture requires
         s = torch.cuda.Stream(device=dev)
@@ -70,14 +73,25 @@ class CapturedStep:
         with torch.cuda.graph(self.graph):
             self.out = forward_backward(g, self.z, self.alpha, **kw)
         self.grads = [p.grad for p in g.walk.parameters()]          # static tensors inside the graph's pool, rewritten by every replay
+        # the graph's kernel nodes hold RAW pointers into the split-K workspaces of conv._WS (allocated during warm-up, outside the graph's
+        # pool): keep those tensors alive for as long as the graph, even if a later eager launch replaces the dict entry with a larger one
+        from . import conv
+        self._ws_keep = list(conv._WS.values())
         self.launches = None
 
     def load(self, zs, alpha):
-        """Host -> the graph's static inputs (pinned staging, asynchronous on the current stream)."""
-        self._stage_z.copy_(torch.as_tensor(np.asarray(zs), dtype=torch.float32))
-        self._stage_a.copy_(torch.as_tensor(np.asarray(alpha), dtype=torch.float32))
-        self.z.copy_(self._stage_z, non_blocking=True)
-        self.alpha.copy_(self._stage_a, non_blocking=True)
+        """Host -> the graph's static inputs (pinned staging ring, asynchronous on the current stream)."""
+        i = self._slot
+        self._slot = (i + 1) % len(self._ring)
+        stage_z, stage_a, ev = self._ring[i]
+        if self._ring_used[i]:
+            ev.synchronize()                                  # the copies that last read this slot have completed
+        stage_z.copy_(torch.as_tensor(np.asarray(zs), dtype=torch.float32))
+        stage_a.copy_(torch.as_tensor(np.asarray(alpha), dtype=torch.float32))
+        self.z.copy_(stage_z, non_blocking=True)
+        self.alpha.copy_(stage_a, non_blocking=True)
+        ev.record()
+        self._ring_used[i] = True
 
     def __call__(self, zs=None, alpha=None, optimize=True):
         if zs is not None:

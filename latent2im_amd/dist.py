@@ -96,23 +96,47 @@ def spawn_local(n, argv, env=None, timeout=None):
         e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    out0 = b''
-    codes = []
-    try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        for p in procs:
-            codes.append(p.wait(timeout=timeout))
-    except subprocess.TimeoutExpired:
-        for p in procs:                       # exactly the processes started here
-            if p.poll() is None:
-                p.kill()
-        codes = [p.wait() for p in procs]
+    # Poll every child: when one rank dies early (import error, out of memory) the others would wait in RCCL init / the all-reduce for
+    # ever, so the first non-zero exit (or the timeout) ends exactly the processes started here.  Rank 0's stdout is drained by a
+    # thread so that a chatty rank cannot fill the pipe and stall.
+    import threading
+    import time
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = None if timeout is None else time.monotonic() + timeout
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes) or (deadline is not None and time.monotonic() > deadline):
+            grace = time.monotonic() + 3.0     # let the failing rank's siblings finish / print their own errors first
+            while time.monotonic() < grace and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            codes = [p.wait() for p in procs]
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = b''.join(c for c in chunks if c)
     return codes, out0.decode(errors='replace')
 
 
-def average_gradients(params):
-    """All-reduce (mean) the gradients of the trainable parameters — for this path: the walk tensor only."""
+def broadcast_parameters(params, src=0):
+    """One source of truth for the trainable state at start-up: every parameter of the walk module from rank ``src`` (the linear walk
+    has one tensor ``w``; the MLP / non-linear walks of transform_base.py:168-243 have several and no ``w``)."""
     if world_size() == 1:
+        return
+    for p in params:
+        td.broadcast(p.data, src=src)
+
+
+def average_gradients(params):
+    """All-reduce (mean) the gradients of the trainable parameters — for this path: the walk tensor only.  Without a process group: a
+    no-op.  A ONE-rank group (L2I_FORCE_PG=1: the RCCL rehearsal on a single-GPU box) still runs the collective."""
+    if not is_initialized():
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
@@ -147,3 +171,46 @@ def max_over_ranks(value, device=None):
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else ('cuda' if td.get_backend() == 'nccl' else 'cpu'))
     td.all_reduce(t, op=td.ReduceOp.MAX)
     return float(t.item())
+
+
+def ranks_seen():
+    """[{rank, device, host}] of every rank (all_gather_object; one entry without a process group): self-reporting evidence of which
+    GPUs a multi-rank run really used."""
+    import socket
+    me = dict(rank=rank(), device=torch.cuda.current_device() if torch.cuda.is_available() else None, host=socket.gethostname())
+    if not is_initialized():
+        return [me]
+    out = [None] * world_size()
+    td.all_gather_object(out, me)
+    return out
+
+
+def gather_floats(value):
+    """[value of rank 0, value of rank 1, ...] on every rank."""
+    if not is_initialized():
+        return [float(value)]
+    out = [None] * world_size()
+    td.all_gather_object(out, float(value))
+    return out
+
+
+def time_allreduce(tensor, iters=100):
+    """Median wall time (microseconds) of ``iters`` all-reduces of a tensor shaped like the walk gradient, each bracketed by a device
+    synchronisation — the latency of the step's only collective.  None without a process group."""
+    import time
+    if not is_initialized():
+        return None
+    buf = torch.zeros_like(tensor)
+    for _ in range(5):
+        td.all_reduce(buf)
+    torch.cuda.synchronize() if buf.is_cuda else None
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        td.all_reduce(buf)
+        if buf.is_cuda:
+            torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e6)
+    ts.sort()
+    return ts[len(ts) // 2]
+

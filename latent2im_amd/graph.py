@@ -223,16 +223,12 @@ class TransformGraph:
         self.Nsliders = nsliders
         self.num_channels = constants.NUM_CHANNELS
         self.BATCH_SIZE = constants.BATCH_SIZE
-        self.LAMBDA = 0.05
-        self.BCE_loss = nn.BCELoss()
         self.BCE_loss_logits = nn.BCEWithLogitsLoss()
-        self.MSE_loss = nn.MSELoss()
         self.ContentLoss = ContentLoss()
         self.trainEmbed = trainEmbed
 
         # the reference hard-codes step = 6 (256^2, transform_base.py:285); generalised: n_latent = 2*(step+1)
         self.step = int(math.log2(self.img_size)) - 2
-        self.alpha = 1
         self.stylegan_opts = stylegan_opts
         self.layers = layers
         self.is_mlp = constants.WALK_IS_MLP
@@ -253,9 +249,6 @@ class TransformGraph:
             raise NotImplementedError('unknown walk_type %r' % (walk_type,))
 
         self.optimizers = torch.optim.Adam(self.walk.parameters(), lr=self.lr, betas=(0.5, 0.99))
-        self.y = None
-        self.z = None
-        self.truncation = None
         self.walk_type = walk_type
         self.last_terms = None
 

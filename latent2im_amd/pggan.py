@@ -224,10 +224,7 @@ class TransformGraph:
         self.img_size = constants.PG_RESOLUTION
         self.num_channels = constants.NUM_CHANNELS
         self.BATCH_SIZE = constants.BATCH_SIZE
-        self.LAMBDA = 0.1
-        self.BCE_loss = nn.BCELoss()
         self.BCE_loss_logits = nn.BCEWithLogitsLoss()
-        self.MSE_loss = nn.MSELoss()
         self.ContentLoss = ContentLoss()
         self.trainEmbed = trainEmbed
         self.step = 6                                            # PGAN 256 (transform_base.py:244-246)
@@ -245,9 +242,6 @@ class TransformGraph:
         else:
             raise NotImplementedError('WalkMlpZ3 ("MLP", transform_base.py:279-283) is not on the config-1 path')
         self.optimizer = torch.optim.Adam(self.walk.parameters(), lr=self.lr, betas=(0.5, 0.99))
-        self.y = None
-        self.z = None
-        self.truncation = None
         self.walk_type = walk_type
         self.N_f = N_f
         self.eps = eps

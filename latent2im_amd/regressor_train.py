@@ -163,6 +163,8 @@ class TrainableResNet50:
             for bn in self._bns():
                 bn.running_mean.copy_(torch.as_tensor(sd[bn.name + '.running_mean']).to(self.device))
                 bn.running_var.copy_(torch.as_tensor(sd[bn.name + '.running_var']).to(self.device))
+                if bn.name + '.num_batches_tracked' in sd:
+                    bn.num_batches_tracked.copy_(torch.as_tensor(sd[bn.name + '.num_batches_tracked']).to(bn.num_batches_tracked.device))
         self.replan()
 
     def replan(self):
@@ -288,7 +290,7 @@ def load_labelfile(path):
     """annotations.tsv: name <tab> 40 x 'value,confidence' (scene_regressor_256.py:67-74)."""
     labels = {}
     with open(path, 'r') as f:
-        for line in csv.reader(f, delimiter='\\t'):
+        for line in csv.reader(f, delimiter='\t'):
             labels[line[0]] = np.array([float(i.split(',')[0]) for i in line[1:]])
     return labels
 
@@ -312,8 +314,10 @@ class CustomDataset:
         path = self.image_list[index]
         im = Image.open(path).convert('RGB')
         w, h = im.size
-        s = self.image_size / min(w, h)
-        im = im.resize((max(int(round(w * s)), self.image_size), max(int(round(h * s)), self.image_size)), Image.BILINEAR)
+        # torchvision Resize(int): the short side becomes image_size, the long side int(image_size * long / short) (truncated, not rounded)
+        size = self.image_size
+        new = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
+        im = im.resize(new, Image.BILINEAR)
         w, h = im.size
         l, t = (w - self.image_size) // 2, (h - self.image_size) // 2
         a = np.asarray(im.crop((l, t, l + self.image_size, t + self.image_size)), dtype=np.float32) / 255.0

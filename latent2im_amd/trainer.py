@@ -1,7 +1,7 @@
 """The training drivers' loop (reference train.py:25-134 and train_multi_attr.py:43-231), single process or one
 process per GPU.  Call order per iteration is the reference's: get_w -> get_logits -> get_reg_preds -> get_train_alpha ->
 get_alphas -> get_w_new_tensor -> get_logits -> optimizeParametersAll.  Under data parallelism every rank draws the same
-z (seed = epoch) and the same alpha (same numpy seed) and takes its contiguous slice of the batch."""
+z (seed = epoch) and the same alpha (same numpy seed) and takes every world-th sample of the batch (dist.shard: strided shards keep the discriminator's stddev groups whole)."""
 import logging
 import math
 import os
@@ -150,7 +150,7 @@ def main(multi_attr=False, argv=None):
     model = graph_mod.find_model_using_name(opt.model, opt.transform)
     g = model(**graph_kwargs)
     if world > 1:                                    # one source of truth for the trainable state
-        torch.distributed.broadcast(g.walk.w.data, src=0)
+        dist.broadcast_parameters(g.walk.parameters())
     if rk == 0:                                      # which frozen weights this run trained against: stdout, opt.yml (and log.txt in train())
         print('weight sources: ', g.weight_sources)
         yml = os.path.join(opt.output_dir, 'opt.yml')

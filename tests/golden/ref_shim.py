@@ -4,8 +4,8 @@
 import, ``transform_base.py`` wants torchvision / easydict / ``.cuda()``.  This module pre-registers stub
 packages so that the reference's *first-party arithmetic* (networks.py, transform_base.py, pggan/model_256.py,
 utils/util.py, utils/transforms.py, options/train_options.py) loads from where it lies and runs on CPU.  It
-is used only by tests/golden/make_golden.py (fixture generation) and tests/test_oracle_vs_reference.py (live
-pin, skipped when /root/reference is absent, e.g. on the GPU box).  Nothing here is shipped product code and
+is used only by tests/golden/make_golden.py (fixture generation, build container only: the GPU box has no
+/root/reference and the tests there read the committed .npz fixtures).  Nothing here is shipped product code and
 no reference source text is copied: the two CUDA ops are replaced by (a) the reference's own
 ``upfirdn2d_native`` extracted from its file with ``ast`` at run time and (b) a leaky-relu written from the
 kernel's switch table (fused_bias_act_kernel.cu:36-47).

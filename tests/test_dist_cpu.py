@@ -124,3 +124,25 @@ def test_spawn_local_starts_one_fresh_process_per_rank(tmp_path):
     assert codes == [0, 0] and lines == ['{"sum": 3, "world": 2}'], out0
     codes, _ = dist.spawn_local(2, [sys.executable, str(script), 'fail'], env=env, timeout=120)
     assert codes == [0, 3]                                          # a failing rank is reported (bench.py then exits non-zero)
+
+
+def test_spawn_local_ends_the_group_when_a_rank_dies_early(tmp_path):
+    """A rank that dies before joining the group (import error, out of memory) must not leave its siblings — and `bench.py --gpus N` —
+    waiting for ever: spawn_local polls every child, ends the ones it started after the first non-zero exit and reports every code."""
+    import time
+    from latent2im_amd import dist
+    script = tmp_path / 'rank.py'
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1': sys.exit(5)\n"
+                      "time.sleep(120)\n")
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    t0 = time.monotonic()
+    codes, _ = dist.spawn_local(2, [sys.executable, str(script)], env=env, timeout=None)
+    assert time.monotonic() - t0 < 30
+    assert codes[1] == 5 and codes[0] not in (0, None)             # rank 0 was ended (killed), not left sleeping
+    t0 = time.monotonic()
+    script.write_text("import time\ntime.sleep(120)\n")
+    codes, _ = dist.spawn_local(2, [sys.executable, str(script)], env=env, timeout=2)
+    assert time.monotonic() - t0 < 30 and all(c not in (0, None) for c in codes)      # the finite timeout bench.py passes
+

@@ -166,3 +166,43 @@ def test_gpu_flag_is_applied_before_the_runtime_starts(monkeypatch):
     for mod in (trainer, vis, evaluate):
         src = inspect.getsource(mod.main)
         assert 0 < src.index('dist.select_gpu(') < src.index('dist.init_from_env()'), mod.__name__
+
+
+def test_regressor_training_label_file_and_dataset(tmp_path):
+    """scene_regressor_256.py:27-74 on the host: annotations.tsv (name <TAB> 40 x 'value,confidence') through load_labelfile, images
+    listed in a split file through CustomDataset — Resize(256) like torchvision (short side 256, long side int(256 * long / short),
+    truncated), CenterCrop(256), ToTensor, Normalize(0.5, 0.5)."""
+    from PIL import Image
+    from latent2im_amd import regressor_train as RT
+    rs = np.random.RandomState(0)
+    names = ['00000001/1.jpg', '00000001/2.jpg', '00000002/7.jpg']
+    vals = rs.rand(3, 40)
+    with open(tmp_path / 'annotations.tsv', 'w') as f:
+        for n, v in zip(names, vals):
+            f.write(n + '\t' + '\t'.join('%.4f,%.2f' % (x, 0.9) for x in v) + '\n')
+    labels = RT.load_labelfile(str(tmp_path / 'annotations.tsv'))
+    assert set(labels) == set(names)
+    np.testing.assert_allclose(labels[names[2]], np.round(vals[2], 4), atol=1e-12)
+    sizes = {names[0]: (300, 451), names[1]: (517, 260), names[2]: (256, 256)}          # (w, h)
+    for n, (w, h) in sizes.items():
+        os.makedirs(tmp_path / 'imgs' / n.split('/')[0], exist_ok=True)
+        Image.fromarray(rs.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(tmp_path / 'imgs' / n, quality=95)
+    (tmp_path / 'training.txt').write_text(names[0] + '\n' + names[2] + '\n')
+    ds = RT.CustomDataset(str(tmp_path / 'imgs'), labels, str(tmp_path / 'training.txt'))
+    assert len(ds) == 2
+    x, y = ds[0]
+    assert tuple(x.shape) == (3, 256, 256) and x.dtype == torch.float32 and float(x.min()) >= -1 and float(x.max()) <= 1
+    np.testing.assert_allclose(y.numpy(), labels[names[0]].astype(np.float32))
+    # the resize rule (long side truncated): 300 x 451 -> 256 x int(256 * 451 / 300) = 384 (round() would give 385)
+    seen = []
+    orig = Image.Image.resize
+    try:
+        Image.Image.resize = lambda self, size, *a, **k: (seen.append(tuple(size)), orig(self, size, *a, **k))[1]
+        ds[0]
+        ds2 = RT.CustomDataset(str(tmp_path / 'imgs'), labels, str(tmp_path / 'all.txt')) if (tmp_path / 'all.txt').write_text('\n'.join(names)) else None
+        ds2[1]
+    finally:
+        Image.Image.resize = orig
+    assert seen == [(256, int(256 * 451 / 300)), (int(256 * 517 / 260), 256)] and seen[0][1] == 384
+    # TrainableResNet50.load_state_dict keeps num_batches_tracked (checked on the GPU in test_regressor_training_step_vs_oracle)
+
