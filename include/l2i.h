@@ -235,6 +235,32 @@ int l2i_pixelnorm_act_bwd_f32(float* dx, const float* gy, const float* x, int B,
 int l2i_upsample2x_nearest_f32(float* y, const float* x, int64_t planes, int H, int W, float scale, void* stream);
 int l2i_pool2x2_f32(float* y, const float* x, int64_t planes, int OH, int OW, float scale, void* stream);
 
+/* ---- style-dependent vectors of a generator pass (networks.py:148-156 EqualLinear modulation, :231-239 demodulation, and their gradients) ----
+ * Segmented mat-vec:  out[b, r] = epi( sum over the segment's parts of  sum_k pre(in)[b, k] * w[w_off + k * w_pitch + r] ),  r < rows, b < B.
+ * One launch evaluates every layer of a kind (all modulations s = w A^T + bias and the ToRGB weights; all demodulation factors; all
+ * d s; the whole latent gradient).  `segs` / `block_seg` are DEVICE arrays built once per network (latent2im_amd/generator.py): block i works
+ * on rows block_seg[2i+1]*64 .. +63 of segment block_seg[2i].  Offsets that scale with the batch are (constant, per-sample) pairs:
+ * offset = off_c + B * off_b.
+ *   pre: 0  x = in[idx]                       idx = in_off + b * in_bstride + k
+ *        1  x = in[idx]^2                                                              (demodulation: sum s^2 T)
+ *        2  x = in[idx] * in2[idx]^2                                                   (d demod * demod^3 = red / demod * demod^3)
+ *        3  x = sum_o in2[in_off + (b * K + k) * 3 + o] * wrgb[aux_off + o * K + k]    (ToRGB: d s_rgb from the [B, C, 3] reduction, read from in2)
+ *   epi: 0  out = acc + bias[bias_off + r]; if rgb_off_b >= 0 also wmod[B * rgb_off_b + (b * 3 + o) * rows + r] = wrgb[rgb_w_off + o * rows + r] * out
+ *        1  out = rsqrt(acc + 1e-8)
+ *        2  out = e1[e] - e2[e] * acc          e = e_off + b * e_bstride + r            (d s = q - s * (d demod demod^3) T)
+ *        3  out = acc
+ * K <= 512 and K % 4 == 0 for every part. */
+typedef struct l2i_segmv_part {
+    int32_t K, in_off_c, in_off_b, in_bstride, w_pitch, pre, aux_off, pad_;
+    int64_t w_off;
+} l2i_segmv_part;
+typedef struct l2i_segmv_seg {
+    int32_t rows, nparts, out_off_c, out_off_b, out_bstride, epi, bias_off, e_off_c, e_off_b, e_bstride, rgb_off_b, rgb_w_off;
+    l2i_segmv_part part[2];
+} l2i_segmv_seg;
+int l2i_segmented_matvec_f32(float* out, const float* in, const float* in2, const float* w, const float* bias, const float* e1, const float* e2,
+                             float* wmod, const float* wrgb, const l2i_segmv_seg* segs, const int32_t* block_seg, int nblocks, int B, void* stream);
+
 const char* l2i_last_error(void);
 int l2i_abi_version(void);
 

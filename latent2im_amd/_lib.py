@@ -41,6 +41,18 @@ class ConvParams(ctypes.Structure):
 SQ_SLOTS = 1024          # L2I_SQ_SLOTS
 
 
+class SegmvPart(ctypes.Structure):
+    """Mirror of ``struct l2i_segmv_part`` (include/l2i.h)."""
+    _fields_ = [('K', c_i), ('in_off_c', c_i), ('in_off_b', c_i), ('in_bstride', c_i), ('w_pitch', c_i), ('pre', c_i), ('aux_off', c_i), ('pad_', c_i),
+                ('w_off', c_l)]
+
+
+class SegmvSeg(ctypes.Structure):
+    """Mirror of ``struct l2i_segmv_seg`` (include/l2i.h)."""
+    _fields_ = [('rows', c_i), ('nparts', c_i), ('out_off_c', c_i), ('out_off_b', c_i), ('out_bstride', c_i), ('epi', c_i), ('bias_off', c_i),
+                ('e_off_c', c_i), ('e_off_b', c_i), ('e_bstride', c_i), ('rgb_off_b', c_i), ('rgb_w_off', c_i), ('part', SegmvPart * 2)]
+
+
 _SIGNATURES = {
     'l2i_conv2d_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_family': (c_i, [ctypes.POINTER(ConvParams)]),
@@ -71,6 +83,7 @@ _SIGNATURES = {
     'l2i_pixelnorm_act_bwd_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_l, c_f, c_f, c_p]),
     'l2i_upsample2x_nearest_f32': (c_i, [c_p, c_p, c_l, c_i, c_i, c_f, c_p]),
     'l2i_pool2x2_f32': (c_i, [c_p, c_p, c_l, c_i, c_i, c_f, c_p]),
+    'l2i_segmented_matvec_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     'l2i_last_error': (ctypes.c_char_p, []),
     'l2i_abi_version': (c_i, []),
 }

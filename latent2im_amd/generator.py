@@ -70,6 +70,132 @@ class _ToRGB:
             self.up_k_flip = torch.flip(self.up_k, [0, 1]).contiguous()
 
 
+class _ModPlan:
+    """Segment tables of l2i_segmented_matvec_f32 (include/l2i.h) for one generator: all style-dependent vectors of a pass in four
+    launches instead of ~10 tiny rocBLAS / elementwise launches per layer.
+
+    forward   (2 launches): s = w_l A^T + bias for every styled conv and ToRGB (+ the ToRGB weights wmod = W * s), then
+                            demod = rsqrt(s^2 T^T + 1e-8) for every styled conv                         (networks.py:148-156, 231-239, 346-351)
+    backward  (2 launches): d s = q - s * ((red / demod * demod^3) T) per conv, then the whole latent gradient
+                            g_lat[:, l] = sum over the layers fed by latent l of d s A (ToRGB: d s_rgb = sum_o red_rgb[..., o] W[o])
+    Buffers are per-layer contiguous ([layer][B][C]) so that every layer's vector is a contiguous [B, C] view (the conv kernels take it by
+    pointer); offsets that scale with the batch are stored per sample, the tables do not depend on B."""
+
+    def __init__(self, gen, device):
+        from . import _lib
+        import ctypes
+        layers, rgbs = gen.layers, gen.rgbs
+        conv_idx, rgb_idx = gen.latent_index()
+        sd, nl = gen.style_dim, gen.n_latent
+        self.device, self.nl, self.sd = device, nl, sd
+        self.cin = [L.cin for L in layers]
+        self.cout = [L.cout for L in layers]
+        self.crgb = [R.W.shape[1] for R in rgbs]
+        for k in self.cin + self.cout + self.crgb + [sd]:
+            assert k % 4 == 0 and k <= 512, 'l2i_segmented_matvec_f32: contraction lengths must be multiples of 4 up to 512 (got %d)' % k
+        pre = lambda xs: [int(v) for v in np.concatenate([[0], np.cumsum(xs)[:-1]])] if xs else []
+        self.s_off = pre(self.cin) + [sum(self.cin) + o for o in pre(self.crgb)]          # rows before each segment in s_all (convs, then ToRGBs)
+        self.d_off = pre(self.cout)                                                       # ... in demod_all / red_dz_all
+        self.r_off = pre(self.crgb)                                                       # channels before each ToRGB (x 3: wmod_all / red_rgb_all)
+        self.n_s, self.n_d, self.n_r = sum(self.cin) + sum(self.crgb), sum(self.cout), sum(self.crgb)
+        self.n_q = sum(self.cin)
+        mods = [L.mod for L in layers] + [R.mod for R in rgbs]
+        rows = self.cin + self.crgb
+        lat_of = list(conv_idx) + list(rgb_idx)
+        # weights, concatenated per use
+        self.w_modT = torch.cat([m.A.t().contiguous().reshape(-1) for m in mods]).contiguous()          # [512, rows] per segment
+        self.w_A = torch.cat([m.A.contiguous().reshape(-1) for m in mods]).contiguous()                 # [rows, 512] per segment
+        self.bias = torch.cat([m.b.reshape(-1) for m in mods]).contiguous()
+        self.w_rgb = torch.cat([R.W.contiguous().reshape(-1) for R in rgbs]).contiguous()               # [3, C] per ToRGB
+        self.w_Tt = torch.cat([L.T.t().contiguous().reshape(-1) for L in layers]).contiguous()          # [cin, cout] per conv
+        self.w_T = torch.cat([L.T.contiguous().reshape(-1) for L in layers]).contiguous()               # [cout, cin] per conv
+        a_off = pre([r * sd for r in rows])
+        t_off = pre([ci * co for ci, co in zip(self.cin, self.cout)])
+        nconv = len(layers)
+
+        def part(K, in_off_c=0, in_off_b=0, in_bstride=0, w_pitch=0, pre_=0, aux_off=0, w_off=0):
+            return _lib.SegmvPart(K, in_off_c, in_off_b, in_bstride, w_pitch, pre_, aux_off, 0, w_off)
+
+        def seg(rows_, parts, out_off_c=0, out_off_b=0, out_bstride=0, epi=0, bias_off=0, e_off_b=0, e_bstride=0, rgb_off_b=-1, rgb_w_off=0):
+            sg = _lib.SegmvSeg()
+            sg.rows, sg.nparts, sg.out_off_c, sg.out_off_b, sg.out_bstride, sg.epi, sg.bias_off = rows_, len(parts), out_off_c, out_off_b, out_bstride, epi, bias_off
+            sg.e_off_c, sg.e_off_b, sg.e_bstride, sg.rgb_off_b, sg.rgb_w_off = 0, e_off_b, e_bstride, rgb_off_b, rgb_w_off
+            for i, pt in enumerate(parts):
+                sg.part[i] = pt
+            return sg
+
+        mod, dem, ds = [], [], []
+        for i, r in enumerate(rows):
+            j = i - nconv
+            mod.append(seg(r, [part(sd, in_off_c=lat_of[i] * sd, in_bstride=nl * sd, w_pitch=r, w_off=a_off[i])], out_off_b=self.s_off[i], out_bstride=r,
+                           epi=0, bias_off=self.s_off[i], rgb_off_b=(3 * self.r_off[j] if j >= 0 else -1), rgb_w_off=(3 * self.r_off[j] if j >= 0 else 0)))
+        for i in range(nconv):
+            ci, co = self.cin[i], self.cout[i]
+            dem.append(seg(co, [part(ci, in_off_b=self.s_off[i], in_bstride=ci, w_pitch=co, pre_=1, w_off=t_off[i])], out_off_b=self.d_off[i], out_bstride=co, epi=1))
+            ds.append(seg(ci, [part(co, in_off_b=self.d_off[i], in_bstride=co, w_pitch=ci, pre_=2, w_off=t_off[i])], out_off_b=self.s_off[i], out_bstride=ci,
+                          epi=2, e_off_b=self.s_off[i], e_bstride=ci))
+        glat = []
+        for l in range(nl):
+            parts = []
+            for i in range(nconv):
+                if conv_idx[i] == l:
+                    parts.append(part(self.cin[i], in_off_b=self.s_off[i], in_bstride=self.cin[i], w_pitch=sd, pre_=0, w_off=a_off[i]))
+            for j in range(len(rgbs)):
+                if rgb_idx[j] == l:       # pre 3: the [B, C, 3] reduction of the ToRGB, read from the in2 slot
+                    parts.append(part(self.crgb[j], in_off_b=3 * self.r_off[j], in_bstride=0, w_pitch=sd, pre_=3, aux_off=3 * self.r_off[j], w_off=a_off[nconv + j]))
+            assert 1 <= len(parts) <= 2
+            glat.append(seg(sd, parts, out_off_c=l * sd, out_bstride=nl * sd, epi=3))
+
+        def table(segs):
+            arr = (_lib.SegmvSeg * len(segs))(*segs)
+            raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8).clone()
+            blocks = [(i, rb) for i, sg in enumerate(segs) for rb in range((sg.rows + 63) // 64)]
+            return raw.to(device), torch.tensor(blocks, dtype=torch.int32).reshape(-1).to(device), len(blocks)
+        self.t_mod, self.t_dem, self.t_ds, self.t_glat = table(mod), table(dem), table(ds), table(glat)
+
+    # -- views -------------------------------------------------------------------------------------------------------------------------
+    def s(self, s_all, B, li):
+        return s_all[B * self.s_off[li]:B * (self.s_off[li] + self.cin[li])].view(B, self.cin[li])
+
+    def demod(self, d_all, B, li):
+        return d_all[B * self.d_off[li]:B * (self.d_off[li] + self.cout[li])].view(B, self.cout[li])
+
+    def wmod(self, w_all, B, j):
+        c = self.crgb[j]
+        return w_all[3 * B * self.r_off[j]:3 * B * (self.r_off[j] + c)].view(B, 3, c)
+
+    def red_rgb(self, r_all, B, j):
+        c = self.crgb[j]
+        return r_all[3 * B * self.r_off[j]:3 * B * (self.r_off[j] + c)].view(B, c, 3)
+
+    # -- launches ----------------------------------------------------------------------------------------------------------------------
+    def forward(self, lat):
+        """lat [B, n_latent, 512] contiguous -> (s_all, demod_all, wmod_all), flat, per-layer contiguous."""
+        B, dev = lat.shape[0], lat.device
+        s_all = torch.empty(B * self.n_s, device=dev, dtype=torch.float32)
+        d_all = torch.empty(B * self.n_d, device=dev, dtype=torch.float32)
+        w_all = torch.empty(3 * B * self.n_r, device=dev, dtype=torch.float32)
+        K.segmented_matvec(s_all, lat, self.w_modT, self.t_mod[0], self.t_mod[1], self.t_mod[2], B, bias=self.bias, wmod=w_all, wrgb=self.w_rgb)
+        K.segmented_matvec(d_all, s_all, self.w_Tt, self.t_dem[0], self.t_dem[1], self.t_dem[2], B)
+        return s_all, d_all, w_all
+
+    def reductions(self, B, dev):
+        """One zeroed buffer for every per-layer reduction of a backward pass: (red_dz_z like demod_all, q like the conv part of s_all,
+        red_x_grgb [layer][B][C][3])."""
+        buf = torch.zeros(B * (self.n_d + self.n_q + 3 * self.n_r), device=dev, dtype=torch.float32)
+        return buf[:B * self.n_d], buf[B * self.n_d:B * (self.n_d + self.n_q)], buf[B * (self.n_d + self.n_q):]
+
+    def backward(self, B, s_all, d_all, red_dz, q, red_rgb):
+        """-> g_lat [B, n_latent, 512]."""
+        dev = s_all.device
+        ds_all = torch.empty(B * self.n_q, device=dev, dtype=torch.float32)
+        K.segmented_matvec(ds_all, red_dz, self.w_T, self.t_ds[0], self.t_ds[1], self.t_ds[2], B, in2=d_all, e1=q, e2=s_all)
+        g_lat = torch.empty(B, self.nl, self.sd, device=dev, dtype=torch.float32)
+        # parts of kind 0 read d s (`in`), parts of kind 3 the ToRGB reductions (`in2`)
+        K.segmented_matvec(g_lat, ds_all, self.w_A, self.t_glat[0], self.t_glat[1], self.t_glat[2], B, in2=red_rgb, wrgb=self.w_rgb)
+        return g_lat
+
+
 class Generator:
     """Frozen ``Generator(size, 512, 8)``.  ``style(z)`` = mapping network; ``synthesis(latent, noise)`` = forward
     with ``input_is_latent=True``.  Both are differentiable w.r.t. their first argument only."""
@@ -93,6 +219,7 @@ class Generator:
         for j in range(self.log_size - 2):
             self.rgbs.append(_ToRGB(P, 'to_rgbs.%d' % j, geo[2 + 2 * j][2], True, device))
         self.randomize_noise = True
+        self.modplan = _ModPlan(self, device)
 
     # -- mapping network -----------------------------------------------------------------------------------------
     def style(self, z):
@@ -141,9 +268,10 @@ class _SynthesisFn(torch.autograd.Function):
         saved = []
         x = gen.const.expand(B, -1, -1, -1).contiguous()
         skip = None
+        plan = gen.modplan
+        s_all, d_all, w_all = plan.forward(lat.contiguous())       # every modulation / demodulation / ToRGB weight of the pass: two launches
         for li, L in enumerate(gen.layers):
-            s = L.mod(lat[:, conv_idx[li]].contiguous())
-            demod = torch.rsqrt(torch.mm(s * s, L.T.t()) + 1e-8)
+            s, demod = plan.s(s_all, B, li), plan.demod(d_all, B, li)
             h = x.shape[2]
             res = h * 2 if L.up else h
             nz = _noise_for(gen, noise, li, B, res, dev)
@@ -165,18 +293,17 @@ class _SynthesisFn(torch.autograd.Function):
             rec = dict(x=x if keep else None, y=y if keep else None, s=s, demod=demod, nz=nz)
             if li == 0 or (li % 2 == 0):                # conv1 and every second conv of a block feed a ToRGB
                 R = gen.rgbs[li // 2]
-                srgb = R.mod(lat[:, rgb_idx[li // 2]].contiguous())
-                wmod = (R.W.unsqueeze(0) * srgb.unsqueeze(1)).contiguous()          # [B,3,C]
+                wmod = plan.wmod(w_all, B, li // 2)                                  # [B,3,C] = scale * W * s_rgb
                 rgb = K.torgb_fwd(y, wmod, R.bias)
                 if R.up:
                     skip = K.upfirdn2d(skip, R.up_k, up=(2, 2), pad=(2, 1, 2, 1), addend=rgb)
                 else:
                     skip = rgb
                 rec['wmod'] = wmod
-                rec['srgb'] = srgb
             saved.append(rec)
             x = y
         ctx.gen, ctx.saved, ctx.B = gen, saved if keep else None, B
+        ctx.mod = (s_all, d_all) if keep else None
         return skip
 
     @staticmethod
@@ -186,7 +313,9 @@ class _SynthesisFn(torch.autograd.Function):
             raise RuntimeError('synthesis was run without a differentiable latent')
         dev = g_img.device
         conv_idx, rgb_idx = gen.latent_index()
-        g_lat = torch.zeros(B, gen.n_latent, gen.style_dim, device=dev, dtype=torch.float32)
+        plan = gen.modplan
+        s_all, d_all = ctx.mod
+        red_dz, q_all, red_rgb = plan.reductions(B, dev)               # every per-layer reduction of this pass lands in one zeroed buffer
         # gradient of every ToRGB output: skip_j = up(skip_{j-1}) + rgb_j  (networks.py:353-356)
         n_rgb = len(gen.rgbs)
         g_rgb = [None] * n_rgb
@@ -200,14 +329,9 @@ class _SynthesisFn(torch.autograd.Function):
             L, rec = gen.layers[li], saved[li]
             has_rgb = 'wmod' in rec
             grgb = g_rgb[li // 2] if has_rgb else None
-            dz, red_dz_z, red_x_grgb = K.sg2_act_bwd(rec['y'], gin, gin_scale, grgb, rec.get('wmod'), L.bias, rec['nz'],
-                                                     L.noise_w, 0.2, SQRT2)
-            if has_rgb:
-                R = gen.rgbs[li // 2]
-                d_srgb = (red_x_grgb * R.W.t().unsqueeze(0)).sum(2)                 # [B,C]
-                g_lat[:, rgb_idx[li // 2]] += torch.mm(d_srgb, R.mod.A)
+            dz, _, _ = K.sg2_act_bwd(rec['y'], gin, gin_scale, grgb, rec.get('wmod'), L.bias, rec['nz'], L.noise_w, 0.2, SQRT2,
+                                     red=plan.demod(red_dz, B, li), red_rgb=plan.red_rgb(red_rgb, B, li // 2) if has_rgb else None)
             demod, s = rec['demod'], rec['s']
-            d_demod = red_dz_z / demod
             x = rec['x']
             hw = (x.shape[2], x.shape[3])
             if L.up:
@@ -220,9 +344,9 @@ class _SynthesisFn(torch.autograd.Function):
             else:
                 dxmod = L.conv.dgrad(dz, hw, in_scale=demod)
                 del dz
-            q = K.dot_reduce(dxmod, x)                                              # [B,Cin] = d s via x*s
-            d_s = q - s * torch.mm(d_demod * demod * demod * demod, L.T)
-            g_lat[:, conv_idx[li]] += torch.mm(d_s, L.mod.A)
+            K.dot_reduce(dxmod, x, out=plan.s(q_all, B, li).view(-1))                # [B,Cin] = d s via x*s
             gin, gin_scale = dxmod, s
             rec['y'] = rec['x'] = None
+        # d s = q - s * ((d demod * demod^3) T) for every conv, then the whole latent gradient (d s A, and d s_rgb A of the ToRGBs): two launches
+        g_lat = plan.backward(B, s_all, d_all, red_dz, q_all, red_rgb)
         return g_lat, None, None

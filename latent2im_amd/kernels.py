@@ -64,13 +64,18 @@ def torgb_fwd(x, wmod, bias):
 
 
 def sg2_act_bwd(y, gin=None, gin_scale=None, grgb=None, wmod_rgb=None, bias=None, noise=None, noise_w=0.0,
-                slope=0.2, gain=SQRT2, want_rgb_red=True):
-    """Fused StyledConv elementwise backward (see l2i.h).  Returns (dz, red_dz_z [B,C], red_x_grgb [B,C,3] or None)."""
+                slope=0.2, gain=SQRT2, want_rgb_red=True, red=None, red_rgb=None):
+    """Fused StyledConv elementwise backward (see l2i.h).  Returns (dz, red_dz_z [B,C], red_x_grgb [B,C,3] or None).  ``red`` / ``red_rgb``:
+    ZEROED destination buffers of the two reductions (views of one buffer zeroed once per backward pass); allocated here when absent."""
     lib = _lib.load()
     b, c, h, w = y.shape
     dz = torch.empty_like(y)
-    red = torch.zeros(b, c, device=y.device, dtype=torch.float32)
-    red_rgb = torch.zeros(b, c, 3, device=y.device, dtype=torch.float32) if (grgb is not None and want_rgb_red) else None
+    if red is None:
+        red = torch.zeros(b, c, device=y.device, dtype=torch.float32)
+    if red_rgb is None and grgb is not None and want_rgb_red:
+        red_rgb = torch.zeros(b, c, 3, device=y.device, dtype=torch.float32)
+    if grgb is None or not want_rgb_red:
+        red_rgb = None
     _lib.check(lib.l2i_sg2_act_bwd_f32(_lib.fptr(dz), _lib.fptr(gin), _lib.fptr(gin_scale), _lib.fptr(grgb),
                                        _lib.fptr(wmod_rgb), _lib.fptr(y), _lib.fptr(bias), _lib.fptr(noise),
                                        float(noise_w), float(slope), float(gain), _lib.fptr(red), _lib.fptr(red_rgb),
@@ -78,8 +83,9 @@ def sg2_act_bwd(y, gin=None, gin_scale=None, grgb=None, wmod_rgb=None, bias=None
     return dz, red, red_rgb
 
 
-def dot_reduce(a, b=None):
-    """a, b [..., P] viewed as [rows, cols] with cols = prod(last 2 dims) for 4-D maps: returns sum over pixels."""
+def dot_reduce(a, b=None, out=None):
+    """a, b [..., P] viewed as [rows, cols] with cols = prod(last 2 dims) for 4-D maps: returns sum over pixels.  ``out``: a ZEROED
+    contiguous destination of ``rows`` floats (a view of a buffer zeroed once per backward pass); allocated here when absent."""
     lib = _lib.load()
     if a.dim() == 4:
         rows, cols = a.shape[0] * a.shape[1], a.shape[2] * a.shape[3]
@@ -87,7 +93,9 @@ def dot_reduce(a, b=None):
     else:
         rows, cols = a.shape[0], a.numel() // a.shape[0]
         shape = (rows,)
-    out = torch.zeros(rows, device=a.device, dtype=torch.float32)
+    if out is None:
+        out = torch.zeros(rows, device=a.device, dtype=torch.float32)
+    assert out.numel() == rows and out.is_contiguous()
     _lib.check(lib.l2i_dot_reduce_f32(_lib.fptr(out), _lib.fptr(a), _lib.fptr(b), rows, cols, _lib.stream_ptr()),
                'l2i_dot_reduce_f32')
     return out.reshape(shape)
@@ -190,3 +198,14 @@ def pool2x2(x, scale=0.25):
     y = torch.empty(n, c, h // 2, w // 2, device=x.device, dtype=torch.float32)
     _lib.check(lib.l2i_pool2x2_f32(_lib.fptr(y), _lib.fptr(x), n * c, h // 2, w // 2, float(scale), _lib.stream_ptr()), 'l2i_pool2x2_f32')
     return y
+
+
+def segmented_matvec(out, inp, w, segs, block_seg, nblocks, B, in2=None, bias=None, e1=None, e2=None, wmod=None, wrgb=None):
+    """l2i_segmented_matvec_f32 (include/l2i.h): every layer's style-dependent vectors of one kind in one launch.  ``segs`` / ``block_seg``
+    are device tensors holding the segment tables (latent2im_amd/generator.py:_ModPlan)."""
+    lib = _lib.load()
+    _lib.check(lib.l2i_segmented_matvec_f32(_lib.fptr(out), _lib.fptr(inp), _lib.fptr(in2), _lib.fptr(w), _lib.fptr(bias), _lib.fptr(e1), _lib.fptr(e2),
+                                            _lib.fptr(wmod), _lib.fptr(wrgb), _lib.ptr(segs), _lib.ptr(block_seg), int(nblocks), int(B),
+                                            _lib.stream_ptr()), 'l2i_segmented_matvec_f32')
+    return out
+

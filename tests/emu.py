@@ -106,3 +106,60 @@ def seeded_state(module, seed, scale=1.0):
         sd[k] = (a * (scale / np.sqrt(v.shape[1])) if v.dim() == 2 else a * 0.1).astype(np.float32)
     module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return sd
+
+
+def emulate_segmented_matvec(out, inp, w, segs, block_seg, nblocks, B, in2=None, bias=None, e1=None, e2=None, wmod=None, wrgb=None):
+    """Semantics of l2i_segmented_matvec_f32 (include/l2i.h) in float64 numpy, driven by the same device-format segment tables the product
+    hands the kernel (latent2im_amd/generator.py:_ModPlan): walks the (segment, row block) list block by block like the grid does."""
+    import ctypes
+    import numpy as np
+    from latent2im_amd import _lib
+    raw = bytes(segs.cpu().numpy().tobytes())
+    n = len(raw) // ctypes.sizeof(_lib.SegmvSeg)
+    table = (_lib.SegmvSeg * n).from_buffer_copy(raw)
+    bs = block_seg.cpu().numpy().reshape(-1, 2)
+    assert len(bs) == nblocks
+    f = lambda t: None if t is None else t.detach().cpu().double().numpy().reshape(-1)
+    o, i1, i2, W, bi, E1, E2, wm, wr = out.detach().cpu().double().numpy().reshape(-1).copy(), f(inp), f(in2), f(w), f(bias), f(e1), f(e2), \
+        (None if wmod is None else wmod.detach().cpu().double().numpy().reshape(-1).copy()), f(wrgb)
+    written = np.zeros(o.shape, dtype=bool)
+    for si, rb in bs:
+        sg = table[si]
+        r = np.arange(rb * 64, min(rb * 64 + 64, sg.rows))
+        for b in range(B):
+            acc = np.zeros(len(r))
+            for pi in range(sg.nparts):
+                pt = sg.part[pi]
+                assert pt.K % 4 == 0 and pt.K <= 512
+                base = pt.in_off_c + B * pt.in_off_b
+                k = np.arange(pt.K)
+                if pt.pre == 3:
+                    x = sum(i2[base + (b * pt.K + k) * 3 + q] * wr[pt.aux_off + q * pt.K + k] for q in range(3))
+                else:
+                    x = i1[base + b * pt.in_bstride + k]
+                    if pt.pre == 1:
+                        x = x * x
+                    elif pt.pre == 2:
+                        x = x * i2[base + b * pt.in_bstride + k] ** 2
+                Wm = W[pt.w_off + k[:, None] * pt.w_pitch + r[None, :]]
+                acc = acc + x @ Wm
+            v = acc
+            if sg.epi == 0:
+                v = v + bi[sg.bias_off + r]
+            elif sg.epi == 1:
+                v = 1.0 / np.sqrt(v + 1e-8)
+            elif sg.epi == 2:
+                ei = sg.e_off_c + B * sg.e_off_b + b * sg.e_bstride + r
+                v = E1[ei] - E2[ei] * v
+            idx = sg.out_off_c + B * sg.out_off_b + b * sg.out_bstride + r
+            assert not written[idx].any(), 'two blocks write the same output'
+            written[idx] = True
+            o[idx] = v
+            if sg.epi == 0 and sg.rgb_off_b >= 0:
+                for q in range(3):
+                    wm[B * sg.rgb_off_b + b * 3 * sg.rows + q * sg.rows + r] = wr[sg.rgb_w_off + q * sg.rows + r] * v
+    assert written.all(), 'output elements left unwritten'
+    out.copy_(torch.from_numpy(o).to(out.dtype).reshape(out.shape))
+    if wmod is not None:
+        wmod.copy_(torch.from_numpy(wm).to(wmod.dtype).reshape(wmod.shape))
+    return out

@@ -714,3 +714,37 @@ def test_batchnorm_training_kernels():
     close(dg, gg_r, 1e-4, 1e-4)
     close(db, gb_r, 1e-4, 1e-4)
     close(gm, gy.double() * (yr > 0), 0, 0)
+
+
+@pytest.mark.parametrize('size,batch', [(32, 3), (256, 8), (1024, 16)])
+def test_segmented_matvec_kernel_vs_table_emulation(size, batch):
+    """l2i_segmented_matvec_f32 (every modulation / demodulation / ToRGB weight of a generator pass in two launches, d s and the latent
+    gradient in two more) against a float64 numpy execution of the SAME segment tables (tests/emu.py; the tables themselves are checked
+    against the layer-by-layer formulas in tests/test_modplan_cpu.py).  Batches above 8 take a second accumulator pass."""
+    from latent2im_amd import generator
+    from tests import emu
+    G = generator.Generator(synth.generator_state(size, seed=100), size, device=DEV)
+    plan = G.modplan
+    rs = np.random.RandomState(size + batch)
+    B = batch
+    lat = T(rs.randn(B, G.n_latent, 512)).to(DEV)
+    s_all, d_all, w_all = plan.forward(lat)
+    red_dz, q_all, red_rgb = plan.reductions(B, DEV)
+    red_dz.copy_(T(rs.randn(red_dz.numel())))
+    q_all.copy_(T(rs.randn(q_all.numel())))
+    red_rgb.copy_(T(rs.randn(red_rgb.numel())))
+    g = plan.backward(B, s_all, d_all, red_dz, q_all, red_rgb)
+    torch.cuda.synchronize()
+    real = kernels.segmented_matvec
+    try:
+        kernels.segmented_matvec = emu.emulate_segmented_matvec
+        cpu = lambda t: t.detach().cpu()
+        plan_c = generator.Generator(synth.generator_state(size, seed=100), size, device='cpu').modplan
+        s_c, d_c, w_c = plan_c.forward(cpu(lat))
+        g_c = plan_c.backward(B, s_c, d_c, cpu(red_dz), cpu(q_all), cpu(red_rgb))
+    finally:
+        kernels.segmented_matvec = real
+    close(s_all, s_c, 1e-5, 1e-5)
+    close(d_all, d_c, 1e-5, 1e-6)
+    close(w_all, w_c, 1e-5, 1e-5)
+    assert float((g.cpu() - g_c).abs().max()) < 1e-5 * float(g_c.abs().max())
