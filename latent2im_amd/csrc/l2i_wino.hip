@@ -28,6 +28,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "l2i.h"
 #include "l2i_internal.h"
@@ -36,7 +37,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Packed fp32 VALU (two independent lanes of work per issue slot).  Inline asm because hipcc scalarises most f32x2
-// arithmetic (and cannot see hazards inside asm: see pk_mul_op).
+// arithmetic (and cannot see hazards inside asm: see pk_mul_op).  [r3] A/B against the same arithmetic as two single-lane
+// v_add / v_sub / v_mul per packed instruction (one asm statement each, so that the SLP vectoriser cannot re-pack them), interleaved in one
+// process on fifteen launch shapes of the step: the single-lane build is 1.2 - 6.4 % SLOWER on every shape.  Packed stays.
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -67,10 +70,11 @@ constexpr int BM = 32, CK = 8;               // block = 32 channels x 64 tiles (
 constexpr int IH = 10, IW = 34, PLANE = IH * IW, NRAW = CK * PLANE, NIN = (NRAW + 255) / 256;
 constexpr int NU4 = CK * 4 * BM;                       // float4 of U per chunk: [c][i][ch] x (4 j) = 16 KiB
 constexpr int NWV = NU4 / 256;
-constexpr int RAWBUF = NRAW + 64;
-constexpr int TAB = 96;                                // [2 x 8 style scales, pad to 32][32 demod][32 bias]
-constexpr int LDS_FLOATS = 2 * RAWBUF + 2 * NU4 * 4 + TAB;   // raw tile and U double buffered: one barrier per chunk; the 32 KiB
-                                                             // of epilogue transpose strips alias the two U stages
+constexpr int RAWBUF = NIN * 256;                      // a DMA slot writes all 256 lanes (out-of-tile lanes: zeros behind the tile)
+constexpr int TAB = 96;                                // [2 x 8 style scales of the masked path, pad to 32][32 demod][32 bias]
+constexpr int NRS = 3;                                 // raw stages: the unmasked (DMA) path fetches the raw tile TWO chunks ahead
+constexpr int LDS_FLOATS = NRS * RAWBUF + 2 * NU4 * 4 + TAB;   // one barrier per chunk; the 32 KiB of epilogue transpose strips alias the two
+                                                               // U stages; SCALE && !MASK: + Cin style scales
 }
 
 // SCALE: the launch has a style scale (in_scale: the generator's modulated convs).  Without one (VGG-19, ResNet-50, discriminator and every
@@ -78,13 +82,21 @@ constexpr int LDS_FLOATS = 2 * RAWBUF + 2 * NU4 * 4 + TAB;   // raw tile and U d
 // matrix time (ablation builds: the kernel's time is the MFMA time PLUS its other instructions' issue time, almost without overlap —
 // 0.63 ms = 0.44 (MFMA-bound) + 0.26 (everything else, MFMAs replaced by one FMA each) at 512->512 @64^2), and 16 of the 48 packed VALU
 // instructions of a chunk were that multiply
-template <bool MASK, bool SCALE>
+// [r3] MASK = false (87 % of the family's time): the raw halo tile goes global -> LDS by DMA too (buffer_load_dword ... lds: one element per
+// lane, element e = slot * 256 + tid of the [CK][IH][IW] tile exactly as before, out-of-image elements through an out-of-range offset =
+// zeros) — no staging registers, no commit pass (11 LDS stores + 34 VALU per chunk and wave: the mask / ReLU selects ran even when the launch
+// had neither), no wait on register loads at the top of a chunk; the style scales of the whole layer are read into LDS once per block.
+// RELU (the gradient mask is the input itself, VGG-19's convs on pre-ReLU taps): max(x, 0) on the fragment reads, only in that instantiation.
+// MASK = true keeps the register path (the mask tile would otherwise be a second DMA stream multiplied into every fragment).
+template <bool MASK, bool SCALE, bool RELU>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params p, const WinoLaunch L) {
     using namespace wg;
+    static_assert(!(MASK && RELU), "relu_in launches take the unmasked path");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* rawbuf = smem;                              // 2 x [CK][IH][IW]
-    float* ubuf = smem + 2 * RAWBUF;                   // 2 x [CK][4][BM] float4
-    float* tab = smem + 2 * RAWBUF + 2 * NU4 * 4;
+    float* rawbuf = smem;                              // NRS x [CK][IH][IW] (the masked path uses two of them)
+    float* ubuf = smem + NRS * RAWBUF;                 // 2 x [CK][4][BM] float4
+    float* tab = smem + NRS * RAWBUF + 2 * NU4 * 4;
+    float* stab = tab + TAB;                           // SCALE && !MASK: [Cin] style scales of this sample
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, n = lane & 15;           // MFMA K index (channel within a group of 4) / tile column
@@ -138,8 +150,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
     // barrier is in the chunk loop), slots NWV.. = raw halo elements (+ the style scale) into registers.  `on` = false (no next
     // chunk) swaps in null descriptors: no traffic, zeros.  compute() issues two slots per MFMA group, between the MFMAs.
     const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0u, 0x00020000);
-    constexpr int NSLOT = NWV + NIN + 1;
-    auto issue_slot = [&](int sl, int c0, float* ustage, bool on) {
+    constexpr int NSLOT = NWV + NIN + (MASK ? 1 : 0);
+    // [r3] Unmasked path: the raw tile is fetched TWO chunks ahead into a ring of three LDS stages (c0r / rstage), U one chunk ahead (c0 /
+    // ustage): a chunk is ~1.2 us of matrix work, and on the high-resolution layers (2 GB inputs streamed from HBM while the chip moves
+    // 2 TB/s) a one-chunk distance left the top-of-chunk wait exposed: 64 -> 64 @1024^2 ran at 185 TFLOP/s against 230 on the L2-resident
+    // 512-channel layers.  LDS-DMA needs no registers, so the distance costs one 11 KiB stage.  U slots are issued first, raw slots last:
+    // the top-of-chunk wait is vmcnt(NIN) = everything but the youngest raw tile.
+    auto issue_slot = [&](int sl, int c0, float* ustage, int c0r, float* rstage, bool on) {
         if (sl < NWV) {
             const unsigned sw = (unsigned)((size_t)c0 * 4 * p.CoutP * 16);
             const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(ustage + wave_u * 256);
@@ -148,43 +165,50 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
                          : "=&s"(keep) : "v"(wvoff), "s"(on ? rs_w : rs_null), "s"(__builtin_amdgcn_readfirstlane(lds0 + sl * 4096)), "s"(sw + sl * wstep));
         } else if (sl < NWV + NIN) {
             const int u = sl - NWV;
-            const unsigned so = (unsigned)c0 * plane_b;
-            rin[u] = __builtin_amdgcn_raw_buffer_load_b32(on ? rs_x : rs_null, voff[u], so, 0);
-            if constexpr (MASK) rmk[u] = __builtin_amdgcn_raw_buffer_load_b32(on ? rs_m : rs_null, voff[u], so, 0);
-        } else if (sl == NWV + NIN) {
+            const unsigned so = (unsigned)(MASK ? c0 : c0r) * plane_b;
+            if constexpr (MASK) {
+                rin[u] = __builtin_amdgcn_raw_buffer_load_b32(on ? rs_x : rs_null, voff[u], so, 0);
+                rmk[u] = __builtin_amdgcn_raw_buffer_load_b32(on ? rs_m : rs_null, voff[u], so, 0);
+            } else {                                       // element e = u * 256 + tid lands at rstage[e]: lane l of the wave at M0 base + 4 l
+                const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(rstage + wave_u * 64);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff[u]), "s"(on ? rs_x : rs_null), "s"(__builtin_amdgcn_readfirstlane(lds0 + u * 1024)), "s"(so));
+            }
+        } else if (MASK && sl == NWV + NIN) {
             rsc = __builtin_amdgcn_raw_buffer_load_b32(on ? rs_s : rs_null, svoff, (unsigned)(c0 * sizeof(float)), 0);
         }
     };
-    auto issue = [&](int c0, float* ustage) {
+    auto issue = [&](int c0, float* ustage, float* rstage) {
 #pragma unroll
-        for (int sl = 0; sl < NSLOT; ++sl) issue_slot(sl, c0, ustage, true);
+        for (int sl = 0; sl < NSLOT; ++sl) issue_slot(sl, c0, ustage, c0, rstage, true);
     };
     const bool relu_mask = p.mask_pos == 1.f && p.mask_neg == 0.f;      // kernel arguments: wave-uniform
-    auto commit = [&](int par) {
-        float* raw = rawbuf + par * RAWBUF;
+    auto commit = [&](int par) {                                         // masked launches only: registers -> LDS with the gradient mask applied
+        if constexpr (MASK) {
+            float* raw = rawbuf + par * RAWBUF;
 #pragma unroll
-        for (int u = 0; u < NIN; ++u) {
-            const int e = tid + u * 256;
-            float v = __uint_as_float(rin[u]);
-            if constexpr (MASK) {
+            for (int u = 0; u < NIN; ++u) {
+                float v = __uint_as_float(rin[u]);
                 if (relu_mask) v = (__uint_as_float(rmk[u]) > 0.f) ? v : 0.f;      // ReLU masks (ResNet-50 gradients): select, no multiply
                 else v *= (__uint_as_float(rmk[u]) > 0.f) ? p.mask_pos : p.mask_neg;
-            } else if (L.relu_in) {
-                v = __builtin_fmaxf(v, 0.f);                                     // (x > 0 ? x : 0) for every x, NaN and -0 included
+                raw[tid + u * 256] = v;
             }
-            raw[(u * 256 + 255 < NRAW || e < NRAW) ? e : NRAW + lane] = v;
+            if (tid < CK) tab[par * CK + tid] = p.in_scale ? __uint_as_float(rsc) : 1.f;
         }
-        if (tid < CK) tab[par * CK + tid] = p.in_scale ? __uint_as_float(rsc) : 1.f;
     };
+    if constexpr (SCALE && !MASK) {                                      // the layer's style scales of this sample, once per block
+        for (int i = tid; i < p.Cin; i += 256) stab[i] = p.in_scale[(size_t)b * p.Cin + i];
+    }
 
     f32x4 acc[16][2];                                  // first defined by the MFMAs of the peeled first chunk (C = 0 constant)
 
     // ---- one chunk: 2 K-steps of 4 channels; lane (kq, n) transforms the patch of (channel 4 s + kq, tile (wave, n)) ----
-    auto compute = [&](int par, auto first_tag, int c0n, float* un, bool on) {
+    auto compute = [&](int par, int rpar, auto first_tag, int c0, int c0n, float* un, int c0r, float* rn, bool on) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const float4* u4 = reinterpret_cast<const float4*>(ubuf + par * NU4 * 4) + n;
-        const float* rp0 = rawbuf + par * RAWBUF + kq * PLANE + (2 * wave) * IW + 2 * n;
+        const float* rp0 = rawbuf + rpar * RAWBUF + kq * PLANE + (2 * wave) * IW + 2 * n;
         // fragments are fetched one step ahead of the MFMAs that use them (raw patch: one K-step ahead; U rows: one position
         // row ahead), so a wave does not depend on its SIMD partner to cover its own LDS latency
         float2 dn[4][2];
@@ -193,6 +217,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
             for (int r = 0; r < 4; ++r) {
                 dn[r][0] = *reinterpret_cast<const float2*>(rp0 + 4 * s * PLANE + r * IW);
                 dn[r][1] = *reinterpret_cast<const float2*>(rp0 + 4 * s * PLANE + r * IW + 2);
+            }
+        };
+        auto relu_d = [&]() {                                  // RELU: pro(x) = max(x, 0) (one plain v_max each: no canonicalising second max)
+            if constexpr (RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        asm("v_max_f32 %0, 0, %0" : "+v"(dn[r][q].x));
+                        asm("v_max_f32 %0, 0, %0" : "+v"(dn[r][q].y));
+                    }
             }
         };
         float4 a0n, a1n;
@@ -208,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
             // occupancy, so the transform is written on register pairs (v_pk_add_f32 / v_pk_mul_f32: two lanes of work per issue
             // slot).  Pairs are the column pairs (0,1) and (2,3) of the patch, exactly what ds_read2_b64 delivers.
             f32x2 t01[4], t23[4];                                  // B^T d, rows i = 0..3
+            relu_d();
             {
                 const f32x2 d0a = {dn[0][0].x, dn[0][0].y}, d0b = {dn[0][1].x, dn[0][1].y};
                 const f32x2 d1a = {dn[1][0].x, dn[1][0].y}, d1b = {dn[1][1].x, dn[1][1].y};
@@ -219,15 +255,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
                 t01[3] = pk_sub(d1a, d3a); t23[3] = pk_sub(d1b, d3b);
             }
             f32x2 scp = {1.f, 1.f};
-            if constexpr (SCALE) { const float sc = tab[par * CK + 4 * s + kq]; scp = f32x2{sc, sc}; }
+            if constexpr (SCALE) { const float sc = MASK ? tab[par * CK + 4 * s + kq] : stab[c0 + 4 * s + kq]; scp = f32x2{sc, sc}; }
             if (s == 0) fetch_d(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 a0 = a0n, a1 = a1n;
                 if (i < 3) fetch_a(s, i + 1);
                 else if (s == 0) fetch_a(1, 0);
-                issue_slot(2 * (4 * s + i), c0n, un, on);            // next chunk: two staging slots per MFMA group, issued beside the MFMAs
-                issue_slot(2 * (4 * s + i) + 1, c0n, un, on);
+                issue_slot(2 * (4 * s + i), c0n, un, c0r, rn, on);   // later chunks: two staging slots per MFMA group, issued beside the MFMAs
+                issue_slot(2 * (4 * s + i) + 1, c0n, un, c0r, rn, on);
                 __builtin_amdgcn_sched_barrier(0);
                 // (B^T d) B: (v0, v3) = (t0 - t2, t1 - t3);  (v1, v2) = (t2 + t1, t2 - t1); then the style scale of the channel
                 const f32x2 v03 = SCALE ? pk_mul_op(pk_sub(t01[i], t23[i]), scp) : pk_sub_op(t01[i], t23[i]);
@@ -244,21 +280,41 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const l2i_conv_params
         }
     };
 
-    static_assert(wg::NWV + wg::NIN + 1 <= 16, "two staging slots per MFMA group, 8 groups per chunk");
-    issue(0, ubuf);
-    commit(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the chunk's U DMA has landed
-    __syncthreads();
-    compute(0, std::true_type(), 1 < L.nchunks ? CK : 0, ubuf + NU4 * 4, true);
-    for (int ch = 1; ch < L.nchunks; ++ch) {
-        const int par = ch & 1;
-        commit(par);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's U DMA (issued one chunk ago) has landed
-        __syncthreads();                                   // raw tile of this chunk written; every wave is past the MFMAs of the previous chunk,
-                                                           // so the other raw / U stage may be refilled
-        // (after the last chunk the staging slots re-fetch chunk 0 — valid addresses, L2 hits, never read — instead of switching every
-        //  slot's descriptor to a null one: 32 scalar selects per chunk less in the MFMA stream)
-        compute(par, std::false_type(), ch + 1 < L.nchunks ? (ch + 1) * CK : 0, ubuf + (par ^ 1) * NU4 * 4, true);
+    static_assert(NSLOT <= 16, "two staging slots per MFMA group, 8 groups per chunk");
+    if constexpr (MASK) {
+        issue(0, ubuf, rawbuf);
+        commit(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the chunk's U DMA has landed
+        __syncthreads();
+        compute(0, 0, std::true_type(), 0, 1 < L.nchunks ? CK : 0, ubuf + NU4 * 4, 0, rawbuf, true);
+        for (int ch = 1; ch < L.nchunks; ++ch) {
+            const int par = ch & 1;
+            commit(par);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's U DMA (issued one chunk ago) has landed
+            __syncthreads();                                   // raw tile of this chunk written; every wave is past the MFMAs of the previous chunk,
+                                                               // so the other raw / U stage may be refilled
+            // (after the last chunk the staging slots re-fetch chunk 0 — valid addresses, L2 hits, never read — instead of switching every
+            //  slot's descriptor to a null one: 32 scalar selects per chunk less in the MFMA stream)
+            compute(par, par, std::false_type(), ch * CK, ch + 1 < L.nchunks ? (ch + 1) * CK : 0, ubuf + (par ^ 1) * NU4 * 4, 0, rawbuf, true);
+        }
+    } else {
+        // U(0), raw(0), then raw(1): the wait leaves the youngest raw tile in flight
+        issue(0, ubuf, rawbuf);
+#pragma unroll
+        for (int sl = NWV; sl < NWV + NIN; ++sl) issue_slot(sl, 0, ubuf, 1 < L.nchunks ? CK : 0, rawbuf + RAWBUF, true);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN) : "memory");
+        __syncthreads();
+        compute(0, 0, std::true_type(), 0, 1 < L.nchunks ? CK : 0, ubuf + NU4 * 4, 2 < L.nchunks ? 2 * CK : 0, rawbuf + 2 * RAWBUF, true);
+        int rpar = 1;
+        for (int ch = 1; ch < L.nchunks; ++ch) {
+            const int par = ch & 1;
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN) : "memory");   // U(ch) and raw(ch) have landed; raw(ch + 1) stays in flight
+            __syncthreads();                                   // ... for every wave, and every wave is past the MFMAs of chunk ch - 1: its stages may be refilled
+            const int rnext = rpar == 0 ? 2 : rpar - 1;        // (ch + 2) % 3 == (ch - 1) % 3
+            compute(par, rpar, std::false_type(), ch * CK, ch + 1 < L.nchunks ? (ch + 1) * CK : 0, ubuf + (par ^ 1) * NU4 * 4,
+                    ch + 2 < L.nchunks ? (ch + 2) * CK : 0, rawbuf + rnext * RAWBUF, true);
+            rpar = rpar == 2 ? 0 : rpar + 1;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (null-descriptor DMA of the last chunk)
     __syncthreads();                                       // the U stages become the transpose strips
@@ -374,17 +430,26 @@ static int launch_wino(const l2i_conv_params& p, hipStream_t st) {
     if (total <= 0 || total > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv2d_wino: too many tiles");
     L.total = (int)total;
     L.nchunks = p.Cin / wg::CK;
-    const size_t lds = (size_t)wg::LDS_FLOATS * sizeof(float);
     const unsigned grid = (unsigned)((total + 7) & ~7L);
     L.relu_in = (p.in_mask == p.x && p.mask_pos == 1.f && p.mask_neg == 0.f) ? 1 : 0;
     const bool mask = p.in_mask != nullptr && !L.relu_in;
-    if (p.in_scale) {
-        if (mask) hipLaunchKernelGGL((conv_wino_kernel<true, true>), dim3(grid), dim3(256), lds, st, p, L);
-        else hipLaunchKernelGGL((conv_wino_kernel<false, true>), dim3(grid), dim3(256), lds, st, p, L);
-    } else {
-        if (mask) hipLaunchKernelGGL((conv_wino_kernel<true, false>), dim3(grid), dim3(256), lds, st, p, L);
-        else hipLaunchKernelGGL((conv_wino_kernel<false, false>), dim3(grid), dim3(256), lds, st, p, L);
-    }
+    const bool scale = p.in_scale != nullptr;
+    const size_t lds = (size_t)(wg::LDS_FLOATS + ((scale && !mask) ? ((p.Cin + 3) & ~3) : 0)) * sizeof(float);
+    if (lds > 80 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino: too many input channels for the style-scale table");
+    // > 64 KiB of dynamic LDS (three raw stages): the limit is raised once per instantiation
+#define L2I_WINO(M_, S_, R_)                                                                                                            \
+    do {                                                                                                                                \
+        static bool done = false;                                                                                                       \
+        if (!done) {                                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<M_, S_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            done = true;                                                                                                                \
+        }                                                                                                                               \
+        hipLaunchKernelGGL((conv_wino_kernel<M_, S_, R_>), dim3(grid), dim3(256), lds, st, p, L);                                        \
+    } while (0)
+    if (mask) { if (scale) L2I_WINO(true, true, false); else L2I_WINO(true, false, false); }
+    else if (L.relu_in) { if (scale) L2I_WINO(false, true, true); else L2I_WINO(false, false, true); }
+    else { if (scale) L2I_WINO(false, true, false); else L2I_WINO(false, false, false); }
+#undef L2I_WINO
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }
