@@ -90,6 +90,9 @@ typedef struct l2i_conv_params {
     float* sq_out;          /* sum (y - sq_ref)^2 over its outputs into sq_out[0 .. L2I_SQ_SLOTS-1] (fp32 atomics, one slot per block id mod   */
                             /* L2I_SQ_SLOTS; the caller zeroes the slots and sums them): the ContentLoss value of a VGG tap                  */
                             /* (transform_base.py:57-63, mse = the sum / N) without re-reading the feature map in a separate pass             */
+    int64_t w_bstride;      /* l2i_conv2d_h8 / l2i_conv_transpose2d_h8: bytes between the weight planes of consecutive samples (the generator's */
+                            /* modulated convs: style and demodulation folded into one plane set per sample), 0 = one set for every sample    */
+    int32_t out_f32;        /* l2i_conv2d_h8: 1 = the output (and residual / res_mask / out_mask / res_sub) is fp32 NCHW instead of bf16 h8      */
 } l2i_conv_params;
 #define L2I_SQ_SLOTS 1024
 
@@ -135,6 +138,18 @@ int l2i_conv_transpose2d_bf16x3_f32(const l2i_conv_params* p, void* stream);
  * (latent2im_amd/conv.py:pack_weight_wino).  tile_hint must be 0.
  * Shapes outside the constraints return L2I_E_UNSUPPORTED (callers use l2i_conv2d_f32). */
 int l2i_conv2d_wino_f32(const l2i_conv_params* p, void* stream);
+
+/* ---- the 16-bit path (BASELINE config 5: "fp16 MFMA"; bf16 here: fp32's exponent range, so gradients of 1e-9 need no loss scaling) ----
+ * Tensors in the channel-blocked "h8" layout [B][C/8][H][W][8] bf16 (the 8 channels of a pixel = 16 contiguous bytes = one MFMA fragment);
+ * one v_mfma_f32_32x32x16_bf16 product per MAC, fp32 accumulation; fp32 only for bias, noise, per-sample scales and the loss sums.
+ * l2i_conv2d_h8: 1x1 (pad 0) / 3x3 (pad 0 or 1) correlation, stride 1 or 2, Cin % 32 == 0.  Same struct as l2i_conv2d_f32 with
+ *   x, y, residual, res_mask, out_mask, res_sub, sq_ref -> bf16 h8 tensors (fp32 NCHW for y and the epilogue operands when out_f32 = 1);
+ *   w_hi -> bf16 weight planes [Cin/16][KH*KW][2][CoutP][8] (latent2im_amd/conv.py:pack_weight_bf16x3, hi plane), per sample when w_bstride != 0;
+ *   noise [B,1,OHf,OWf], bias [Cout], out_scale [B,Cout] fp32; `w`, `w_lo` ignored; in_scale / in_mask must be NULL (no prologue fusions:
+ *   scales live in the weights, masks in the producing epilogue).  h8 output needs Cout % 8 == 0.
+ * l2i_conv_transpose2d_h8: stride-2 transposed 3x3 conv (pad 0 / 1), all four output parities per launch, h8 in and out. */
+int l2i_conv2d_h8(const l2i_conv_params* p, void* stream);
+int l2i_conv_transpose2d_h8(const l2i_conv_params* p, void* stream);
 
 /* out[i] = act_grad_table(x[i] + b[(i / step_b) % size_b], ref[i]) * scale   — the reference op, all six
  * act*10+grad cases (fused_bias_act_kernel.cu:36-47).  b / ref may be NULL (= the reference's empty tensors). */

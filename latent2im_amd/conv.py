@@ -33,6 +33,8 @@ FAMILY_INFO = {
     'direct_small_valu': ('conv_direct_small_kernel', 1.0, 157.3),
     'implicit_gemm_bf16x3': ('conv_bf16x3_pipe_kernel', 3.0, 2500.0),
     'transposed_bf16x3': ('conv_bf16x3_pipe_kernel<TR>', 3.0, 2500.0),
+    'conv_h8': ('conv_h8_kernel', 1.0, 2500.0),
+    'transposed_h8': ('conv_h8_kernel<TR>', 1.0, 2500.0),
 }
 
 
@@ -480,3 +482,138 @@ class FrozenConv2d:
                 and gy.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and (kw.get('in_mask') is None or kw['in_mask'].data_ptr() % 16 == 0)):
             return run_small_transposed(self.bwd_small, gy, out, **kw)
         return run_plan(self.bwd, gy, out, **kw)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The 16-bit path (BASELINE config 5): bf16 tensors in the channel-blocked "h8" layout [B, C/8, H, W, 8] (include/l2i.h: l2i_conv2d_h8)
+# ------------------------------------------------------------------------------------------------------------------------------------
+def to_h8(x, pad_to=8):
+    """fp32 / bf16 NCHW -> bf16 h8 [B, C/8, H, W, 8] (channels zero-padded to a multiple of ``pad_to``).  A torch reshuffle: used at the few
+    fp32 boundaries of the 16-bit path and by the tests, not inside the conv stack (the kernels read and write h8 directly)."""
+    B, C, H, W = x.shape
+    cp = (C + pad_to - 1) // pad_to * pad_to
+    if cp != C:
+        x = torch.cat([x, x.new_zeros(B, cp - C, H, W)], 1)
+    return x.reshape(B, cp // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().to(torch.bfloat16)
+
+
+def from_h8(t, channels=None):
+    """bf16 h8 [B, C/8, H, W, 8] -> fp32 NCHW (the first ``channels`` channels)."""
+    B, G8, H, W, _ = t.shape
+    x = t.float().permute(0, 1, 4, 2, 3).reshape(B, G8 * 8, H, W)
+    return x if channels is None else x[:, :channels].contiguous()
+
+
+def pack_weight_h8(w):
+    """[Cout, Cin, KH, KW] fp32 -> bf16 plane [Cin/16][KH*KW][2][CoutP][8] (int16 view): the LDS image order of csrc/l2i_conv_h8.hip.
+    Cin is zero-padded to a multiple of 32 (the kernel's K chunk)."""
+    w = torch.as_tensor(w, dtype=torch.float32)
+    cout, cin, kh, kw = w.shape
+    cinp = (cin + 31) // 32 * 32
+    if cinp != cin:
+        w = torch.cat([w, w.new_zeros(cout, cinp - cin, kh, kw)], 1)
+    return pack_weight_bf16x3(w)[0]
+
+
+class H8Conv:
+    """A frozen convolution of the 16-bit path: ``weight`` [Cout, Cin, K, K] in correlation form (K = 1 or 3), stride 1 or 2, or the stride-2
+    TRANSPOSED conv (``transposed=True``: y[co, 2i+k-pad] += x[ci, i] w[co, ci, k], as FrozenConv2d).  Forward and input-gradient both run on
+    l2i_conv2d_h8 / l2i_conv_transpose2d_h8; no weight gradients (the walk is the only trainable tensor)."""
+
+    def __init__(self, weight, stride=1, padding=0, transposed=False, device='cuda'):
+        w = torch.as_tensor(np.asarray(weight) if not torch.is_tensor(weight) else weight, dtype=torch.float32).cpu()
+        self.cout, self.cin, self.k, _ = w.shape
+        self.stride, self.padding, self.transposed, self.device = stride, padding, transposed, device
+        self.cinp, self.coutp_in = (self.cin + 31) // 32 * 32, (self.cout + 31) // 32 * 32
+        wt = w.transpose(0, 1).contiguous()
+        self.w_f32 = w                                               # kept for per-sample modulation (generator)
+        self.fwd_planes = pack_weight_h8(w).to(device)
+        if transposed or stride == 2:
+            self.bwd_planes = pack_weight_h8(wt).to(device)          # transposed fwd: dx = corr_s2(gy, wt); stride-2 fwd: dx = transposed(gy, wt)
+        else:
+            self.bwd_planes = pack_weight_h8(torch.flip(wt, [2, 3])).to(device)
+
+    def out_hw(self, h, w):
+        if self.transposed:
+            return (h - 1) * 2 - 2 * self.padding + self.k, (w - 1) * 2 - 2 * self.padding + self.k
+        return (h + 2 * self.padding - self.k) // self.stride + 1, (w + 2 * self.padding - self.k) // self.stride + 1
+
+    def forward(self, x, out=None, planes=None, w_bstride=0, out_hw=None, **kw):
+        """x h8 [B, Cin/8, H, W, 8] -> h8 [B, Cout/8, OH, OW, 8] (or fp32 NCHW with out_f32=True)."""
+        B, _, H, W, _ = x.shape
+        oh, ow = out_hw if out_hw is not None else self.out_hw(H, W)
+        out_f32 = kw.get('out_f32', False)
+        if out is None:
+            out = (torch.empty(B, self.cout, oh, ow, device=x.device, dtype=torch.float32) if out_f32
+                   else torch.empty(B, (self.cout + 7) // 8, oh, ow, 8, device=x.device, dtype=torch.bfloat16))
+        return run_h8(planes if planes is not None else self.fwd_planes, x, out, self.cinp, self.cout, self.k, 2 if self.transposed else self.stride, self.padding,
+                      transposed=self.transposed, w_bstride=w_bstride, **kw)
+
+    def dgrad(self, gy, in_hw, out=None, planes=None, w_bstride=0, **kw):
+        """Gradient w.r.t. the input of ``forward`` given the gradient w.r.t. its (pre-epilogue) output, both h8."""
+        B = gy.shape[0]
+        out_f32 = kw.get('out_f32', False)
+        if out is None:
+            out = (torch.empty(B, self.cin, in_hw[0], in_hw[1], device=gy.device, dtype=torch.float32) if out_f32
+                   else torch.empty(B, (self.cin + 7) // 8, in_hw[0], in_hw[1], 8, device=gy.device, dtype=torch.bfloat16))
+        pl = planes if planes is not None else self.bwd_planes
+        if self.transposed:                                   # dx[ci, i] = sum gy[co, 2i + k - pad] w[co, ci, k]: a stride-2 correlation
+            return run_h8(pl, gy, out, self.coutp_in, self.cin, self.k, 2, self.padding, transposed=False, w_bstride=w_bstride, **kw)
+        if self.stride == 2:                                  # dx[ci, 2o + k - pad] += gy[co, o] w[co, ci, k]: the transposed conv
+            return run_h8(pl, gy, out, self.coutp_in, self.cin, self.k, 2, self.padding, transposed=True, w_bstride=w_bstride, **kw)
+        return run_h8(pl, gy, out, self.coutp_in, self.cin, self.k, 1, self.k - 1 - self.padding, transposed=False, w_bstride=w_bstride, **kw)
+
+
+def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=0, out_f32=False, out_scale=None, noise=None, noise_w=0.0, bias=None,
+           residual=None, res_mask=None, out_mask=None, act=ACT_NONE, slope=0.2, gain=1.0, out_gain=1.0, accumulate=False, res_sub=None, res_coef=1.0,
+           res_coef_dev=None, sq=None):
+    """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels."""
+    lib = _lib.load()
+    B, cg, H, W, _ = x.shape
+    assert x.dtype == torch.bfloat16 and cg * 8 == cin and cin % 32 == 0, (x.shape, cin)
+    coutp = planes.shape[-2]
+    assert planes.shape[-5] == cin // 16 and planes.shape[-4] == k * k and coutp >= cout, (planes.shape, cin, k, cout)
+    if out_f32:
+        assert y.dtype == torch.float32 and y.shape[1] == cout
+        OHf, OWf = y.shape[2], y.shape[3]
+    else:
+        assert y.dtype == torch.bfloat16 and y.shape[1] * 8 >= cout and cout % 8 == 0, (y.shape, cout)
+        OHf, OWf = y.shape[2], y.shape[3]
+    p = ConvParams()
+    p.x, p.w_hi, p.y = _lib.ptr(x), _lib.ptr(planes), _lib.ptr(y)
+    p.B, p.Cin, p.H, p.W, p.Cout, p.CoutP = B, cin, H, W, cout, coutp
+    p.KH = p.KW = k
+    p.stride, p.pad_y, p.pad_x = stride, pad, pad
+    p.OHf, p.OWf = OHf, OWf
+    if transposed:
+        p.OH, p.OW = (OHf + 1) // 2, (OWf + 1) // 2
+        p.oy_step = p.ox_step = 2
+    else:
+        p.OH, p.OW = min(OHf, (H + 2 * pad - k) // stride + 1), min(OWf, (W + 2 * pad - k) // stride + 1)
+        p.oy_step = p.ox_step = 1
+    p.out_scale, p.noise, p.noise_w, p.bias = _lib.fptr(out_scale), _lib.fptr(noise), float(noise_w), _lib.fptr(bias)
+    for t in (residual, res_mask, out_mask, res_sub):
+        assert t is None or (t.shape == y.shape and t.dtype == y.dtype)
+    p.residual, p.res_mask, p.out_mask = _lib.ptr(residual), _lib.ptr(res_mask), _lib.ptr(out_mask)
+    if res_sub is not None:
+        p.res_sub, p.res_coef, p.res_coef_dev = _lib.ptr(res_sub), float(res_coef), _lib.fptr(res_coef_dev)
+    p.act, p.act_slope, p.act_gain, p.out_gain = act, slope, gain, out_gain
+    p.accumulate = int(accumulate)
+    p.w_bstride, p.out_f32 = int(w_bstride), int(out_f32)
+    if sq is not None:                                            # (reference like y, [SQ_SLOTS] zeroed accumulator, [fused flag])
+        assert sq[0].shape == y.shape and sq[0].dtype == y.dtype and sq[1].numel() == _lib.SQ_SLOTS
+        p.sq_ref, p.sq_out = _lib.ptr(sq[0]), _lib.fptr(sq[1])
+        sq[2][0] = True
+    entry, name = (lib.l2i_conv_transpose2d_h8, 'l2i_conv_transpose2d_h8') if transposed else (lib.l2i_conv2d_h8, 'l2i_conv2d_h8')
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(entry(p, _lib.stream_ptr()), name)
+        e1.record()
+        npx = H * W if transposed else int(p.OH) * int(p.OW)
+        PROFILE.append((e0, e1, 2.0 * B * cout * cin * k * k * npx, (B, cin, cout, k, k, stride, H, W, int(p.OH), int(p.OW), 2 if transposed else 1, False, False,
+                                                                     ''.join(c for c, t in zip('dnbrmoas', (out_scale, noise, bias, residual, res_mask, out_mask, accumulate or None, res_sub)) if t is not None) + str(act)),
+                        name, 'transposed_h8' if transposed else 'conv_h8'))
+        return y
+    _lib.check(entry(p, _lib.stream_ptr()), name)
+    return y

@@ -1,0 +1,454 @@
+// l2i_conv_h8.hip — 1x1 / 3x3 correlations (stride 1 / 2) and the stride-2 transposed 3x3 conv on bf16 tensors in the channel-blocked
+// "h8" layout, one v_mfma_f32_32x32x16_bf16 product per MAC, fp32 accumulation (gfx950).  Entry points l2i_conv2d_h8 /
+// l2i_conv_transpose2d_h8: the 16-bit path of BASELINE config 5.
+//
+// Layout.  An activation tensor is [B][C/8][H][W][8] bf16: the 8 channels of a pixel are 16 contiguous bytes.  That is exactly one B
+// fragment of the 32x32x16 MFMA (lane (n, half) holds k = 8 half .. 8 half + 7 of pixel n), so
+//   * a halo tile goes global -> LDS by DMA (buffer_load_dwordx4 ... lds) one 16-byte pixel slot per lane, ALWAYS 16-byte aligned whatever
+//     the tile origin (the fp32 NCHW kernels need aligned 4-pixel row vectors, register staging and a split pass: what bounds
+//     conv_bf16x3_pipe_kernel), stride-2 layers with even / odd columns in separate planes of a row (the DMA's source
+//     address is per lane, its LDS target lane-linear) so that fragment reads stay unit-stride;
+//   * a fragment read is one ds_read_b128 at lane base + immediate, consecutive lanes on consecutive slots (conflict free);
+//   * the epilogue exchanges the two lane halves' channel quads with v_permlane32_swap and stores one 16-byte pixel slot per lane and
+//     8-channel group: 512 contiguous bytes per half wave.
+// Weights: bf16 planes in the LDS image order [Cin/16][tap][half][CoutP][8] (latent2im_amd/conv.py:pack_weight_bf16x3, hi plane), DMA'd one
+// kernel ROW (K taps x 2 steps) per phase, double buffered; `w_bstride` != 0: one plane set per sample (the generator's modulated
+// convs: the host folds style and demodulation into the weights per sample, like the reference's own formulation, networks.py:234-243).
+// K chunk = 32 channels; phase = (chunk, kernel row): wait for the phase's weights, ONE barrier, start the next phase's weight DMA and
+// (first phase of a chunk) the next chunk's tile DMA, then K x 2 x WM x WN MFMAs.
+// Mapping as everywhere in this library: M = out-channels (A operand), N = 32-pixel row segments (B operand), 4 waves along N.
+// No prologue fusions (in_scale / in_mask): masks are applied by the producing epilogues, scales live in the weights.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "l2i.h"
+#include "l2i_internal.h"
+#include "l2i_epilogue.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace g8 {
+template <int WN, int K, int S, int TR> struct Geo {
+    static constexpr int TH = 4 * WN;
+    static constexpr bool GATHER = (K == 1 && S == 2);                    // 1x1 stride 2: only even rows / columns are staged
+    static constexpr int ROWS = TR ? TH + 1 : (GATHER ? TH : (TH - 1) * S + K);
+    static constexpr int RSTEP = GATHER ? 2 : 1;                          // image rows between staged rows
+    static constexpr int COLS = TR ? 33 : (GATHER ? 32 : 31 * S + K);     // staged pixel slots per row
+    static constexpr int CSTEP = GATHER ? 2 : 1;
+    static constexpr bool SPLIT = (S == 2 && !GATHER);                    // even columns first, odd columns from RPH on
+    static constexpr int RPH = (COLS + 1) / 2;
+    static constexpr int RP = COLS;
+    static constexpr int KS = 2;                                          // 16-channel MFMA steps per chunk
+    static constexpr int NH = 2 * KS;                                     // 8-channel groups per chunk
+    static constexpr int CK = 16 * KS;
+    static constexpr int HSTRIDE = ROWS * RP;                             // slots of one 8-channel group
+    static constexpr int IN_SLOTS = NH * HSTRIDE;
+    static constexpr int NPW = ((IN_SLOTS + 63) / 64 + 3) / 4;            // 1 KiB DMA pieces per wave and chunk (every wave issues NPW: the
+    static constexpr int IN_STAGE = 4 * NPW * 64;                         // pieces past the tile land in padding behind it)
+};
+}
+
+struct H8Launch {
+    int tiles_x, tiles_y, mblocks, total, nchunks;
+    int vec_epi;                       // fp32 NCHW output: the LDS-transposed epilogue with 16-byte accesses applies
+};
+
+__device__ __forceinline__ unsigned cvt_pk_bf16_h8(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// ---- epilogue, h8 output ----------------------------------------------------------------------------------------------------------
+// acc[m][n][r]: channel m0 + 32 m + (r & 3) + 8 (r >> 2) + 4 half, pixel (oy0 + wave WN + n, ox0 + j).  Register quad q = r >> 2 of a lane
+// half holds channels 4 half .. 4 half + 3 of 8-channel group q; v_permlane32_swap on the quads of groups (2 pr, 2 pr + 1) gives lanes
+// 0-31 all eight channels of group 2 pr and lanes 32-63 those of group 2 pr + 1 (guide T21), i.e. lane (half, j) finishes pixel j of group
+// 2 pr + half: fused terms are applied on whole 16-byte slots, then one 16-byte store.
+//   epi(a) = act( a * out_scale[b,co] * (out_mask > 0) + noise * noise_w + bias[co] + R * (res_mask > 0) ) * out_gain,
+//   R = res_sub ? res_coef * res_coef_dev[0] * (residual - res_sub) : residual         (include/l2i.h; all operand maps in h8 bf16)
+__device__ __forceinline__ void h8_unpack(const u32x4& u, float (&v)[8]) {
+    v[0] = bf16_lo(u.x); v[1] = bf16_hi(u.x); v[2] = bf16_lo(u.y); v[3] = bf16_hi(u.y);
+    v[4] = bf16_lo(u.z); v[5] = bf16_hi(u.z); v[6] = bf16_lo(u.w); v[7] = bf16_hi(u.w);
+}
+
+struct H8Out {
+    const l2i_conv_params& p;
+    int b, cg_out;                       // sample, 8-channel groups of the output tensor
+    float rc;                            // res_coef * res_coef_dev[0]
+    float sq;                            // running sum (y - sq_ref)^2
+    __device__ __forceinline__ void finish(float (&v)[8], int grp, int oy, int ox, float nz) {
+        // v: eight channels 8 grp .. 8 grp + 7 of pixel (oy, ox) (output-tensor coordinates), raw accumulators
+        const int co0 = grp * 8;
+        const size_t slot = (((size_t)b * cg_out + grp) * p.OHf + oy) * p.OWf + ox;
+        const u32x4* y4 = reinterpret_cast<const u32x4*>(p.y);
+        if (p.out_scale) {
+            const float4 s0 = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Cout + co0), s1 = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Cout + co0 + 4);
+            v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w; v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
+        }
+        if (p.out_mask) {
+            float m[8];
+            h8_unpack(reinterpret_cast<const u32x4*>(p.out_mask)[slot], m);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+        }
+        if (p.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co0), b1 = *reinterpret_cast<const float4*>(p.bias + co0 + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (p.noise) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += nz;
+        }
+        if (p.residual) {
+            float r[8];
+            h8_unpack(reinterpret_cast<const u32x4*>(p.residual)[slot], r);
+            if (p.res_sub) {
+                float s[8];
+                h8_unpack(reinterpret_cast<const u32x4*>(p.res_sub)[slot], s);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = rc * (r[e] - s[e]);
+            }
+            if (p.res_mask) {
+                float m[8];
+                h8_unpack(reinterpret_cast<const u32x4*>(p.res_mask)[slot], m);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = m[e] > 0.f ? r[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (p.act == L2I_ACT_LRELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * p.act_slope) * p.act_gain;
+        } else if (p.act == L2I_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (p.out_gain != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.out_gain;
+        }
+        if (p.accumulate) {
+            float o[8];
+            h8_unpack(y4[slot], o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += o[e];
+        }
+        const u32x4 out = {cvt_pk_bf16_h8(v[0], v[1]), cvt_pk_bf16_h8(v[2], v[3]), cvt_pk_bf16_h8(v[4], v[5]), cvt_pk_bf16_h8(v[6], v[7])};
+        reinterpret_cast<u32x4*>(p.y)[slot] = out;
+        if (p.sq_ref) {                                            // ContentLoss value of a VGG tap on the ROUNDED output (what the next layer reads)
+            float rf[8], w[8];
+            h8_unpack(reinterpret_cast<const u32x4*>(p.sq_ref)[slot], rf);
+            h8_unpack(out, w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = w[e] - rf[e]; sq += d * d; }
+        }
+    }
+};
+
+// one (m, n) accumulator tile -> the two 8-channel groups this lane finishes for quad pair pr: g[0..7]
+__device__ __forceinline__ void h8_gather(const f32x16& a, int pr, int half, float (&g)[8]) {
+    float lo[4], hi[4];                                            // quad 2 pr (group 2 pr) and quad 2 pr + 1 (group 2 pr + 1), own channel quad
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lo[e] = a[8 * pr + e]; hi[e] = a[8 * pr + 4 + e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // lanes 32-63 of lo <-> lanes 0-31 of hi: lower half then holds (own lo | upper's lo) = group 2 pr, upper half (lower's hi | own hi) = group 2 pr + 1
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[e]), __float_as_uint(hi[e]), false, false);
+        lo[e] = __uint_as_float(r[0]); hi[e] = __uint_as_float(r[1]);
+    }
+    // lower half: lo = channels 0-3 (own), hi = channels 4-7 (from the upper half's lo)
+    // upper half: lo = channels 0-3 of group 2 pr + 1 (from the lower half's hi), hi = channels 4-7 (own)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[e] = lo[e]; g[4 + e] = hi[e]; }
+    (void)half;
+}
+
+template <int WM, int WN, int K, int S, int TR, bool OUT32>
+__global__ __launch_bounds__(256, 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
+    using G = g8::Geo<WN, K, S, TR>;
+    constexpr int NACC = TR ? 4 : 1;
+    constexpr int DMIN = (TR == 1) ? -1 : 0;
+    constexpr int BM = WM * 32;
+    constexpr int WSLOTS = K * G::KS * 2 * BM;             // slots per phase: K taps x KS steps x 2 halves x BM channels
+    constexpr int WPIECES = WSLOTS / 64;
+    constexpr int WPW = (WPIECES + 3) / 4;
+    constexpr int IN_STAGE = G::IN_STAGE;
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
+    u32x4* const in_st = smem4;                            // 2 stages x [group][row][slot]
+    u32x4* const w_st = smem4 + 2 * IN_STAGE;              // 2 stages x [tap][step][half][channel]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    // XCD-aware block order: the channel blocks of a pixel tile share an XCD (and its L2)
+    int w = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (w >= L.total) return;
+    const int mblk = __builtin_amdgcn_readfirstlane(w % L.mblocks); w /= L.mblocks;
+    const int tx = __builtin_amdgcn_readfirstlane(w % L.tiles_x); w /= L.tiles_x;
+    const int ty = __builtin_amdgcn_readfirstlane(w % L.tiles_y); w /= L.tiles_y;
+    const int b = __builtin_amdgcn_readfirstlane(w), m0 = mblk * BM, oy0 = ty * G::TH, ox0 = tx * 32;
+    const int iy0 = TR ? oy0 + DMIN : oy0 * S - p.pad_y;
+    const int ix0 = TR ? ox0 + DMIN : ox0 * S - p.pad_x;
+
+    // ---- descriptors (one sample's tensor: 32-bit offsets) ----
+    const unsigned plane_b = (unsigned)((size_t)p.H * p.W * 16);                       // bytes of one 8-channel group
+    const unsigned in_bytes = (unsigned)(p.Cin / 8) * plane_b;
+    const char* xb = reinterpret_cast<const char*>(p.x) + (size_t)b * in_bytes;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, in_bytes, 0x00020000);
+    const unsigned wpl_bytes = (unsigned)((size_t)(p.Cin / 16) * K * K * 2 * p.CoutP * 16);
+    const char* wb = reinterpret_cast<const char*>(p.w_hi) + (size_t)b * (size_t)p.w_bstride;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, wpl_bytes, 0x00020000);
+
+    // ---- tile DMA: piece q = wave + 4 t covers LDS slots [64 q, 64 q + 64) of the stage; slot -> (group, row, column) ----
+    unsigned ivoff[G::NPW];
+#pragma unroll
+    for (int t = 0; t < G::NPW; ++t) {
+        const int sl = (wave + 4 * t) * 64 + lane;
+        ivoff[t] = in_bytes;                                                           // out of range: the DMA writes zeros (= the padding)
+        if (sl < G::IN_SLOTS) {
+            const int nh = sl / G::HSTRIDE, r2 = sl - nh * G::HSTRIDE;
+            const int row = r2 / G::RP, rc = r2 - row * G::RP;
+            const int col = G::SPLIT ? (rc < G::RPH ? 2 * rc : 2 * (rc - G::RPH) + 1) : rc * G::CSTEP;
+            const int gy = iy0 + row * G::RSTEP, gx = ix0 + col;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ivoff[t] = (unsigned)nh * plane_b + (unsigned)(gy * p.W + gx) * 16u;
+        }
+    }
+    auto dma_in = [&](int chunk, int stage) {
+        const unsigned soff = (unsigned)chunk * G::NH * plane_b;
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(in_st + stage * IN_STAGE);
+#pragma unroll
+        for (int t = 0; t < G::NPW; ++t) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(ivoff[t]), "s"(rs_x), "s"(__builtin_amdgcn_readfirstlane(lds0 + (wave_u + 4 * t) * 1024)), "s"(soff)
+                         : "memory");
+        }
+    };
+    // ---- weight DMA: piece q covers slots [64 q, 64 q + 64) of the phase ([tap][step][half][channel]) ----
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int t = 0; t < WPW; ++t) {
+        const int sl = ((wave + 4 * t) * 64 + lane) % WSLOTS;
+        const int r = sl / BM, i = sl - r * BM;                            // r = (tap * KS + step) * 2 + half
+        const int hf = r & 1, st = (r >> 1) % G::KS, tap = (r >> 1) / G::KS;
+        wvoff[t] = (unsigned)((((st * K * K + tap) * 2 + hf) * p.CoutP + m0 + i) * 16);
+    }
+    auto dma_w = [&](int chunk, int ky, int stage) {
+        const unsigned soff = (unsigned)((((size_t)chunk * G::KS * K * K + ky * K) * 2) * p.CoutP * 16);
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(w_st + stage * WSLOTS);
+#pragma unroll
+        for (int t = 0; t < WPW; ++t) {
+            const int q = wave_u + 4 * t;                  // wave-uniform: a scalar branch
+            if (q < WPIECES) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(wvoff[t]), "s"(rs_w), "s"(__builtin_amdgcn_readfirstlane(lds0 + q * 1024)), "s"(soff)
+                             : "memory");
+            }
+        }
+    };
+
+    f32x16 acc[NACC][WM][WN];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
+
+    // fragment bases (slots): lane (half, j) + compile-time / wave-uniform offsets
+    constexpr int rstep_out = G::GATHER ? 1 : S;           // staged rows between consecutive output rows
+    const int bbase = half * G::HSTRIDE + wave * WN * rstep_out * G::RP + j;
+    const int abase = half * BM + j;
+
+    auto mfma_phase = [&](int in_stage, int w_stage, auto ky_t) {
+        constexpr int ky = decltype(ky_t)::value;
+        constexpr int PADT = (TR == 2) ? 1 : 0;
+        constexpr int py = (ky + PADT) & 1;
+        constexpr int rowoff = TR ? (py + PADT - ky) / 2 - DMIN : (G::GATHER ? 0 : ky);
+        const u32x4* ih = in_st + in_stage * IN_STAGE + bbase + rowoff * G::RP;
+        const u32x4* wh = w_st + w_stage * WSLOTS + abase;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            // transposed: tap kx feeds output parity px = (kx + pad) & 1 from input column s + dx, dx = (px + pad - kx) / 2; staged column dx - DMIN
+            const int c = TR ? (((kx + PADT) & 1) + PADT - kx) / 2 - DMIN : kx;
+            const int coloff = G::GATHER ? 0 : (G::SPLIT ? (c & 1) * G::RPH + (c >> 1) : c);
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                bf16x8 af[WM], bf[WN];
+#pragma unroll
+                for (int m = 0; m < WM; ++m) af[m] = __builtin_bit_cast(bf16x8, wh[((kx * G::KS + ks) * 2) * BM + m * 32]);
+#pragma unroll
+                for (int n = 0; n < WN; ++n) bf[n] = __builtin_bit_cast(bf16x8, ih[ks * 2 * G::HSTRIDE + n * rstep_out * G::RP + coloff]);
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        acc[TR ? py * 2 + ((kx + PADT) & 1) : 0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[TR ? py * 2 + ((kx + PADT) & 1) : 0][m][n], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- pipeline ----
+    const int nphases = L.nchunks * K;
+    dma_w(0, 0, 0);
+    dma_in(0, 0);
+    auto phase_head = [&](int ch, int ky, bool more) {
+        const int ph = ch * K + ky;
+        // this phase's weights (and, first phase of a chunk, the chunk's tile) have landed; the next chunk's tile, issued AFTER the
+        // weights of phase (ch, 1), stays in flight across that phase's barrier
+        if (K > 1 && ky == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ph + 1 < nphases) dma_w(ky + 1 < K ? ch : ch + 1, ky + 1 < K ? ky + 1 : 0, (ph + 1) & 1);
+        if (ky == 0 && more) dma_in(ch + 1, (ch + 1) & 1);
+    };
+    for (int ch = 0; ch < L.nchunks; ++ch) {
+        const bool more = ch + 1 < L.nchunks;
+        using K0 = std::integral_constant<int, 0>;
+        using K1 = std::integral_constant<int, 1>;
+        using K2 = std::integral_constant<int, 2>;
+        phase_head(ch, 0, more);
+        mfma_phase(ch & 1, (ch * K) & 1, K0());
+        if constexpr (K == 3) {
+            phase_head(ch, 1, more);
+            mfma_phase(ch & 1, (ch * K + 1) & 1, K1());
+            phase_head(ch, 2, more);
+            mfma_phase(ch & 1, (ch * K + 2) & 1, K2());
+        }
+    }
+
+    if constexpr (OUT32) {
+        static_assert(!OUT32 || TR == 0, "fp32 NCHW output: correlations only");
+        __syncthreads();                                   // the stages become the epilogue's transpose strips
+        l2i_epilogue_32x32<WM, WN>(p, acc[0], reinterpret_cast<float*>(smem4), b, m0, oy0, ox0, L.vec_epi != 0);
+    } else {
+        H8Out o{p, b, p.Cout / 8, p.res_sub ? p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) : 1.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int t = oy0 + wave * WN + n, sx = ox0 + j;
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+                const int oy = TR ? 2 * t + (a >> 1) : t + p.oy_off, ox = TR ? 2 * sx + (a & 1) : sx + p.ox_off;
+                const bool pok = TR ? (oy < p.OHf && ox < p.OWf) : (t < p.OH && sx < p.OW);
+                float nz = 0.f;
+                if (pok && p.noise) nz = p.noise[((size_t)b * p.OHf + oy) * p.OWf + ox] * p.noise_w;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) {
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        float g[8];
+                        h8_gather(acc[a][m][n], pr, half, g);
+                        const int grp = (m0 >> 3) + 4 * m + 2 * pr + half;
+                        if (pok && grp * 8 < p.Cout) o.finish(g, grp, oy, ox, nz);
+                    }
+                }
+            }
+        }
+        if (p.sq_ref) {                                            // one atomic per block into L2I_SQ_SLOTS slots
+            float sq = o.sq;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem4);
+            if (lane == 0) red[wave] = sq;
+            __syncthreads();
+            if (tid == 0) atomicAdd(p.sq_out + (blockIdx.x & (L2I_SQ_SLOTS - 1)), (red[0] + red[1]) + (red[2] + red[3]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int K, int S, int TR, bool OUT32>
+static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
+    using G = g8::Geo<WN, K, S, TR>;
+    constexpr int BM = WM * 32;
+    constexpr int WSLOTS = K * G::KS * 2 * BM;
+    H8Launch L;
+    L.tiles_x = (p.OW + 31) / 32;
+    L.tiles_y = (p.OH + G::TH - 1) / G::TH;
+    L.mblocks = (p.CoutP + BM - 1) / BM;
+    const long total = (long)p.B * L.tiles_y * L.tiles_x * L.mblocks;
+    if (total <= 0 || total > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv2d_h8: grid too large");
+    L.total = (int)total;
+    L.nchunks = p.Cin / G::CK;
+    L.vec_epi = (OUT32 && l2i_epilogue_vec_ok(p)) ? 1 : 0;
+    size_t lds = (size_t)(2 * G::IN_STAGE + 2 * WSLOTS) * 16;
+    if (OUT32 && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
+    if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: tile does not fit the LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h8_kernel<WM, WN, K, S, TR, OUT32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)((total + 7) & ~7L);
+    hipLaunchKernelGGL((conv_h8_kernel<WM, WN, K, S, TR, OUT32>), dim3(grid), dim3(256), lds, st, p, L);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+static int h8_common_checks(const l2i_conv_params& p, const char* who) {
+    if (!p.x || !p.w_hi || !p.y) return l2i_set_error(L2I_E_ARG, "conv h8: null tensor");
+    if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0) return l2i_set_error(L2I_E_ARG, "conv h8: non-positive dimension");
+    if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv h8: CoutP must be Cout rounded up to 32");
+    if (p.in_scale || p.in_mask) return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: no prologue fusions (scales live in the weights, masks in the producing epilogue)");
+    if ((p.Cin % 32) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: Cin must be a multiple of 32");
+    auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
+    if (!al16(p.x) || !al16(p.w_hi) || !al16(p.y) || !al16(p.residual) || !al16(p.res_mask) || !al16(p.res_sub) || !al16(p.out_mask) || !al16(p.sq_ref) ||
+        !al16(p.bias) || !al16(p.out_scale) || (p.w_bstride % 16) != 0)
+        return l2i_set_error(L2I_E_ARG, "conv h8: tensors must be 16-byte aligned");
+    if ((size_t)(p.Cin / 8) * p.H * p.W * 16 >= 0xFFFFFFF0ull || (size_t)(p.Cin / 16) * p.KH * p.KW * 2 * p.CoutP * 16 >= 0xFFFFFFF0ull)
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: one sample / the weight planes must stay below 4 GiB (32-bit buffer offsets)");
+    if (p.res_sub && !p.residual) return l2i_set_error(L2I_E_ARG, "conv h8: res_sub needs residual");
+    if ((p.sq_ref != nullptr) != (p.sq_out != nullptr)) return l2i_set_error(L2I_E_ARG, "conv h8: sq_ref and sq_out go together");
+    (void)who;
+    return L2I_OK;
+}
+
+extern "C" int l2i_conv2d_h8(const l2i_conv_params* pp, void* stream) {
+    if (!pp) return l2i_set_error(L2I_E_ARG, "conv2d_h8: null params");
+    const l2i_conv_params& p = *pp;
+    if (int rc = h8_common_checks(p, "conv2d_h8")) return rc;
+    const bool k1 = (p.KH == 1 && p.KW == 1 && p.pad_y == 0 && p.pad_x == 0);
+    const bool k3 = (p.KH == 3 && p.KW == 3 && p.pad_y == p.pad_x && p.pad_x >= 0 && p.pad_x <= 1);
+    if (!(k1 || k3) || (p.stride != 1 && p.stride != 2) || p.oy_step != 1 || p.ox_step != 1)
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: 1x1 (pad 0) or 3x3 (pad 0 / 1) layers, stride 1 or 2, dense output window");
+    if (p.oy_off < 0 || p.ox_off < 0 || p.OH + p.oy_off > p.OHf || p.OW + p.ox_off > p.OWf) return l2i_set_error(L2I_E_ARG, "conv2d_h8: output window exceeds the output tensor");
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = (p.CoutP % 64) == 0;
+    if (p.out_f32) {                                       // fp32 NCHW output (gradients landing on images, the last layer in front of an fp32 consumer)
+        if (p.sq_ref) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: sq_ref needs the h8 output");
+        if (p.KH == 3 && p.stride == 1) return wide ? launch_h8<2, 2, 3, 1, 0, true>(p, st) : launch_h8<1, 2, 3, 1, 0, true>(p, st);
+        if (p.KH == 1 && p.stride == 1) return wide ? launch_h8<2, 2, 1, 1, 0, true>(p, st) : launch_h8<1, 2, 1, 1, 0, true>(p, st);
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: fp32 output is built for stride-1 layers");
+    }
+    if ((p.Cout % 8) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: h8 output needs Cout % 8 == 0");
+    if (p.KH == 3 && p.stride == 1) return wide ? launch_h8<2, 2, 3, 1, 0, false>(p, st) : launch_h8<1, 2, 3, 1, 0, false>(p, st);
+    if (p.KH == 1 && p.stride == 1) return wide ? launch_h8<2, 2, 1, 1, 0, false>(p, st) : launch_h8<1, 2, 1, 1, 0, false>(p, st);
+    if (p.KH == 3 && p.stride == 2) return wide ? launch_h8<2, 1, 3, 2, 0, false>(p, st) : launch_h8<1, 1, 3, 2, 0, false>(p, st);
+    return wide ? launch_h8<2, 2, 1, 2, 0, false>(p, st) : launch_h8<1, 2, 1, 2, 0, false>(p, st);
+}
+
+extern "C" int l2i_conv_transpose2d_h8(const l2i_conv_params* pp, void* stream) {
+    if (!pp) return l2i_set_error(L2I_E_ARG, "conv_transpose2d_h8: null params");
+    const l2i_conv_params& p = *pp;
+    if (int rc = h8_common_checks(p, "conv_transpose2d_h8")) return rc;
+    const int nat = (p.H - 1) * 2 - 2 * p.pad_y + 3, natw = (p.W - 1) * 2 - 2 * p.pad_x + 3;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 2 || p.pad_y != p.pad_x || p.pad_x < 0 || p.pad_x > 1 || p.OHf < nat || p.OHf > nat + 8 || p.OWf < natw || p.OWf > natw + 8 ||
+        p.OH != (p.OHf + 1) / 2 || p.OW != (p.OWf + 1) / 2 || p.out_f32 || (p.Cout % 8) != 0 || p.sq_ref)
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d_h8: 3x3 stride-2 layer (pad 0 or 1), natural output size (or up to 8 larger), h8 output");
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = (p.CoutP % 64) == 0;
+    if (p.pad_x == 0) return wide ? launch_h8<2, 1, 3, 1, 1, false>(p, st) : launch_h8<1, 2, 3, 1, 1, false>(p, st);
+    return wide ? launch_h8<2, 1, 3, 1, 2, false>(p, st) : launch_h8<1, 2, 3, 1, 2, false>(p, st);
+}

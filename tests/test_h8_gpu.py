@@ -1,0 +1,99 @@
+"""The 16-bit path (BASELINE config 5): kernels on bf16 tensors in the channel-blocked h8 layout [B, C/8, H, W, 8] (include/l2i.h), through the
+C ABI, against float64 torch on the SAME bf16-rounded operands.  Tolerances: the products and the fp32 accumulation are exact to fp32 rounding,
+the only 16-bit rounding is the output's (relative 2^-9), so outputs are held to 2^-8 of their magnitude plus a small absolute term."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from latent2im_amd import _lib, conv
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).float()
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+def close16(got, want, what=''):
+    got, want = got.double().cpu(), want.double().cpu()
+    tol = 2.0 ** -8 * want.abs() + 2e-3 * float(want.abs().max())
+    bad = (got - want).abs() > tol
+    assert not bool(bad.any()), (what, int(bad.sum()), float((got - want).abs().max()), float(want.abs().max()))
+
+
+H8_CASES = [  # cin, cout, k, stride, pad, transposed, h, w, batch
+    (32, 32, 3, 1, 1, False, 16, 32, 1), (64, 64, 3, 1, 1, False, 37, 45, 2), (32, 40, 3, 1, 1, False, 9, 70, 1), (128, 96, 1, 1, 0, False, 33, 40, 2),
+    (64, 128, 3, 2, 1, False, 33, 31, 2), (32, 64, 3, 2, 0, False, 68, 68, 1), (64, 64, 1, 2, 0, False, 40, 36, 2), (256, 512, 1, 2, 0, False, 16, 16, 1),
+    (64, 32, 3, 2, 0, True, 32, 32, 2), (32, 64, 3, 2, 0, True, 17, 40, 1), (64, 64, 3, 2, 1, True, 20, 33, 1), (512, 512, 3, 1, 1, False, 8, 8, 2),
+]
+
+
+@pytest.mark.parametrize('case', H8_CASES)
+def test_conv_h8_forward_and_dgrad(case):
+    cin, cout, k, stride, pad, tr, h, w, b = case
+    rs = np.random.RandomState(cin + 3 * cout + k + stride + h)
+    wt = T(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    x = T(rs.randn(b, cin, h, w))
+    xr = bf(x).requires_grad_(True)
+    wr = bf(wt)
+    ref = F.conv_transpose2d(xr, wr.transpose(0, 1), stride=2, padding=pad) if tr else F.conv2d(xr, wr, stride=stride, padding=pad)
+    hc = conv.H8Conv(wt, stride, pad, transposed=tr, device=DEV)
+    y = hc.forward(conv.to_h8(x.to(DEV), 32))
+    torch.cuda.synchronize()
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (b, (cout + 7) // 8, ref.shape[2], ref.shape[3], 8)
+    close16(conv.from_h8(y, cout), ref.detach(), 'forward')
+    if cout % 32 == 0 and not (k == 1 and stride == 2):       # the gradient's input tensor carries the conv's Cout channels: whole 32-channel chunks
+                                                              # (a strided 1x1's gradient is a compact 1x1 conv + zero insertion: regressor16)
+        gy = T(rs.randn(*ref.shape))
+        gref, = torch.autograd.grad(ref, xr, bf(gy))
+        gx = hc.dgrad(conv.to_h8(gy.to(DEV), 32), (h, w))
+        close16(conv.from_h8(gx, cin), gref, 'dgrad')
+
+
+def test_conv_h8_epilogue_fusions_and_fp32_output():
+    rs = np.random.RandomState(5)
+    b, cin, cout, h, w = 2, 64, 64, 24, 40
+    wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    x, d, bias = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cout) + 0.5), T(rs.randn(cout))
+    nz, res, rmk, omk, rsub = T(rs.randn(b, 1, h, w)), T(rs.randn(b, cout, h, w)), T(rs.randn(b, cout, h, w)), T(rs.randn(b, cout, h, w)), T(rs.randn(b, cout, h, w))
+    g = lambda t: t.to(DEV)
+    H = lambda t: conv.to_h8(g(t), 32)
+    hc = conv.H8Conv(wt, 1, 1, device=DEV)
+    c64 = F.conv2d(bf(x), bf(wt), padding=1)
+    # modulated-conv epilogue: demod scale, noise, bias, leaky ReLU * sqrt(2)
+    y1 = hc.forward(H(x), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    ref1 = F.leaky_relu(c64 * d.double()[:, :, None, None] + nz.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 2 ** 0.5
+    close16(conv.from_h8(y1, cout), ref1, 'modconv epilogue')
+    # ResNet-style: bias + masked residual + ReLU
+    y2 = hc.forward(H(x), bias=g(bias), residual=H(res), res_mask=H(rmk), act=conv.ACT_RELU)
+    ref2 = torch.relu(c64 + bias.double()[None, :, None, None] + torch.where(bf(rmk) > 0, bf(res), torch.zeros_like(bf(res))))
+    close16(conv.from_h8(y2, cout), ref2, 'residual epilogue')
+    # gradient conv: output mask, ContentLoss direct term res_coef * coef_dev * (residual - res_sub), gain
+    cdev = torch.full((1,), 0.7, device=DEV)
+    y3 = hc.forward(H(x), out_mask=H(omk), residual=H(res), res_sub=H(rsub), res_coef=0.25, res_coef_dev=cdev, out_gain=0.5)
+    ref3 = (torch.where(bf(omk) > 0, c64, torch.zeros_like(c64)) + 0.25 * 0.7 * (bf(res) - bf(rsub))) * 0.5
+    close16(conv.from_h8(y3, cout), ref3, 'gradient epilogue')
+    # ContentLoss value in the epilogue: sum (y - ref)^2 on the rounded output
+    sq_acc, fused = torch.zeros(_lib.SQ_SLOTS, device=DEV), [False]
+    y4 = hc.forward(H(x), bias=g(bias), sq=(H(res), sq_acc, fused))
+    want = float(((conv.from_h8(y4, cout).double().cpu() - bf(res)) ** 2).sum())
+    assert fused[0] and abs(float(sq_acc.double().sum()) - want) <= 1e-4 * want
+    # fp32 NCHW output onto 3 channels (a gradient landing on an image) and its fused terms
+    w3 = T(rs.randn(3, cin, 3, 3) / np.sqrt(cin * 9))
+    h3 = conv.H8Conv(w3, 1, 1, device=DEV)
+    y5 = h3.forward(H(x), out_f32=True, out_gain=2.0)
+    assert y5.dtype == torch.float32 and tuple(y5.shape) == (b, 3, h, w)
+    ref5 = F.conv2d(bf(x), bf(w3), padding=1) * 2.0
+    assert float((y5.double().cpu() - ref5).abs().max()) < 1e-4 * float(ref5.abs().max())           # fp32 output: no 16-bit rounding at all
+    # per-sample weight planes (the generator's modulated convs): sample i uses plane set i
+    s = T(rs.rand(b, cin) + 0.5)
+    planes = torch.stack([conv.pack_weight_h8(wt * s[i][None, :, None, None]) for i in range(b)]).to(DEV)
+    y6 = hc.forward(H(x), planes=planes, w_bstride=planes[0].numel() * 2)
+    ref6 = torch.stack([F.conv2d(bf(x[i:i + 1]), bf(wt * s[i][None, :, None, None]), padding=1)[0] for i in range(b)])
+    close16(conv.from_h8(y6, cout), ref6, 'per-sample weights')
