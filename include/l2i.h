@@ -151,6 +151,30 @@ int l2i_conv2d_wino_f32(const l2i_conv_params* p, void* stream);
 int l2i_conv2d_h8(const l2i_conv_params* p, void* stream);
 int l2i_conv_transpose2d_h8(const l2i_conv_params* p, void* stream);
 
+/* Streaming companions on h8 maps (csrc/l2i_stream_h8.hip; same functions as the fp32 entry points below, arithmetic in fp32 registers):
+ * layout casts fp32 NCHW <-> bf16 h8 (Cpad = channel count of the h8 tensor, a multiple of 8, zero filled above C);
+ * the reference's upfirdn2d on h8 planes (kernels up to 4x4, up / down in {1, 2}) with the generator's fused epilogue
+ *   y = act(fir(x) + noise[b,oy,ox] * noise_w + bias[c]) * act_gain;
+ * ToRGB (x h8 -> rgb fp32 [B,3,HW]); the fused activation backward of a styled conv (dz h8; gin h8; grgb fp32; reductions fp32, zeroed by the caller);
+ * out[b,c] += sum_p a * b; MaxPool2d forward (idx: [planes][OH][OW][8] bytes; relu = 1: y = max(pool, 0)) and backward (optionally + coef *
+ *   coef_dev[0] * (b - a): the ContentLoss term of the pooled tap); the ContentLoss difference; y[2oy, 2ox] += c[oy, ox]; and the per-sample
+ *   weight planes of a modulated conv: planes[b] = bf16(w32 * s[b, input channel]) with w32 = the fp32 weights in plane order. */
+int l2i_cast_f32_to_h8(void* y, const float* x, int B, int C, int Cpad, int64_t HW, void* stream);
+int l2i_cast_h8_to_f32(float* y, const void* x, int B, int C, int Cpad, int64_t HW, void* stream);
+int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
+                     int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
+                     float act_gain, void* stream);
+int l2i_torgb_fwd_h8(float* rgb, const void* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream);
+int l2i_sg2_act_bwd_h8(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
+                       const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream);
+int l2i_dot_reduce_h8(float* out, const void* a, const void* b, int B, int C, int64_t HW, void* stream);
+int l2i_maxpool2d_fwd_h8(void* y, void* idx, const void* x, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, int relu, void* stream);
+int l2i_maxpool2d_bwd_h8(void* gx, const void* gy, const void* idx, const void* a, const void* b, float coef, const float* coef_dev, int64_t planes, int H, int W,
+                         int k, int s, int pad, int OH, int OW, void* stream);
+int l2i_sqdiff_h8(float* sum_out, void* grad, const void* a, const void* b, int64_t slots, float coef, const float* coef_dev, void* stream);
+int l2i_add_zero_insert_h8(void* y, const void* c, int64_t planes, int H, int W, int OH, int OW, void* stream);
+int l2i_modulate_planes_h8(void* planes, const float* w32, const float* s, int B, int Cs, int CinP, int KK, int CoutP, void* stream);
+
 /* out[i] = act_grad_table(x[i] + b[(i / step_b) % size_b], ref[i]) * scale   — the reference op, all six
  * act*10+grad cases (fused_bias_act_kernel.cu:36-47).  b / ref may be NULL (= the reference's empty tensors). */
 int l2i_fused_bias_act_f32(float* y, const float* x, const float* b, const float* ref, int64_t n,

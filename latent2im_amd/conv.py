@@ -504,6 +504,17 @@ def from_h8(t, channels=None):
     return x if channels is None else x[:, :channels].contiguous()
 
 
+def pack_weight_h8_f32(w):
+    """[Cout, Cin, KH, KW] fp32 -> fp32 in the plane order [Cin/16][KH*KW][2][CoutP][8] (Cin zero-padded to a multiple of 32): the source of
+    the per-sample modulated planes (l2i_modulate_planes_h8)."""
+    w = torch.as_tensor(w, dtype=torch.float32)
+    cout, cin, kh, kw = w.shape
+    cinp, coutp = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+    full = torch.zeros(coutp, cinp, kh, kw, dtype=torch.float32, device=w.device)
+    full[:cout, :cin] = w
+    return full.reshape(coutp, cinp // 16, 2, 8, kh * kw).permute(1, 4, 2, 0, 3).contiguous()
+
+
 def pack_weight_h8(w):
     """[Cout, Cin, KH, KW] fp32 -> bf16 plane [Cin/16][KH*KW][2][CoutP][8] (int16 view): the LDS image order of csrc/l2i_conv_h8.hip.
     Cin is zero-padded to a multiple of 32 (the kernel's K chunk)."""

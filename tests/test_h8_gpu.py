@@ -97,3 +97,116 @@ def test_conv_h8_epilogue_fusions_and_fp32_output():
     y6 = hc.forward(H(x), planes=planes, w_bstride=planes[0].numel() * 2)
     ref6 = torch.stack([F.conv2d(bf(x[i:i + 1]), bf(wt * s[i][None, :, None, None]), padding=1)[0] for i in range(b)])
     close16(conv.from_h8(y6, cout), ref6, 'per-sample weights')
+
+
+# ---- streaming companions (csrc/l2i_stream_h8.hip) against torch on the bf16-rounded operands ---------------------------------------------------
+def rb(x):
+    """what an h8 tensor holds of x."""
+    return x.to(torch.bfloat16).float()
+
+
+def test_h8_layout_casts():
+    from latent2im_amd import kernels16 as K16
+    rs = np.random.RandomState(0)
+    for B, C, H, W, cpad in ((2, 3, 9, 11, 32), (1, 40, 5, 70, 40), (2, 64, 16, 16, 64)):
+        x = T(rs.randn(B, C, H, W)).to(DEV)
+        t = K16.cast_to_h8(x, cpad)
+        assert torch.equal(t, conv.to_h8(x, cpad))                                     # == the torch reshuffle (round to nearest even)
+        assert torch.equal(K16.cast_from_h8(t, C), rb(x))
+
+
+def test_h8_upfirdn2d_all_path_geometries():
+    from latent2im_amd import kernels16 as K16
+    from oracle import sg2
+    rs = np.random.RandomState(1)
+    k1 = np.asarray([1.0, 3.0, 3.0, 1.0])
+    k = T(np.outer(k1, k1) / 64.0)
+    for (B, C, H, W), up, down, pad in (((2, 16, 33, 33), 1, 1, (1, 1)),           # generator up-layer blur on the (2H+1)^2 map
+                                        ((1, 8, 36, 36), 1, 1, (1, -2)),            # ... produced (2H+4)^2, cropped by the negative far pad
+                                        ((2, 8, 16, 16), 1, 1, (2, 2)),             # discriminator blur in front of a stride-2 3x3 conv
+                                        ((1, 16, 20, 20), 1, 2, (1, 1)),            # discriminator skip: blur + every second pixel
+                                        ((1, 8, 10, 10), 2, 1, (2, 1)),             # its adjoint family: zero insertion
+                                        ((1, 8, 17, 17), 1, 1, (2, 5))):            # generator backward: the blur gradient padded to (2H+4)^2
+        x = T(rs.randn(B, C, H, W))
+        kk = k * (up * up)
+        y = K16.upfirdn2d(conv.to_h8(x.to(DEV)), kk.to(DEV), up=up, down=down, pad=(pad[0], pad[1], pad[0], pad[1]))
+        ref = sg2.upfirdn2d(rb(x).double(), kk.double(), up=up, down=down, pad=pad)
+        close16(conv.from_h8(y, C), ref, 'upfirdn %s' % (pad,))
+    # fused epilogue of the generator's up layers: noise, bias, leaky ReLU * sqrt(2)
+    x, nz, bias = T(rs.randn(2, 16, 33, 33)), T(rs.randn(2, 1, 32, 32)), T(rs.randn(16))
+    kk = k * 4
+    y = K16.upfirdn2d(conv.to_h8(x.to(DEV)), kk.to(DEV), pad=(1, 1, 1, 1), noise=nz.to(DEV), noise_w=0.3, bias=bias.to(DEV), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    ref = F.leaky_relu(sg2.upfirdn2d(rb(x).double(), kk.double(), pad=(1, 1)) + 0.3 * nz.double() + bias.double()[None, :, None, None], 0.2) * 2 ** 0.5
+    close16(conv.from_h8(y, 16), ref, 'upfirdn epilogue')
+
+
+def test_h8_torgb_act_bwd_reductions_sqdiff():
+    from latent2im_amd import kernels16 as K16
+    rs = np.random.RandomState(2)
+    B, C, H = 2, 24, 20
+    x, wm, bias = T(rs.randn(B, C, H, H)), T(rs.randn(B, 3, C)), T(rs.randn(3))
+    g = lambda t: t.to(DEV)
+    H8 = lambda t: conv.to_h8(g(t))
+    rgb = K16.torgb_fwd(H8(x), g(wm), g(bias))
+    ref = torch.einsum('bchw,boc->bohw', rb(x).double(), wm.double()) + bias.double()[None, :, None, None]
+    assert float((rgb.double().cpu() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    y, gin, gs, grgb = T(rs.randn(B, C, H, H)), T(rs.randn(B, C, H, H)), T(rs.rand(B, C) + 0.5), T(rs.randn(B, 3, H, H))
+    cb, nz = T(rs.randn(C)), T(rs.randn(B, 1, H, H))
+    red, red_rgb = torch.zeros(B, C, device=DEV), torch.zeros(B, C, 3, device=DEV)
+    dz = K16.sg2_act_bwd(H8(y), H8(gin), g(gs), g(grgb), g(wm), g(cb), g(nz), 0.3, 0.2, 2 ** 0.5, red, red_rgb)
+    yb, gb = rb(y).double(), rb(gin).double()
+    gg = gb * gs.double()[:, :, None, None] + torch.einsum('bohw,boc->bchw', grgb.double(), wm.double())
+    dz_ref = gg * torch.where(yb > 0, torch.tensor(2 ** 0.5, dtype=torch.float64), torch.tensor(0.2 * 2 ** 0.5, dtype=torch.float64))
+    zpre = torch.where(yb > 0, yb / 2 ** 0.5, yb / (0.2 * 2 ** 0.5)) - cb.double()[None, :, None, None] - 0.3 * nz.double()
+    close16(conv.from_h8(dz, C), dz_ref, 'dz')
+    assert float((red.double().cpu() - (dz_ref * zpre).sum((2, 3))).abs().max()) < 1e-4 * float((dz_ref * zpre).abs().sum((2, 3)).max())
+    want = torch.einsum('bchw,bohw->bco', yb, grgb.double())
+    assert float((red_rgb.double().cpu() - want).abs().max()) < 1e-4 * float(torch.einsum('bchw,bohw->bco', yb.abs(), grgb.double().abs()).max())
+    # without the ToRGB branch / without an incoming gradient
+    red2 = torch.zeros(B, C, device=DEV)
+    dz2 = K16.sg2_act_bwd(H8(y), H8(gin), g(gs), None, None, g(cb), None, 0.0, 0.2, 2 ** 0.5, red2, None)
+    close16(conv.from_h8(dz2, C), gb * gs.double()[:, :, None, None] * torch.where(yb > 0, 2 ** 0.5, 0.2 * 2 ** 0.5), 'dz without rgb')
+    d = K16.dot_reduce(H8(x), H8(y))
+    want = (rb(x).double() * yb).sum((2, 3))
+    assert float((d.double().cpu() - want).abs().max()) < 1e-4 * float((rb(x).double() * yb).abs().sum((2, 3)).max())
+    s, gr = K16.sqdiff(H8(x), H8(y), coef=0.25, want_grad=True)
+    assert abs(float(s) - float(((yb - rb(x).double()) ** 2).sum())) < 1e-4 * float(s)
+    close16(conv.from_h8(gr, C), 0.25 * (yb - rb(x).double()), 'sqdiff grad')
+
+
+@pytest.mark.parametrize('k,s,pad,h,w', [(3, 2, 1, 16, 16), (2, 2, 0, 16, 24), (3, 2, 1, 15, 21), (2, 2, 0, 40, 8), (3, 2, 1, 9, 72)])
+def test_h8_maxpool_forward_backward(k, s, pad, h, w):
+    from latent2im_amd import kernels16 as K16
+    rs = np.random.RandomState(k + h)
+    x = T(np.round(rs.randn(2, 16, h, w) * 4) / 4)                   # coarse values: ties inside windows
+    xr = rb(x).double().requires_grad_(True)
+    ref = F.max_pool2d(xr, k, s, pad)
+    y, idx = K16.maxpool2d_fwd(conv.to_h8(x.to(DEV)), k, s, pad)
+    assert torch.equal(conv.from_h8(y, 16).cpu().double(), ref.detach())
+    gy = T(rs.randn(*ref.shape))
+    gref, = torch.autograd.grad(ref, xr, rb(gy).double())
+    gx = K16.maxpool2d_bwd(conv.to_h8(gy.to(DEV)), idx, (h, w), k, s, pad)
+    close16(conv.from_h8(gx, 16), gref, 'pool backward')               # first maximum in row-major order, like ATen
+    yr, _ = K16.maxpool2d_fwd(conv.to_h8(x.to(DEV)), k, s, pad, relu=True)
+    assert torch.equal(conv.from_h8(yr, 16).cpu().double(), torch.relu(ref.detach()))
+    if k == 2:                                                          # fused ContentLoss term of the pooled tap
+        a, b = T(rs.randn(2, 16, h, w)), T(rs.randn(2, 16, h, w))
+        cd = torch.full((1,), 0.5, device=DEV)
+        gx2 = K16.maxpool2d_bwd(conv.to_h8(gy.to(DEV)), idx, (h, w), k, s, pad, a=conv.to_h8(a.to(DEV)), b=conv.to_h8(b.to(DEV)), coef=0.3, coef_dev=cd)
+        close16(conv.from_h8(gx2, 16), gref + 0.15 * (rb(b).double() - rb(a).double()), 'pool backward + diff')
+
+
+def test_h8_zero_insert_and_modulated_planes():
+    from latent2im_amd import kernels16 as K16
+    rs = np.random.RandomState(4)
+    y, c = T(rs.randn(2, 16, 10, 14)), T(rs.randn(2, 16, 5, 7))
+    yh = conv.to_h8(y.to(DEV))
+    K16.add_zero_insert(yh, conv.to_h8(c.to(DEV)))
+    want = rb(y).double()
+    want[:, :, ::2, ::2] += rb(c).double()
+    close16(conv.from_h8(yh, 16), want, 'zero insert')
+    w = T(rs.randn(40, 64, 3, 3))
+    s = T(rs.rand(3, 64) + 0.5)
+    planes = K16.modulate_planes(conv.pack_weight_h8_f32(w).to(DEV), s.to(DEV))
+    for i in range(3):
+        assert torch.equal(planes[i].cpu(), conv.pack_weight_h8(w * s[i][None, :, None, None]))

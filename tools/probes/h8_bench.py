@@ -1,0 +1,36 @@
+"""l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the step's conv shapes (batch 8): ms, TFLOP/s of the dense correlation, GB/s of the algorithmic bytes."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+from latent2im_amd import conv
+b = 8
+CASES = [(64, 64, 3, 1, 1, False, 1024), (128, 128, 3, 1, 1, False, 512), (64, 128, 3, 1, 1, False, 512), (32, 32, 3, 1, 1, False, 1024), (256, 256, 3, 1, 1, False, 128),
+         (512, 512, 3, 1, 1, False, 64), (512, 512, 3, 1, 1, False, 32), (256, 1024, 1, 1, 0, False, 64), (1024, 256, 1, 1, 0, False, 64), (64, 256, 1, 1, 0, False, 256),
+         (512, 2048, 1, 1, 0, False, 32), (32, 64, 3, 2, 0, False, 1028), (256, 512, 3, 2, 0, False, 132), (128, 128, 3, 2, 1, False, 256), (256, 512, 1, 2, 0, False, 256),
+         (64, 32, 3, 2, 0, True, 512), (512, 256, 3, 2, 0, True, 64), (128, 64, 3, 2, 0, True, 256)]
+for cin, cout, k, s, pad, tr, res in CASES:
+    w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    hc = conv.H8Conv(w, s, pad, transposed=tr, device='cuda')
+    x = torch.randn(b, cin // 8, res, res, 8, device='cuda').to(torch.bfloat16)
+    oh, ow = hc.out_hw(res, res)
+    y = torch.empty(b, cout // 8, oh, ow, 8, device='cuda', dtype=torch.bfloat16)
+    bias = torch.randn(cout, device='cuda')
+    kw = dict(bias=bias, act=conv.ACT_RELU)
+    for _ in range(3):
+        hc.forward(x, out=y, **kw)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            hc.forward(x, out=y, **kw)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 3)
+    ms = float(np.median(ts))
+    fl = 2.0 * b * cout * cin * k * k * (res * res if tr else oh * ow)
+    by = 2.0 * (x.numel() + y.numel())
+    print('%4d->%-4d k%d s%d %s @%-4d  %.4f ms  %.0f TFLOP/s  %.0f GB/s' % (cin, cout, k, s, 'T' if tr else ' ', res, ms, fl / ms / 1e9, by / ms / 1e6), flush=True)
+    del x, y, hc
+    torch.cuda.empty_cache()
