@@ -99,7 +99,9 @@ def call_bytes(q):
     B, cin, cout, kh, kw, stride, H, W, OH, OW, step, in_mask = q[3][:12]
     flags = q[3][13] if len(q[3]) > 13 else ''
     extra = sum(1 for c in 'rmoas' if c in flags.rstrip('0123456789'))
-    return 4.0 * (B * cin * H * W * (2 if in_mask else 1) + B * cout * OH * OW * (1 + extra))
+    bpe = 2.0 if q[5].endswith('_h8') else 4.0              # bf16 h8 maps on the 16-bit path
+    npx_out = (4 * H * W) if (q[5] == 'transposed_h8') else OH * OW
+    return bpe * (B * cin * H * W * (2 if in_mask else 1) + B * cout * npx_out * (1 + extra))
 
 
 def family_table(prof, steps):
@@ -138,8 +140,9 @@ def main():
     ap.add_argument('--reg_only', action='store_true', help='--no_content_loss --no_gan_loss')
     ap.add_argument('--cpu_baseline_s', type=float, default=12.0, help='CPU-oracle time budget (0 = skip)')
     ap.add_argument('--no_kernel_events', action='store_true', help='do not bracket conv launches with events')
-    ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3'],
-                    help="matrix path: exact fp32 MFMA (c3 default) or the 3-term bf16 split with fp32 accumulation (c5 default)")
+    ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
+                    help="f32: exact fp32 MFMA, fp32 storage (c3 default); bf16: the 16-bit path — bf16 h8 storage, one bf16 MFMA per MAC, fp32 accumulation (c5 "
+                         "default); bf16x3: fp32 storage, 3-term bf16 split on the matrix cores (fp32-class results)")
     ap.add_argument('--hip_graph', type=int, default=None, help='1: replay forward+backward from one hipGraph (c5 default), 0: eager launches')
     ap.add_argument('--no_alt_precision', action='store_true', help='skip the extra timing of the other matrix path')
     ap.add_argument('--direct_3x3', action='store_true', help='run 3x3 stride-1 layers on the direct implicit-GEMM kernel instead of Winograd F(2x2,3x3)')
@@ -166,7 +169,7 @@ def main():
         print(lines[0], flush=True)
         return
     c5 = a.config == 'c5'
-    precision = a.precision or ('bf16x3' if c5 else 'f32')
+    precision = a.precision or ('bf16' if c5 else 'f32')
     use_graph = bool(a.hip_graph) if a.hip_graph is not None else c5
     transform = 'scene' if c5 else 'face'
     attrs = a.attrs.split(',') if a.attrs else (SCENE_ATTRS if c5 else ['Smiling'])
@@ -246,30 +249,6 @@ def main():
         captured = keep_captured
     dist.barrier()
 
-    # the other matrix path, same steps, for the record (all ranks: the all-reduce is inside the step)
-    alt = None
-    if not a.no_alt_precision:
-        other = 'bf16x3' if precision == 'f32' else 'f32'
-        conv.PRECISION = other
-        if use_graph:                                       # a graph holds the kernels of the precision it was captured with; its memory
-            import gc                                       # pool (every activation of a step) is released before the next one is built
-            captured = None
-            gc.collect()
-            torch.cuda.empty_cache()
-            captured = make_captured()
-        one_step(0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t2 = time.perf_counter()
-        for i in range(a.steps):
-            one_step(a.warmup + i)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t_alt = dist.max_over_ranks(time.perf_counter() - t2, dev)
-        conv.PRECISION = precision
-        alt = dict(precision=other, value=round(global_b * a.steps / t_alt, 3), unit='images/s', ms_per_step=round(t_alt / a.steps * 1e3, 2),
-                   note='same workload and steps with the matrix path switched (see DESIGN.md section 2); not the headline value')
-
     # batch sweep (the BASELINE metric is quoted over a batch sweep): the same eager step at other per-GPU batches, every rank
     sweep = None
     if a.sweep:
@@ -304,6 +283,39 @@ def main():
                 sweep.append(dict(batch=bs, global_batch=gb, images_s=None, error='out of memory: %s' % str(e)[:120]))
             gc.collect()
             torch.cuda.empty_cache()
+
+    # the other matrix path, same steps, for the record (all ranks: the all-reduce is inside the step)
+    alt = None
+    if not a.no_alt_precision:
+        other = {'f32': 'bf16x3', 'bf16x3': 'f32', 'bf16': 'bf16x3'}[precision]
+        conv.PRECISION = other
+        if precision == 'bf16':                             # other network classes (fp32 storage): a second graph, the 16-bit one is released first
+            import gc
+            captured = None
+            g = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            np.random.seed(1234)
+            g = selfcheck.build_graph(a.resolution, attrs, a.batch * world, lr=1e-4, transform=transform)
+            dist.broadcast_parameters(g.walk.parameters())
+        if use_graph:                                       # a graph holds the kernels of the precision it was captured with; its memory
+            import gc                                       # pool (every activation of a step) is released before the next one is built
+            captured = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            captured = make_captured()
+        one_step(0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t2 = time.perf_counter()
+        for i in range(a.steps):
+            one_step(a.warmup + i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_alt = dist.max_over_ranks(time.perf_counter() - t2, dev)
+        conv.PRECISION = precision
+        alt = dict(precision=other, value=round(global_b * a.steps / t_alt, 3), unit='images/s', ms_per_step=round(t_alt / a.steps * 1e3, 2),
+                   note='same workload and steps with the matrix path switched (see DESIGN.md section 2); not the headline value')
 
     if rk != 0:
         dist.shutdown()

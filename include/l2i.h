@@ -145,8 +145,9 @@ int l2i_conv2d_wino_f32(const l2i_conv_params* p, void* stream);
  * l2i_conv2d_h8: 1x1 (pad 0) / 3x3 (pad 0 or 1) correlation, stride 1 or 2, Cin % 32 == 0.  Same struct as l2i_conv2d_f32 with
  *   x, y, residual, res_mask, out_mask, res_sub, sq_ref -> bf16 h8 tensors (fp32 NCHW for y and the epilogue operands when out_f32 = 1);
  *   w_hi -> bf16 weight planes [Cin/16][KH*KW][2][CoutP][8] (latent2im_amd/conv.py:pack_weight_bf16x3, hi plane), per sample when w_bstride != 0;
- *   noise [B,1,OHf,OWf], bias [Cout], out_scale [B,Cout] fp32; `w`, `w_lo` ignored; in_scale / in_mask must be NULL (no prologue fusions:
- *   scales live in the weights, masks in the producing epilogue).  h8 output needs Cout % 8 == 0.
+ *   noise [B,1,OHf,OWf], bias [Cout], out_scale [B,Cout] fp32; `w`, `w_lo` ignored; no prologue fusions (scales live in the weights, masks in
+ *   the producing epilogue): in_scale must be NULL, in_mask NULL or == x with mask (1, 0) (ReLU-on-load, 3x3 stride-1 layers); the output
+ *   mask is leaky here: * (out_mask > 0 ? mask_pos : mask_neg).  h8 output needs Cout % 8 == 0.
  * l2i_conv_transpose2d_h8: stride-2 transposed 3x3 conv (pad 0 / 1), all four output parities per launch, h8 in and out. */
 int l2i_conv2d_h8(const l2i_conv_params* p, void* stream);
 int l2i_conv_transpose2d_h8(const l2i_conv_params* p, void* stream);
@@ -163,7 +164,8 @@ int l2i_cast_f32_to_h8(void* y, const float* x, int B, int C, int Cpad, int64_t 
 int l2i_cast_h8_to_f32(float* y, const void* x, int B, int C, int Cpad, int64_t HW, void* stream);
 int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
-                     float act_gain, void* stream);
+                     float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, void* stream);
+                     /* ... then * (mask > 0 ? mask_pos : mask_neg) (h8, like y: a gradient through a (leaky) ReLU) and + addend (h8, like y) */
 int l2i_torgb_fwd_h8(float* rgb, const void* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream);
 int l2i_sg2_act_bwd_h8(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
                        const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream);
@@ -172,7 +174,8 @@ int l2i_maxpool2d_fwd_h8(void* y, void* idx, const void* x, int64_t planes, int 
 int l2i_maxpool2d_bwd_h8(void* gx, const void* gy, const void* idx, const void* a, const void* b, float coef, const float* coef_dev, int64_t planes, int H, int W,
                          int k, int s, int pad, int OH, int OW, void* stream);
 int l2i_sqdiff_h8(float* sum_out, void* grad, const void* a, const void* b, int64_t slots, float coef, const float* coef_dev, void* stream);
-int l2i_add_zero_insert_h8(void* y, const void* c, int64_t planes, int H, int W, int OH, int OW, void* stream);
+int l2i_add_zero_insert_h8(void* y, const void* c, const void* mask, int64_t planes, int H, int W, int OH, int OW, void* stream);   /* mask (h8 like y, or NULL): c * (mask[2oy,2ox] > 0) */
+int l2i_mask_mul_h8(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream);                     /* y = g * (ref > 0 ? pos : neg) */
 int l2i_modulate_planes_h8(void* planes, const float* w32, const float* s, int B, int Cs, int CinP, int KK, int CoutP, void* stream);
 
 /* out[i] = act_grad_table(x[i] + b[(i / step_b) % size_b], ref[i]) * scale   — the reference op, all six

@@ -575,9 +575,21 @@ class H8Conv:
         return run_h8(pl, gy, out, self.coutp_in, self.cin, self.k, 1, self.k - 1 - self.padding, transposed=False, w_bstride=w_bstride, **kw)
 
 
+def _h8_dgrad_compact(self, gy, planes=None, **kw):
+    """Input-gradient of a STRIDED 1x1 conv without the zero insertion: the 1x1 stride-1 conv of gy with the transposed weights, on the
+    compact (output-resolution) map; the caller scatters it into every second pixel (kernels16.add_zero_insert)."""
+    assert self.k == 1 and self.stride == 2 and not self.transposed
+    B, _, oh, ow, _ = gy.shape
+    out = torch.empty(B, (self.cin + 7) // 8, oh, ow, 8, device=gy.device, dtype=torch.bfloat16)
+    return run_h8(planes if planes is not None else self.bwd_planes, gy, out, self.coutp_in, self.cin, 1, 1, 0, **kw)
+
+
+H8Conv.dgrad_compact = _h8_dgrad_compact
+
+
 def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=0, out_f32=False, out_scale=None, noise=None, noise_w=0.0, bias=None,
-           residual=None, res_mask=None, out_mask=None, act=ACT_NONE, slope=0.2, gain=1.0, out_gain=1.0, accumulate=False, res_sub=None, res_coef=1.0,
-           res_coef_dev=None, sq=None):
+           residual=None, res_mask=None, out_mask=None, mask=(1.0, 0.0), act=ACT_NONE, slope=0.2, gain=1.0, out_gain=1.0, accumulate=False, res_sub=None, res_coef=1.0,
+           res_coef_dev=None, sq=None, relu_in=False):
     """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels."""
     lib = _lib.load()
     B, cg, H, W, _ = x.shape
@@ -606,6 +618,10 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
     for t in (residual, res_mask, out_mask, res_sub):
         assert t is None or (t.shape == y.shape and t.dtype == y.dtype)
     p.residual, p.res_mask, p.out_mask = _lib.ptr(residual), _lib.ptr(res_mask), _lib.ptr(out_mask)
+    p.mask_pos, p.mask_neg = mask                                 # of the OUTPUT mask here: * (out_mask > 0 ? mask[0] : mask[1])
+    if relu_in:                                                   # ReLU-on-load (VGG-19 reads pre-ReLU taps): in_mask == x, mask (1, 0)
+        assert out_mask is None
+        p.in_mask, p.mask_pos, p.mask_neg = p.x, 1.0, 0.0
     if res_sub is not None:
         p.res_sub, p.res_coef, p.res_coef_dev = _lib.ptr(res_sub), float(res_coef), _lib.fptr(res_coef_dev)
     p.act, p.act_slope, p.act_gain, p.out_gain = act, slope, gain, out_gain

@@ -94,7 +94,7 @@ struct H8Out {
             float m[8];
             h8_unpack(reinterpret_cast<const u32x4*>(p.out_mask)[slot], m);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < 8; ++e) v[e] *= m[e] > 0.f ? p.mask_pos : p.mask_neg;   // (1, 0): a ReLU mask; (1, 0.2) / (sqrt2, 0.2 sqrt2): leaky ReLU'
         }
         if (p.bias) {
             const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co0), b1 = *reinterpret_cast<const float4*>(p.bias + co0 + 4);
@@ -169,7 +169,10 @@ __device__ __forceinline__ void h8_gather(const f32x16& a, int pr, int half, flo
     (void)half;
 }
 
-template <int WM, int WN, int K, int S, int TR, bool OUT32>
+// RELU_IN: pro(x) = max(x, 0) on the B fragments (VGG-19: a conv reads the PRE-ReLU tap of the layer below, which is what the ContentLoss
+// and the backward masks need in HBM): four v_pk_max_i16 per fragment — a negative bf16 is a negative int16, so the integer max with 0 is
+// the ReLU (and -0 -> +0) — beside the bf16 MFMAs, whose pipe the VALU does not share
+template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false>
 __global__ __launch_bounds__(256, 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
     using G = g8::Geo<WN, K, S, TR>;
     constexpr int NACC = TR ? 4 : 1;
@@ -289,7 +292,14 @@ __global__ __launch_bounds__(256, 2) void conv_h8_kernel(const l2i_conv_params p
 #pragma unroll
                 for (int m = 0; m < WM; ++m) af[m] = __builtin_bit_cast(bf16x8, wh[((kx * G::KS + ks) * 2) * BM + m * 32]);
 #pragma unroll
-                for (int n = 0; n < WN; ++n) bf[n] = __builtin_bit_cast(bf16x8, ih[ks * 2 * G::HSTRIDE + n * rstep_out * G::RP + coloff]);
+                for (int n = 0; n < WN; ++n) {
+                    u32x4 raw = ih[ks * 2 * G::HSTRIDE + n * rstep_out * G::RP + coloff];
+                    if constexpr (RELU_IN) {
+                        asm("v_pk_max_i16 %0, %0, 0" : "+v"(raw.x)); asm("v_pk_max_i16 %0, %0, 0" : "+v"(raw.y));
+                        asm("v_pk_max_i16 %0, %0, 0" : "+v"(raw.z)); asm("v_pk_max_i16 %0, %0, 0" : "+v"(raw.w));
+                    }
+                    bf[n] = __builtin_bit_cast(bf16x8, raw);
+                }
 #pragma unroll
                 for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void conv_h8_kernel(const l2i_conv_params p
 }
 
 // ------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int K, int S, int TR, bool OUT32>
+template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false>
 static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
     using G = g8::Geo<WN, K, S, TR>;
     constexpr int BM = WM * 32;
@@ -388,11 +398,11 @@ static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
     if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: tile does not fit the LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h8_kernel<WM, WN, K, S, TR, OUT32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     const unsigned grid = (unsigned)((total + 7) & ~7L);
-    hipLaunchKernelGGL((conv_h8_kernel<WM, WN, K, S, TR, OUT32>), dim3(grid), dim3(256), lds, st, p, L);
+    hipLaunchKernelGGL((conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN>), dim3(grid), dim3(256), lds, st, p, L);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }
@@ -401,7 +411,9 @@ static int h8_common_checks(const l2i_conv_params& p, const char* who) {
     if (!p.x || !p.w_hi || !p.y) return l2i_set_error(L2I_E_ARG, "conv h8: null tensor");
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0) return l2i_set_error(L2I_E_ARG, "conv h8: non-positive dimension");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv h8: CoutP must be Cout rounded up to 32");
-    if (p.in_scale || p.in_mask) return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: no prologue fusions (scales live in the weights, masks in the producing epilogue)");
+    const bool relu_in = p.in_mask && (const void*)p.in_mask == (const void*)p.x && p.mask_pos == 1.f && p.mask_neg == 0.f && !p.out_mask;
+    if (p.in_scale || (p.in_mask && !relu_in))
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: no prologue fusions (scales live in the weights, masks in the producing epilogue) except ReLU-on-load (in_mask == x)");
     if ((p.Cin % 32) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: Cin must be a multiple of 32");
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
     if (!al16(p.x) || !al16(p.w_hi) || !al16(p.y) || !al16(p.residual) || !al16(p.res_mask) || !al16(p.res_sub) || !al16(p.out_mask) || !al16(p.sq_ref) ||
@@ -427,12 +439,17 @@ extern "C" int l2i_conv2d_h8(const l2i_conv_params* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool wide = (p.CoutP % 64) == 0;
     if (p.out_f32) {                                       // fp32 NCHW output (gradients landing on images, the last layer in front of an fp32 consumer)
+        if (p.in_mask) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: ReLU-on-load needs the h8 output");
         if (p.sq_ref) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: sq_ref needs the h8 output");
         if (p.KH == 3 && p.stride == 1) return wide ? launch_h8<2, 2, 3, 1, 0, true>(p, st) : launch_h8<1, 2, 3, 1, 0, true>(p, st);
         if (p.KH == 1 && p.stride == 1) return wide ? launch_h8<2, 2, 1, 1, 0, true>(p, st) : launch_h8<1, 2, 1, 1, 0, true>(p, st);
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: fp32 output is built for stride-1 layers");
     }
     if ((p.Cout % 8) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: h8 output needs Cout % 8 == 0");
+    if (p.in_mask) {                                       // ReLU-on-load: the 3x3 stride-1 layers of VGG-19
+        if (p.KH == 3 && p.stride == 1) return wide ? launch_h8<2, 2, 3, 1, 0, false, true>(p, st) : launch_h8<1, 2, 3, 1, 0, false, true>(p, st);
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: ReLU-on-load is built for 3x3 stride-1 layers");
+    }
     if (p.KH == 3 && p.stride == 1) return wide ? launch_h8<2, 2, 3, 1, 0, false>(p, st) : launch_h8<1, 2, 3, 1, 0, false>(p, st);
     if (p.KH == 1 && p.stride == 1) return wide ? launch_h8<2, 2, 1, 1, 0, false>(p, st) : launch_h8<1, 2, 1, 1, 0, false>(p, st);
     if (p.KH == 3 && p.stride == 2) return wide ? launch_h8<2, 1, 3, 2, 0, false>(p, st) : launch_h8<1, 1, 3, 2, 0, false>(p, st);
@@ -445,7 +462,7 @@ extern "C" int l2i_conv_transpose2d_h8(const l2i_conv_params* pp, void* stream) 
     if (int rc = h8_common_checks(p, "conv_transpose2d_h8")) return rc;
     const int nat = (p.H - 1) * 2 - 2 * p.pad_y + 3, natw = (p.W - 1) * 2 - 2 * p.pad_x + 3;
     if (p.KH != 3 || p.KW != 3 || p.stride != 2 || p.pad_y != p.pad_x || p.pad_x < 0 || p.pad_x > 1 || p.OHf < nat || p.OHf > nat + 8 || p.OWf < natw || p.OWf > natw + 8 ||
-        p.OH != (p.OHf + 1) / 2 || p.OW != (p.OWf + 1) / 2 || p.out_f32 || (p.Cout % 8) != 0 || p.sq_ref)
+        p.OH != (p.OHf + 1) / 2 || p.OW != (p.OWf + 1) / 2 || p.out_f32 || (p.Cout % 8) != 0 || p.sq_ref || p.in_mask)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d_h8: 3x3 stride-2 layer (pad 0 or 1), natural output size (or up to 8 larger), h8 output");
     hipStream_t st = (hipStream_t)stream;
     const bool wide = (p.CoutP % 64) == 0;

@@ -78,7 +78,8 @@ extern "C" int l2i_cast_h8_to_f32(float* y, const void* x, int B, int C, int Cpa
 //   y = act( fir(x) + noise[b,oy,ox] * noise_w + bias[c] ) * act_gain.        KH, KW <= 4, up / down in {1, 2} (the path's geometries).
 __global__ __launch_bounds__(256) void upfirdn2d_h8_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ x, const float* __restrict__ k, long long planes, int G8,
                                                            int in_h, int in_w, int out_h, int out_w, int kh, int kw, int up, int down, int pad_x0, int pad_y0,
-                                                           const float* __restrict__ noise, float noise_w, const float* __restrict__ bias, int act, float slope, float gain) {
+                                                           const float* __restrict__ noise, float noise_w, const float* __restrict__ bias, int act, float slope, float gain,
+                                                           const u32x4* __restrict__ mask, float mpos, float mneg, const u32x4* __restrict__ addend) {
     __shared__ float taps[16];
     if (threadIdx.x < kh * kw) taps[threadIdx.x] = k[threadIdx.x];
     __syncthreads();
@@ -121,12 +122,24 @@ __global__ __launch_bounds__(256) void upfirdn2d_h8_kernel(u32x4* __restrict__ y
                 acc[e] = v * gain;
             }
         }
+        if (mask) {                                            // a gradient through a (leaky) ReLU: * (mask > 0 ? mpos : mneg)
+            float m[8];
+            unpack8(mask[i], m);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] *= m[e] > 0.f ? mpos : mneg;
+        }
+        if (addend) {
+            float a[8];
+            unpack8(addend[i], a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += a[e];
+        }
         y[i] = pack8(acc);
     }
 }
 extern "C" int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
                                 int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
-                                float act_gain, void* stream) {
+                                float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, void* stream) {
     if (!y || !x || !k) return l2i_set_error(L2I_E_ARG, "upfirdn2d_h8: null tensor");
     if (planes <= 0 || channels <= 0 || (channels % 8) != 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0 || kh > 4 || kw > 4 || (up != 1 && up != 2) || (down != 1 && down != 2))
         return l2i_set_error(L2I_E_ARG, "upfirdn2d_h8: kernels up to 4x4, up / down in {1, 2}, channels % 8 == 0");
@@ -134,7 +147,8 @@ extern "C" int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t 
     if (out_h <= 0 || out_w <= 0) return l2i_set_error(L2I_E_ARG, "upfirdn2d_h8: empty output");
     const long long total = (long long)planes * out_h * out_w;
     hipLaunchKernelGGL(upfirdn2d_h8_kernel, dim3(l2i_grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)x, k, (long long)planes,
-                       channels / 8, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, noise, noise_w, bias, act, act_slope, act_gain);
+                       channels / 8, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, noise, noise_w, bias, act, act_slope, act_gain, (const u32x4*)mask, mask_pos,
+                       mask_neg, (const u32x4*)addend);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }
@@ -410,7 +424,8 @@ extern "C" int l2i_sqdiff_h8(float* sum_out, void* grad, const void* a, const vo
 }
 
 // ---- y[2 oy, 2 ox] += c[oy, ox] (zero insertion: the input-gradient of a strided 1x1 conv added to the gradient of the other branch) ------------
-__global__ __launch_bounds__(256) void add_zero_insert_h8_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ c, long long planes, int H, int W, int OH, int OW) {
+__global__ __launch_bounds__(256) void add_zero_insert_h8_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ c, const u32x4* __restrict__ mask, long long planes, int H, int W,
+                                                                 int OH, int OW) {
     const long long OHW = (long long)OH * OW, total = planes * OHW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long pl = i / OHW;
@@ -421,15 +436,21 @@ __global__ __launch_bounds__(256) void add_zero_insert_h8_kernel(u32x4* __restri
         float a[8], b[8];
         unpack8(y[o], a);
         unpack8(c[i], b);
+        if (mask) {                                            // ReLU mask of the map the sum is the gradient of
+            float m[8];
+            unpack8(mask[o], m);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] = m[e] > 0.f ? b[e] : 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] += b[e];
         y[o] = pack8(a);
     }
 }
-extern "C" int l2i_add_zero_insert_h8(void* y, const void* c, int64_t planes, int H, int W, int OH, int OW, void* stream) {
+extern "C" int l2i_add_zero_insert_h8(void* y, const void* c, const void* mask, int64_t planes, int H, int W, int OH, int OW, void* stream) {
     if (!y || !c || planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return l2i_set_error(L2I_E_ARG, "add_zero_insert_h8: bad arguments");
     hipLaunchKernelGGL(add_zero_insert_h8_kernel, dim3(l2i_grid_for((long long)planes * OH * OW, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)c,
-                       (long long)planes, H, W, OH, OW);
+                       (const u32x4*)mask, (long long)planes, H, W, OH, OW);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }
@@ -455,6 +476,25 @@ extern "C" int l2i_modulate_planes_h8(void* planes, const float* w32, const floa
     if (Cs != CinP) return l2i_set_error(L2I_E_ARG, "modulate_planes_h8: the scale vector must cover the padded channel count");
     const long long sps = (long long)(CinP / 16) * KK * 2 * CoutP, total = sps * B;
     hipLaunchKernelGGL(modulate_planes_kernel, dim3(l2i_grid_for(total, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (u32x4*)planes, w32, s, Cs, sps, KK, CoutP, total);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
+// ---- y = g * (ref > 0 ? pos : neg): a gradient through a (leaky) ReLU whose output `ref` was saved (the conv kernels of this path have no
+// prologue, so a mask that cannot ride on the producing epilogue — the gradient also feeds an unmasked branch — is one pass) ----------------------
+__global__ __launch_bounds__(256) void mask_mul_h8_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ g, const u32x4* __restrict__ ref, float pos, float neg, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float a[8], m[8];
+        unpack8(g[i], a);
+        unpack8(ref[i], m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] *= m[e] > 0.f ? pos : neg;
+        y[i] = pack8(a);
+    }
+}
+extern "C" int l2i_mask_mul_h8(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream) {
+    if (!y || !g || !ref || slots <= 0) return l2i_set_error(L2I_E_ARG, "mask_mul_h8: bad arguments");
+    hipLaunchKernelGGL(mask_mul_h8_kernel, dim3(l2i_grid_for(slots, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)g, (const u32x4*)ref, pos, neg, (long long)slots);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }

@@ -63,7 +63,7 @@ class Discriminator:
     def __call__(self, img):
         """[B,3,size,size] -> [B,1] logits (networks.py:627-645)."""
         from .op import fused_leaky_relu
-        out = _DBodyFn.apply(img, self)                                        # [B,512,4,4]
+        out = self.body(img)                                                   # [B,512,4,4]
         batch, channel, height, width = out.shape
         group = min(batch, 4)
         if batch % group != 0:
@@ -77,6 +77,11 @@ class Discriminator:
         out = out.reshape(batch, -1)
         out = fused_leaky_relu(torch.mm(out, self.lin0_wt), self.lin0_b)
         return torch.addmm(self.lin1_b, out, self.lin1_wt)
+
+
+    def body(self, img):
+        """from_rgb conv + residual blocks: [B,3,size,size] -> [B,512,4,4] fp32 (the 16-bit path overrides this, nets16.Discriminator)."""
+        return _DBodyFn.apply(img, self)
 
 
 class _ConvLReLUFn(torch.autograd.Function):

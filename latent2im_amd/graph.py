@@ -168,8 +168,15 @@ def load_networks(resolution, device, need_vgg=True, need_d=True):
     else:
         r_state = synth.resnet50_state(seed=constants.SYNTH_SEED_R)
         src['R'] = 'synthetic(seed=%d)' % constants.SYNTH_SEED_R
-    netG = Generator(g_state, resolution, device=device)
-    reg = ResNet50(r_state, device=device)
+    from . import conv
+    if conv.PRECISION == 'bf16':                           # the 16-bit path (BASELINE config 5): bf16 h8 feature maps, one bf16 MFMA per MAC (nets16.py)
+        from . import nets16
+        GenCls, RegCls, VggCls, DCls = nets16.Generator, nets16.ResNet50, nets16.VGG19Prefix, nets16.Discriminator
+    else:
+        GenCls, RegCls, VggCls, DCls = Generator, ResNet50, VGG19Prefix, Discriminator
+    src['precision'] = conv.PRECISION
+    netG = GenCls(g_state, resolution, device=device)
+    reg = RegCls(r_state, device=device)
     vgg = netD = None
     if need_vgg:
         if _checkpoint_or_synthetic('VGG-19 (vgg_path; the reference downloads torchvision weights)', constants.vgg_path):
@@ -179,10 +186,10 @@ def load_networks(resolution, device, need_vgg=True, need_d=True):
         else:
             v_state = synth.vgg19_prefix_state(seed=constants.SYNTH_SEED_V)
             src['V'] = 'synthetic(seed=%d)' % constants.SYNTH_SEED_V
-        vgg = VGG19Prefix(v_state, device=device)
+        vgg = VggCls(v_state, device=device)
     if need_d:
         # the reference's netD is ALWAYS freshly initialised (never loaded): seeded here for reproducibility
-        netD = Discriminator(synth.discriminator_state(resolution, seed=constants.SYNTH_SEED_D), resolution, device=device)
+        netD = DCls(synth.discriminator_state(resolution, seed=constants.SYNTH_SEED_D), resolution, device=device)
         src['D'] = 'random-init(seed=%d)' % constants.SYNTH_SEED_D
     return netG, netD, reg, vgg, src
 

@@ -32,8 +32,10 @@ def cast_from_h8(t, channels=None):
     return y
 
 
-def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0, 0, 0), noise=None, noise_w=0.0, bias=None, act=ACT_NONE, slope=0.2, gain=1.0):
-    """x h8; pad = (x0, x1, y0, y1) as in op/upfirdn2d.cpp:12-23; optional fused epilogue act(fir(x) + noise*noise_w + bias[c]) * gain."""
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0, 0, 0), noise=None, noise_w=0.0, bias=None, act=ACT_NONE, slope=0.2, gain=1.0, mask=None, mask_vals=(1.0, 0.0),
+              addend=None):
+    """x h8; pad = (x0, x1, y0, y1) as in op/upfirdn2d.cpp:12-23; optional fused epilogue act(fir(x) + noise*noise_w + bias[c]) * gain, then
+    * (mask > 0 ? mask_vals[0] : mask_vals[1]) and + addend (both h8, shaped like the output)."""
     lib = _lib.load()
     B, G8, H, W, _ = x.shape
     kh, kw = kernel.shape
@@ -41,7 +43,9 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0, 0, 0), noise=None, noise_w=0.0
     ow = (W * up + pad[0] + pad[1] - kw) // down + 1
     y = torch.empty(B, G8, oh, ow, 8, device=x.device, dtype=BF)
     _lib.check(lib.l2i_upfirdn2d_h8(_lib.ptr(y), _h8(x), _lib.fptr(kernel.contiguous()), B * G8, G8 * 8, H, W, kh, kw, up, down, pad[0], pad[1], pad[2], pad[3],
-                                    _lib.fptr(noise), float(noise_w), _lib.fptr(bias), int(act), float(slope), float(gain), _lib.stream_ptr()), 'l2i_upfirdn2d_h8')
+                                    _lib.fptr(noise), float(noise_w), _lib.fptr(bias), int(act), float(slope), float(gain), None if mask is None else _h8(mask),
+                                    float(mask_vals[0]), float(mask_vals[1]), None if addend is None else _h8(addend), _lib.stream_ptr()), 'l2i_upfirdn2d_h8')
+    assert (mask is None or mask.shape == y.shape) and (addend is None or addend.shape == y.shape)
     return y
 
 
@@ -103,11 +107,19 @@ def sqdiff(a, b, coef=0.0, want_grad=False, coef_dev=None, want_sum=True):
     return s, g
 
 
-def add_zero_insert(y, c):
-    """y[.., 2oy, 2ox, :] += c[.., oy, ox, :] in place (h8)."""
+def add_zero_insert(y, c, mask=None):
+    """y[.., 2oy, 2ox, :] += c[.., oy, ox, :] * (mask[.., 2oy, 2ox, :] > 0 if a mask is given) in place (h8)."""
     lib = _lib.load()
     B, G8, H, W, _ = y.shape
-    _lib.check(lib.l2i_add_zero_insert_h8(_h8(y), _h8(c), B * G8, H, W, c.shape[2], c.shape[3], _lib.stream_ptr()), 'l2i_add_zero_insert_h8')
+    _lib.check(lib.l2i_add_zero_insert_h8(_h8(y), _h8(c), None if mask is None else _h8(mask), B * G8, H, W, c.shape[2], c.shape[3], _lib.stream_ptr()), 'l2i_add_zero_insert_h8')
+    return y
+
+
+def mask_mul(g, ref, pos=1.0, neg=0.0):
+    """g * (ref > 0 ? pos : neg) on h8 maps."""
+    lib = _lib.load()
+    y = torch.empty_like(g)
+    _lib.check(lib.l2i_mask_mul_h8(_lib.ptr(y), _h8(g), _h8(ref), float(pos), float(neg), g.numel() // 8, _lib.stream_ptr()), 'l2i_mask_mul_h8')
     return y
 
 

@@ -1,0 +1,404 @@
+"""The frozen networks of the walk-training step on the 16-bit path (BASELINE config 5: "fp16 storage / MFMA with fp32 accumulate"; bf16 here —
+fp32's exponent range, so activations of 1e2 and gradients of 1e-9 need no scaling): every feature map and every saved tensor is a bf16 tensor
+in the channel-blocked h8 layout [B, C/8, H, W, 8]; every contraction is one v_mfma_f32_32x32x16_bf16 product per MAC with fp32 accumulation
+(csrc/l2i_conv_h8.hip); the streaming kernels read and write h8 (csrc/l2i_stream_h8.hip).  fp32 stays where the reference's numbers live:
+images (3 channels), latents, styles / demodulation, noise, biases, every reduction and loss sum, the walk.
+
+Same classes, call signatures and autograd contracts as the fp32 modules (generator.py, discriminator.py, regressor.py, perceptual.py) — images
+in, images / predictions / losses out — so graph.py switches between the two by ``conv.PRECISION`` ('bf16' = this module).  Structural
+differences from the fp32 path, all forced by "no prologue in the conv kernel" (its operands go global -> LDS by DMA):
+  * style modulation: the style is folded into one weight-plane set per sample (the reference's own formulation, networks.py:234-243) by
+    l2i_modulate_planes_h8; demodulation is the conv's out_scale;
+  * activation-gradient masks ride on the PRODUCING epilogue (out_mask with leaky values), on the FIR's epilogue, or on one masked copy where
+    the gradient also feeds an unmasked branch;
+  * VGG-19 reads pre-ReLU taps: ReLU-on-load inside the conv (four packed integer max per fragment).
+Reference call sites as in the fp32 modules."""
+import math
+
+import numpy as np
+import torch
+
+from . import conv as C
+from . import kernels as K
+from . import kernels16 as K16
+from . import specs
+from .discriminator import Discriminator as _Discriminator32, _ConvLReLUFn, _eq_conv, _vec
+from .generator import Generator as _Generator32, _ModPlan, _Mod, _ToRGB, _noise_for, _t
+from .perceptual import VGG_STD, VGG_MEAN
+from .regressor import _CB, _fold_bn
+from .specs import RESNET50_LAYERS
+
+SQRT2 = math.sqrt(2.0)
+LRELU_MASK = (SQRT2, 0.2 * SQRT2)
+
+
+# =====================================================================================================================================
+# VGG-19 prefix content loss (perceptual.py)
+# =====================================================================================================================================
+class VGG19Prefix:
+    def __init__(self, state, device='cuda'):
+        P = state
+        self.device = device
+        w0 = torch.as_tensor(np.asarray(P['0.weight']), dtype=torch.float32)
+        w0 = w0 / torch.tensor(VGG_STD, dtype=torch.float32).reshape(1, 3, 1, 1)
+        ws = [w0] + [torch.as_tensor(np.asarray(P['%d.weight' % i]), dtype=torch.float32) for i in (2, 5, 7)]
+        self.convs = [C.H8Conv(w, 1, 1, device=device) for w in ws]
+        self.biases = [torch.as_tensor(np.asarray(P['%d.bias' % i]), dtype=torch.float32).contiguous().to(device) for i in (0, 2, 5, 7)]
+        self.neg_mean = (-torch.tensor(VGG_MEAN, dtype=torch.float32)).to(device)
+
+    def taps(self, img, org=None):
+        """[B,3,H,W] fp32 -> (c1, c2, p, c3, c4, pool_idx) h8: pre-ReLU conv outputs conv_1..conv_4, p = relu(maxpool(c2)).  ``org`` = the four
+        taps of the original image: a seventh element, the four sums of (c_k - org_k)^2, formed in the conv epilogues."""
+        xc = K.fused_bias_act(img.contiguous(), self.neg_mean, None, 1, 0, 0.0, 1.0)        # x - mean (fp32: the padding stays exactly zero)
+        xh = K16.cast_to_h8(xc, 32)                                # three real channels of a 32-channel chunk
+        sq = [None] * 4
+        if org is not None:
+            acc = torch.zeros(4, C._lib.SQ_SLOTS, device=img.device, dtype=torch.float32)
+            sq = [(org[k], acc[k], [False]) for k in range(4)]
+        c1 = self.convs[0].forward(xh, bias=self.biases[0], sq=sq[0])
+        c2 = self.convs[1].forward(c1, relu_in=True, bias=self.biases[1], sq=sq[1])
+        p, idx = K16.maxpool2d_fwd(c2, 2, 2, 0, relu=True)          # relu(maxpool(.)) == maxpool(relu(.)); the stored map is already rectified
+        c3 = self.convs[2].forward(p, bias=self.biases[2], sq=sq[2])
+        c4 = self.convs[3].forward(c3, relu_in=True, bias=self.biases[3], sq=sq[3])
+        if org is None:
+            return c1, c2, p, c3, c4, idx
+        return c1, c2, p, c3, c4, idx, [acc[k].sum().reshape(1) for k in range(4)]
+
+    def content_losses(self, org, shifted):
+        with torch.no_grad():
+            o1, o2, _, o3, o4, _ = self.taps(org.detach())
+        return _Content16Fn.apply(shifted, self, (o1, o2, o3, o4))
+
+
+class _Content16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, net, org_taps):
+        c1, c2, p, c3, c4, idx, sums = net.taps(img.detach(), org=org_taps)
+        mine = (c1, c2, c3, c4)
+        losses = torch.cat([s / float(b.numel()) for s, b in zip(sums, mine)])
+        if img.requires_grad:
+            ctx.net, ctx.org, ctx.acts, ctx.in_hw = net, org_taps, (c1, c2, p, c3, c4, idx), (img.shape[2], img.shape[3])
+        return losses
+
+    @staticmethod
+    def backward(ctx, g_losses):
+        net, (o1, o2, o3, o4) = ctx.net, ctx.org
+        c1, c2, p, c3, c4, idx = ctx.acts
+        gl = [g_losses[k:k + 1].contiguous() for k in range(4)]
+        hw = lambda t: (t.shape[2], t.shape[3])
+        d4 = K16.sqdiff(o4, c4, coef=2.0 / c4.numel(), coef_dev=gl[3], want_grad=True, want_sum=False)[1]
+        g3 = net.convs[3].dgrad(d4, hw(c3), out_mask=c3, residual=c3, res_sub=o3, res_coef=2.0 / c3.numel(), res_coef_dev=gl[2])
+        del d4
+        gp = net.convs[2].dgrad(g3, hw(p), out_mask=p)
+        del g3
+        g2 = K16.maxpool2d_bwd(gp, idx, hw(c2), 2, 2, 0, a=o2, b=c2, coef=2.0 / c2.numel(), coef_dev=gl[1])
+        del gp
+        g1 = net.convs[1].dgrad(g2, hw(c1), out_mask=c1, residual=c1, res_sub=o1, res_coef=2.0 / c1.numel(), res_coef_dev=gl[0])
+        del g2
+        g_img = net.convs[0].dgrad(g1, ctx.in_hw, out_f32=True)
+        ctx.acts = ctx.org = None
+        return g_img, None, None
+
+
+# =====================================================================================================================================
+# ResNet-50 regressor (regressor.py)
+# =====================================================================================================================================
+class _CB16:
+    def __init__(self, P, conv_name, bn_name, stride, padding, device):
+        w, b = _fold_bn(P, conv_name, bn_name)
+        self.conv = C.H8Conv(w, stride=stride, padding=padding, device=device)
+        self.bias = b.contiguous().to(device)
+
+
+class ResNet50:
+    def __init__(self, state, device='cuda'):
+        P = state
+        self.device = device
+        self.stem = _CB(P, 'conv1', 'bn1', 2, 3, device)            # 7x7 stride 2 on the 3-channel fp32 image: the fp32 kernels (0.3 % of the net's MACs)
+        self.blocks = []
+        for li, (planes, blocks, stride) in enumerate(RESNET50_LAYERS):
+            for b in range(blocks):
+                p = 'layer%d.%d' % (li + 1, b)
+                s = stride if b == 0 else 1
+                self.blocks.append(dict(c1=_CB16(P, p + '.conv1', p + '.bn1', 1, 0, device), c2=_CB16(P, p + '.conv2', p + '.bn2', s, 1, device),
+                                        c3=_CB16(P, p + '.conv3', p + '.bn3', 1, 0, device),
+                                        down=_CB16(P, p + '.downsample.0', p + '.downsample.1', s, 0, device) if b == 0 else None))
+        self.fc_w = torch.as_tensor(np.asarray(P['fc.weight']), dtype=torch.float32).contiguous().to(device)
+        self.fc_b = torch.as_tensor(np.asarray(P['fc.bias']), dtype=torch.float32).contiguous().to(device)
+
+    def __call__(self, img):
+        feat = _ResNet16Fn.apply(img, self)
+        return torch.addmm(self.fc_b, feat, self.fc_w.t())
+
+
+class _ResNet16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, net):
+        keep = img.requires_grad
+        x = img.detach().contiguous()
+        a0 = net.stem.conv.forward(x, bias=net.stem.bias, act=C.ACT_RELU)              # fp32 [B,64,H/2,W/2]
+        p0, idx0 = K16.maxpool2d_fwd(K16.cast_to_h8(a0), 3, 2, 1)
+        saved = dict(in_hw=(x.shape[2], x.shape[3]), a0=a0 if keep else None, idx0=idx0 if keep else None, blocks=[])
+        cur = p0
+        for blk in net.blocks:
+            y1 = blk['c1'].conv.forward(cur, bias=blk['c1'].bias, act=C.ACT_RELU)
+            y2 = blk['c2'].conv.forward(y1, bias=blk['c2'].bias, act=C.ACT_RELU)
+            idt = blk['down'].conv.forward(cur, bias=blk['down'].bias) if blk['down'] is not None else cur
+            out = blk['c3'].conv.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU)
+            if keep:
+                saved['blocks'].append((cur, y1, y2, out))
+            cur = out
+        b, g8, h, w, _ = cur.shape
+        feat = K16.dot_reduce(cur) * (1.0 / (h * w))                                   # adaptive avg-pool (1,1), fp32 sums
+        ctx.net, ctx.saved, ctx.last = net, saved if keep else None, cur if keep else None
+        return feat
+
+    @staticmethod
+    def backward(ctx, g_feat):
+        net, saved, last = ctx.net, ctx.saved, ctx.last
+        if saved is None:
+            raise RuntimeError('regressor was run without a differentiable input')
+        b, g8, h, w, _ = last.shape
+        hw = lambda t: (t.shape[2], t.shape[3])
+        g = (g_feat * (1.0 / (h * w))).reshape(b, g8, 1, 1, 8).expand(b, g8, h, w, 8).contiguous().to(torch.bfloat16)
+        G = K16.mask_mul(g, last)                                                        # gradient w.r.t. the pre-ReLU sum of the last block
+        n = len(net.blocks)
+        for bi in range(n - 1, -1, -1):
+            blk, (cur, y1, y2, out) = net.blocks[bi], saved['blocks'][bi]
+            m = cur if bi > 0 else None                    # the block input is the previous block's ReLU output (the pooled stem map is not)
+            g_y2 = blk['c3'].conv.dgrad(G, hw(y2), out_mask=y2)
+            g_y1 = blk['c2'].conv.dgrad(g_y2, hw(y1), out_mask=y1)
+            del g_y2
+            if blk['down'] is None:
+                Gp = blk['c1'].conv.dgrad(g_y1, hw(cur), residual=G, out_mask=m, res_mask=m)
+            elif blk['down'].conv.stride == 1:
+                t = blk['c1'].conv.dgrad(g_y1, hw(cur))
+                Gp = blk['down'].conv.dgrad(G, hw(cur), residual=t, out_mask=m, res_mask=m)
+                del t
+            else:
+                Gp = blk['c1'].conv.dgrad(g_y1, hw(cur), out_mask=m)
+                K16.add_zero_insert(Gp, blk['down'].conv.dgrad_compact(G), mask=m)       # strided 1x1: compact 1x1 conv + zero insertion
+            del g_y1
+            G = Gp
+        a0 = saved['a0']
+        g_a0 = K16.cast_from_h8(K16.maxpool2d_bwd(G, saved['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1), a0.shape[1])
+        g_img = net.stem.conv.dgrad(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0))
+        ctx.saved = ctx.last = None
+        return g_img, None
+
+
+# =====================================================================================================================================
+# StyleGAN2 discriminator (discriminator.py)
+# =====================================================================================================================================
+def _eq16(P, name, stride, padding, device):
+    w = torch.as_tensor(np.asarray(P[name]), dtype=torch.float32)
+    w = w * (1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3]))
+    return C.H8Conv(w, stride=stride, padding=padding, device=device)
+
+
+class Discriminator(_Discriminator32):
+    """Body on the 16-bit path; the 4x4 tail (minibatch stddev, final conv, two linears: [B,513,4,4] and smaller) is the fp32 code of the base class."""
+
+    def __init__(self, state, size, device='cuda'):
+        P = state
+        self.size, self.device = size, device
+        log_size = int(math.log2(size))
+        self.conv0 = _eq16(P, 'convs.0.0.weight', 1, 0, device)
+        self.bias0 = _vec(P, 'convs.0.1.bias', device)
+        self.blocks = []
+        for n in range(1, log_size - 1):
+            p = 'convs.%d' % n
+            blk = dict(c1=_eq16(P, p + '.conv1.0.weight', 1, 1, device), b1=_vec(P, p + '.conv1.1.bias', device),
+                       c2=_eq16(P, p + '.conv2.1.weight', 2, 0, device), b2=_vec(P, p + '.conv2.2.bias', device),
+                       sk1=_eq16(P, p + '.skip.1.weight', 1, 0, device), k=_vec(P, p + '.conv2.0.kernel', device))
+            blk['kf'] = torch.flip(blk['k'], [0, 1]).contiguous()
+            self.blocks.append(blk)
+        self.final_conv = _eq_conv(P, 'final_conv.0.weight', 1, 1, device)
+        self.final_bias = _vec(P, 'final_conv.1.bias', device)
+        w = _vec(P, 'final_linear.0.weight', device)
+        self.lin0_wt = (w * (1.0 / math.sqrt(w.shape[1]))).t().contiguous()
+        self.lin0_b = _vec(P, 'final_linear.0.bias', device)
+        w = _vec(P, 'final_linear.1.weight', device)
+        self.lin1_wt = (w * (1.0 / math.sqrt(w.shape[1]))).t().contiguous()
+        self.lin1_b = _vec(P, 'final_linear.1.bias', device)
+
+    def body(self, img):
+        return _DBody16Fn.apply(img, self)
+
+
+class _DBody16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, net):
+        keep = img.requires_grad
+        x = img.detach().contiguous()
+        lr = dict(act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
+        y0 = net.conv0.forward(K16.cast_to_h8(x, 32), bias=net.bias0, **lr)
+        saved = [y0]
+        cur = y0
+        for blk in net.blocks:
+            h = cur.shape[2]
+            y1 = blk['c1'].forward(cur, bias=blk['b1'], **lr)
+            t = K16.upfirdn2d(y1, blk['k'], pad=(2, 2, 2, 2))                    # Blur before the stride-2 3x3 (networks.py:530-536): (h+1)^2
+            y2 = blk['c2'].forward(t, bias=blk['b2'], **lr)
+            del t
+            ts = K16.upfirdn2d(cur, blk['k'], down=2, pad=(1, 1, 1, 1))          # skip (networks.py:586-590): the blur only where the stride-2 1x1 samples it
+            out = blk['sk1'].forward(ts, residual=y2, out_gain=1.0 / SQRT2)      # (conv2 + skip) / sqrt2
+            del ts
+            if keep:
+                saved.append((y1, y2, (h, cur.shape[3])))
+            cur = out
+        ctx.net, ctx.saved, ctx.in_hw = net, saved if keep else None, (x.shape[2], x.shape[3])
+        return K16.cast_from_h8(cur)                                               # [B,512,4,4] fp32 for the tail
+
+    @staticmethod
+    def backward(ctx, g32):
+        net, saved = ctx.net, ctx.saved
+        if saved is None:
+            raise RuntimeError('discriminator was run without a differentiable input')
+        g = K16.cast_to_h8(g32.contiguous())
+        for blk, (y1, y2, in_hw) in zip(reversed(net.blocks), reversed(saved[1:])):
+            h = in_hw[0]
+            gm = K16.mask_mul(g, y2, 1.0, 0.2)                                    # 1/sqrt2 * lrelu' * sqrt2 on the conv2 branch (g also feeds the skip branch)
+            g_t = blk['c2'].dgrad(gm, (h + 1, h + 1))
+            del gm
+            g_y1 = K16.upfirdn2d(g_t, blk['kf'], pad=(1, 1, 1, 1), mask=y1, mask_vals=LRELU_MASK)
+            del g_t
+            g_a = blk['c1'].dgrad(g_y1, in_hw)
+            del g_y1
+            g_ts = blk['sk1'].dgrad(g, (h // 2, h // 2), out_gain=1.0 / SQRT2)
+            g = K16.upfirdn2d(g_ts, blk['kf'], up=2, pad=(2, 1, 2, 1), addend=g_a)      # adjoint of (blur, every second pixel): zero-insertion FIR
+            del g_ts, g_a
+        g_img = net.conv0.dgrad(K16.mask_mul(g, saved[0], *LRELU_MASK), ctx.in_hw, out_f32=True)
+        ctx.saved = None
+        return g_img, None
+
+
+# =====================================================================================================================================
+# StyleGAN2 generator (generator.py)
+# =====================================================================================================================================
+class _StyledLayer16:
+    def __init__(self, P, prefix, cin, cout, upsample, device):
+        w = torch.as_tensor(np.asarray(P[prefix + '.conv.weight']), dtype=torch.float32)[0]
+        ws = w * (1.0 / math.sqrt(cin * 9))
+        self.cin, self.cout, self.up = cin, cout, upsample
+        self.conv = C.H8Conv(ws, stride=2 if upsample else 1, padding=0 if upsample else 1, transposed=upsample, device=device)
+        wt = ws.transpose(0, 1).contiguous()
+        # fp32 weights in plane order: the style (forward) / the demodulation factor (backward) is folded in per sample (l2i_modulate_planes_h8)
+        self.w32_fwd = C.pack_weight_h8_f32(ws).to(device)
+        self.w32_bwd = C.pack_weight_h8_f32(wt if upsample else torch.flip(wt, [2, 3])).to(device)
+        self.T = (ws * ws).sum((2, 3)).contiguous().to(device)
+        self.mod = _Mod(P, prefix + '.conv', device)
+        self.noise_w = float(np.asarray(P[prefix + '.noise.weight']).reshape(-1)[0])
+        self.bias = _t(P[prefix + '.activate.bias'], device)
+        if upsample:
+            self.blur_k = _t(P[prefix + '.conv.blur.kernel'], device)
+            self.blur_k_flip = torch.flip(self.blur_k, [0, 1]).contiguous()
+
+
+class Generator(_Generator32):
+    def __init__(self, state, size, device='cuda', style_dim=512, n_mlp=8, lr_mlp=0.01):
+        self.size, self.device, self.style_dim = size, device, style_dim
+        self.log_size = int(math.log2(size))
+        self.n_latent = self.log_size * 2 - 2
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        P = state
+        self.mlp = []
+        for i in range(1, n_mlp + 1):
+            w = _t(P['style.%d.weight' % i], device)
+            self.mlp.append(((w * ((1.0 / math.sqrt(w.shape[1])) * lr_mlp)).t().contiguous(), _t(P['style.%d.bias' % i], device) * lr_mlp))
+        self.const = _t(P['input.input'], device)
+        self.const16 = C.to_h8(self.const)                                     # [1, 64, 4, 4, 8]
+        geo, _ = specs.generator_geometry(size)
+        self.layers = [_StyledLayer16(P, name, cin, cout, up, device) for name, cin, cout, res, up in geo]
+        self.rgbs = [_ToRGB(P, 'to_rgb1', geo[0][2], False, device)]
+        for j in range(self.log_size - 2):
+            self.rgbs.append(_ToRGB(P, 'to_rgbs.%d' % j, geo[2 + 2 * j][2], True, device))
+        self.randomize_noise = True
+        self.modplan = _ModPlan(self, device)
+
+    def synthesis(self, latent, noise=None):
+        return _Synthesis16Fn.apply(latent, self, noise)
+
+
+class _Synthesis16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, latent, gen, noise):
+        B = latent.shape[0]
+        dev = latent.device
+        lat = latent.detach()
+        keep = latent.requires_grad
+        saved = []
+        plan = gen.modplan
+        s_all, d_all, w_all = plan.forward(lat.contiguous())
+        x = gen.const16.expand(B, -1, -1, -1, -1).contiguous()
+        skip = None
+        lr = dict(act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
+        for li, L in enumerate(gen.layers):
+            s, demod = plan.s(s_all, B, li), plan.demod(d_all, B, li)
+            h = x.shape[2]
+            res = h * 2 if L.up else h
+            nz = _noise_for(gen, noise, li, B, res, dev)
+            planes = K16.modulate_planes(L.w32_fwd, s)                         # weight * style, one plane set per sample (networks.py:234-235)
+            bstride = planes[0].numel() * 2
+            if L.up:
+                t = L.conv.forward(x, planes=planes, w_bstride=bstride, out_scale=demod)          # (2H+1)^2
+                y = K16.upfirdn2d(t, L.blur_k, pad=(1, 1, 1, 1), noise=nz, noise_w=L.noise_w, bias=L.bias, **lr)
+                del t
+            else:
+                y = L.conv.forward(x, planes=planes, w_bstride=bstride, out_scale=demod, noise=nz, noise_w=L.noise_w, bias=L.bias, **lr)
+            del planes
+            rec = dict(x=x if keep else None, y=y if keep else None, s=s, demod=demod, nz=nz)
+            if li == 0 or (li % 2 == 0):
+                R = gen.rgbs[li // 2]
+                wmod = plan.wmod(w_all, B, li // 2)
+                rgb = K16.torgb_fwd(y, wmod, R.bias)                           # fp32 [B,3,H,W]: the skip image stays fp32
+                skip = K.upfirdn2d(skip, R.up_k, up=(2, 2), pad=(2, 1, 2, 1), addend=rgb) if R.up else rgb
+                rec['wmod'] = wmod
+            saved.append(rec)
+            x = y
+        ctx.gen, ctx.saved, ctx.B = gen, saved if keep else None, B
+        ctx.mod = (s_all, d_all) if keep else None
+        return skip
+
+    @staticmethod
+    def backward(ctx, g_img):
+        gen, saved, B = ctx.gen, ctx.saved, ctx.B
+        if saved is None:
+            raise RuntimeError('synthesis was run without a differentiable latent')
+        dev = g_img.device
+        plan = gen.modplan
+        s_all, d_all = ctx.mod
+        red_dz, q_all, red_rgb = plan.reductions(B, dev)
+        n_rgb = len(gen.rgbs)
+        g_rgb = [None] * n_rgb
+        g = g_img.contiguous()
+        for j in range(n_rgb - 1, -1, -1):
+            g_rgb[j] = g
+            if j > 0:
+                g = K.upfirdn2d(g, gen.rgbs[j].up_k_flip, up=(1, 1), down=(2, 2), pad=(1, 1, 1, 1))
+        gin, gin_scale = None, None
+        for li in range(len(gen.layers) - 1, -1, -1):
+            L, rec = gen.layers[li], saved[li]
+            has_rgb = 'wmod' in rec
+            grgb = g_rgb[li // 2] if has_rgb else None
+            dz = K16.sg2_act_bwd(rec['y'], gin, gin_scale, grgb, rec.get('wmod'), L.bias, rec['nz'], L.noise_w, 0.2, SQRT2,
+                                 plan.demod(red_dz, B, li), plan.red_rgb(red_rgb, B, li // 2) if has_rgb else None)
+            demod, s = rec['demod'], rec['s']
+            x = rec['x']
+            hw = (x.shape[2], x.shape[3])
+            planes = K16.modulate_planes(L.w32_bwd, demod)                     # the gradient conv's weights carry the demodulation factor
+            bstride = planes[0].numel() * 2
+            if L.up:
+                dt = K16.upfirdn2d(dz, L.blur_k_flip, pad=(2, 2, 2, 2))        # gradient of the (2H+1)^2 map under the blur
+                del dz
+                dxmod = L.conv.dgrad(dt, hw, planes=planes, w_bstride=bstride)
+                del dt
+            else:
+                dxmod = L.conv.dgrad(dz, hw, planes=planes, w_bstride=bstride)
+                del dz
+            del planes
+            K16.dot_reduce(dxmod, x, out=plan.s(q_all, B, li).view(-1))          # d s via x * s
+            gin, gin_scale = dxmod, s
+            rec['y'] = rec['x'] = None
+        g_lat = plan.backward(B, s_all, d_all, red_dz, q_all, red_rgb)
+        return g_lat, None, None

@@ -1,0 +1,111 @@
+"""Tolerance study of the 16-bit path (conv.PRECISION = 'bf16': bf16 h8 feature maps, one bf16 MFMA per MAC) against the float64 CPU oracle on
+the same z / weights: per network (forward and input gradient) and for whole training steps at 64^2 (batch 4), 256^2 (batch 2), 1024^2 (batch 1).
+Prints one JSON line per case; profiles/r03_bf16_tolerance.json is this script's output on the MI355X.  usage: python tools/bf16_study.py [sizes]"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from latent2im_amd import conv, selfcheck, synth
+from oracle import nets as onets, sg2, step as ostep
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+DEV = 'cuda'
+torch.set_num_threads(min(32, os.cpu_count() or 1))
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def cosine(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float(torch.dot(a, b) / (a.norm() * b.norm()))
+
+
+def l2rel(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm())
+
+
+def networks(size, batch):
+    from latent2im_amd import nets16
+    out = dict(case='networks', size=size, batch=batch)
+    dt = torch.float64
+    rs = np.random.RandomState(size)
+    stG = synth.generator_state(size, seed=100, noise_strength=0.05)
+    G = nets16.Generator(stG, size, device=DEV)
+    PG = ostep.to_torch(stG, dt)
+    lat = rs.randn(batch, G.n_latent, 512)
+    noise = synth.noise_maps(size, batch)
+    gy = rs.randn(batch, 3, size, size)
+    lg = T(lat).float().to(DEV).requires_grad_(True)
+    img = G.synthesis(lg, [T(n).to(DEV) for n in noise])
+    img.backward(T(gy).float().to(DEV))
+    lo = T(lat).requires_grad_(True)
+    img_o = sg2.generator_synthesis(PG, lo, [T(n).double() for n in noise])
+    go, = torch.autograd.grad(img_o, lo, T(gy))
+    out.update(G_img_relmax=rel(img, img_o), G_img_l2=l2rel(img, img_o), G_grad_cos=cosine(lg.grad, go), G_grad_l2=l2rel(lg.grad, go))
+    x = img_o.detach()
+    for name, net, fwd in (('R', nets16.ResNet50(synth.resnet50_state(seed=300), device=DEV), lambda P, t: onets.resnet50_forward(P, t)),
+                           ('D', nets16.Discriminator(synth.discriminator_state(size, seed=200), size, device=DEV), lambda P, t: sg2.discriminator_forward(P, t))):
+        P = ostep.to_torch(synth.resnet50_state(seed=300) if name == 'R' else synth.discriminator_state(size, seed=200), dt)
+        xg = x.float().to(DEV).requires_grad_(True)
+        y = net(xg)
+        gyy = T(rs.randn(*y.shape))
+        y.backward(gyy.float().to(DEV))
+        xo = x.clone().requires_grad_(True)
+        yo = fwd(P, xo)
+        gxo, = torch.autograd.grad(yo, xo, gyy)
+        out.update({name + '_out_relmax': rel(y, yo), name + '_grad_cos': cosine(xg.grad, gxo), name + '_grad_l2': l2rel(xg.grad, gxo)})
+    stV = synth.vgg19_prefix_state(seed=400)
+    V = nets16.VGG19Prefix(stV, device=DEV)
+    other = torch.roll(x, 5, 3)
+    xg = x.float().to(DEV).requires_grad_(True)
+    losses = V.content_losses(other.float().to(DEV), xg)
+    losses.sum().backward()
+    xo = x.clone().requires_grad_(True)
+    _, lo_ = ostep.content_loss(ostep.to_torch(stV, dt), other, xo)
+    gxo, = torch.autograd.grad(sum(lo_), xo)
+    out.update(V_loss_rel=[float(abs(float(a) - float(b)) / float(b)) for a, b in zip(losses, lo_)], V_grad_cos=cosine(xg.grad, gxo), V_grad_l2=l2rel(xg.grad, gxo))
+    return out
+
+
+def step(size, batch, attrs, clamp, transform='face'):
+    from latent2im_amd import constants
+    conv.PRECISION = 'bf16'
+    gr = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform=transform)
+    zs = synth.z_sample(batch, seed=21)
+    rs = np.random.RandomState(22)
+    alpha = np.ones((batch, len(attrs))) * (rs.uniform(-1, 1, len(attrs)) if clamp else rs.uniform(0, 1, len(attrs)))
+    r = selfcheck.run_step(gr, zs, alpha, clamp=clamp, optimize=False)
+    torch.cuda.synchronize()
+    dt = torch.float64
+    nets = dict(G=ostep.to_torch(synth.generator_state(size, seed=100), dt), D=ostep.to_torch(synth.discriminator_state(size, seed=200), dt),
+                R=ostep.to_torch(synth.resnet50_state(seed=300), dt), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400), dt))
+    o = ostep.train_step_bounded(nets, T(synth.walk_init(len(attrs), gr.module.netG.n_latent, seed=7)).to(dt), T(zs).to(dt), T(alpha).to(dt), gr.attrIdx, clamp_variant=clamp)
+    idx = gr.attrIdx
+    pg = gr.regressor(r['x1'])[:, idx].double().cpu()
+    po = onets.resnet50_forward(nets['R'], o['x1'])[:, idx].double()
+    tgt = o['target'].double()
+    per_attr = lambda p: -(tgt * p.clamp(min=1e-12).log() + (1 - tgt) * (1 - p).clamp(min=1e-12).log()).mean(0)
+    out = dict(case='step', size=size, batch=batch, attrs=len(attrs), clamp=clamp,
+               x0_relmax=rel(r['x0'], o['x0']), x1_relmax=rel(r['x1'], o['x1']), x1_l2=l2rel(r['x1'], o['x1']),
+               a0_absmax=float((r['a0'].double().cpu() - o['alpha_org']).abs().max()), eps_absmax=float((r['eps'].double().cpu() - o['eps']).abs().max()),
+               reg_rel=abs(float(r['terms']['reg']) - float(o['reg'])) / abs(float(o['reg'])), cont_rel=abs(float(r['terms']['cont']) - float(o['cont'])) / abs(float(o['cont'])),
+               gan_rel=abs(float(r['terms']['gan']) - float(o['gan'])) / abs(float(o['gan'])), loss_rel=abs(float(r['loss']) - float(o['loss'])) / abs(float(o['loss'])),
+               per_attr_reg_loss_delta=[float(v) for v in (per_attr(pg) - per_attr(po)).abs()], per_attr_reg_loss=[float(v) for v in per_attr(po)],
+               grad_cos=cosine(r['grad'], o['grad']), grad_l2=l2rel(r['grad'], o['grad']), grad_relmax=rel(r['grad'], o['grad']))
+    constants.resolution, constants.BATCH_SIZE = 256, 4
+    return out
+
+
+if __name__ == '__main__':
+    sizes = [int(s) for s in sys.argv[1].split(',')] if len(sys.argv) > 1 else [64, 256, 1024]
+    for size in sizes:
+        batch = {64: 4, 256: 2, 1024: 1}.get(size, 1)
+        if size <= 256:
+            print(json.dumps(networks(size, min(batch, 2))), flush=True)
+        print(json.dumps(step(size, batch, ['Smiling'], False)), flush=True)
+        print(json.dumps(step(size, batch, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], True, 'scene')), flush=True)
