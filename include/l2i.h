@@ -164,8 +164,10 @@ int l2i_cast_f32_to_h8(void* y, const float* x, int B, int C, int Cpad, int64_t 
 int l2i_cast_h8_to_f32(float* y, const void* x, int B, int C, int Cpad, int64_t HW, void* stream);
 int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
-                     float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, void* stream);
-                     /* ... then * (mask > 0 ? mask_pos : mask_neg) (h8, like y: a gradient through a (leaky) ReLU) and + addend (h8, like y) */
+                     float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, void* stream);
+                     /* ... then * (mask > 0 ? mask_pos : mask_neg) (h8, like y: a gradient through a (leaky) ReLU) and + addend (h8, like y).
+                        k1y / k1x: HOST pointers to four floats each, or NULL: the caller states that k = outer(k1y, k1x) (4x4, up = down = 1: the
+                        register-streaming separable kernel) */
 int l2i_torgb_fwd_h8(float* rgb, const void* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream);
 int l2i_sg2_act_bwd_h8(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
                        const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream);

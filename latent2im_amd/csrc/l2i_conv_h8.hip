@@ -21,6 +21,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "l2i.h"
 #include "l2i_internal.h"
@@ -31,7 +32,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace g8 {
-template <int WN, int K, int S, int TR> struct Geo {
+template <int WN, int K, int S, int TR, int KS_ = 2> struct Geo {
     static constexpr int TH = 4 * WN;
     static constexpr bool GATHER = (K == 1 && S == 2);                    // 1x1 stride 2: only even rows / columns are staged
     static constexpr int ROWS = TR ? TH + 1 : (GATHER ? TH : (TH - 1) * S + K);
@@ -41,7 +42,7 @@ template <int WN, int K, int S, int TR> struct Geo {
     static constexpr bool SPLIT = (S == 2 && !GATHER);                    // even columns first, odd columns from RPH on
     static constexpr int RPH = (COLS + 1) / 2;
     static constexpr int RP = COLS;
-    static constexpr int KS = 2;                                          // 16-channel MFMA steps per chunk
+    static constexpr int KS = KS_;                                        // 16-channel MFMA steps per chunk (1: low-Cin layers, half the LDS, four blocks per CU)
     static constexpr int NH = 2 * KS;                                     // 8-channel groups per chunk
     static constexpr int CK = 16 * KS;
     static constexpr int HSTRIDE = ROWS * RP;                             // slots of one 8-channel group
@@ -172,9 +173,9 @@ __device__ __forceinline__ void h8_gather(const f32x16& a, int pr, int half, flo
 // RELU_IN: pro(x) = max(x, 0) on the B fragments (VGG-19: a conv reads the PRE-ReLU tap of the layer below, which is what the ContentLoss
 // and the backward masks need in HBM): four v_pk_max_i16 per fragment — a negative bf16 is a negative int16, so the integer max with 0 is
 // the ReLU (and -0 -> +0) — beside the bf16 MFMAs, whose pipe the VALU does not share
-template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false>
-__global__ __launch_bounds__(256, 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
-    using G = g8::Geo<WN, K, S, TR>;
+template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false, int KS = 2>
+__global__ __launch_bounds__(256, (KS == 1 && TR == 0) ? 4 : 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
+    using G = g8::Geo<WN, K, S, TR, KS>;
     constexpr int NACC = TR ? 4 : 1;
     constexpr int DMIN = (TR == 1) ? -1 : 0;
     constexpr int BM = WM * 32;
@@ -379,9 +380,9 @@ __global__ __launch_bounds__(256, 2) void conv_h8_kernel(const l2i_conv_params p
 }
 
 // ------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false>
+template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false, int KS = 2>
 static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
-    using G = g8::Geo<WN, K, S, TR>;
+    using G = g8::Geo<WN, K, S, TR, KS>;
     constexpr int BM = WM * 32;
     constexpr int WSLOTS = K * G::KS * 2 * BM;
     H8Launch L;
@@ -398,11 +399,11 @@ static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
     if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: tile does not fit the LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     const unsigned grid = (unsigned)((total + 7) & ~7L);
-    hipLaunchKernelGGL((conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN>), dim3(grid), dim3(256), lds, st, p, L);
+    hipLaunchKernelGGL((conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN, KS>), dim3(grid), dim3(256), lds, st, p, L);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }
@@ -414,7 +415,7 @@ static int h8_common_checks(const l2i_conv_params& p, const char* who) {
     const bool relu_in = p.in_mask && (const void*)p.in_mask == (const void*)p.x && p.mask_pos == 1.f && p.mask_neg == 0.f && !p.out_mask;
     if (p.in_scale || (p.in_mask && !relu_in))
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: no prologue fusions (scales live in the weights, masks in the producing epilogue) except ReLU-on-load (in_mask == x)");
-    if ((p.Cin % 32) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: Cin must be a multiple of 32");
+    if ((p.Cin % 16) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: Cin must be a multiple of 16");
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
     if (!al16(p.x) || !al16(p.w_hi) || !al16(p.y) || !al16(p.residual) || !al16(p.res_mask) || !al16(p.res_sub) || !al16(p.out_mask) || !al16(p.sq_ref) ||
         !al16(p.bias) || !al16(p.out_scale) || (p.w_bstride % 16) != 0)
@@ -441,15 +442,26 @@ extern "C" int l2i_conv2d_h8(const l2i_conv_params* pp, void* stream) {
     if (p.out_f32) {                                       // fp32 NCHW output (gradients landing on images, the last layer in front of an fp32 consumer)
         if (p.in_mask) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: ReLU-on-load needs the h8 output");
         if (p.sq_ref) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: sq_ref needs the h8 output");
+        if ((p.Cin % 32) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: fp32 output needs Cin % 32 == 0");
         if (p.KH == 3 && p.stride == 1) return wide ? launch_h8<2, 2, 3, 1, 0, true>(p, st) : launch_h8<1, 2, 3, 1, 0, true>(p, st);
         if (p.KH == 1 && p.stride == 1) return wide ? launch_h8<2, 2, 1, 1, 0, true>(p, st) : launch_h8<1, 2, 1, 1, 0, true>(p, st);
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: fp32 output is built for stride-1 layers");
     }
     if ((p.Cout % 8) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: h8 output needs Cout % 8 == 0");
+    // K chunk of the 3x3 stride-1 layers: 16 channels (one MFMA step per tap) — half the LDS per block puts FOUR blocks on a CU, and it is the number
+    // of tiles in flight that fills the memory pipeline on the HBM-bound high-resolution layers (64 -> 64 @1024^2: 738 against 663 TFLOP/s) and
+    // hides the per-phase barriers on the others (512 -> 512 @64^2: 1188 against 1135); 32 channels only for 512 channels on <= 32^2 maps
+    static const int ks_env = getenv("L2I_H8_KS") ? atoi(getenv("L2I_H8_KS")) : 0;
+    const bool ks1 = (p.Cin % 32) != 0 || (ks_env ? ks_env == 1 : (p.Cin <= 256 || p.OW > 32));    // measured per shape (tools/probes/h8_bench.py): 16 wins everywhere but 512 channels on <= 32^2 maps
     if (p.in_mask) {                                       // ReLU-on-load: the 3x3 stride-1 layers of VGG-19
-        if (p.KH == 3 && p.stride == 1) return wide ? launch_h8<2, 2, 3, 1, 0, false, true>(p, st) : launch_h8<1, 2, 3, 1, 0, false, true>(p, st);
+        if (p.KH == 3 && p.stride == 1) {
+            if (ks1) return wide ? launch_h8<2, 2, 3, 1, 0, false, true, 1>(p, st) : launch_h8<1, 2, 3, 1, 0, false, true, 1>(p, st);
+            return wide ? launch_h8<2, 2, 3, 1, 0, false, true>(p, st) : launch_h8<1, 2, 3, 1, 0, false, true>(p, st);
+        }
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: ReLU-on-load is built for 3x3 stride-1 layers");
     }
+    if (p.KH == 3 && p.stride == 1 && ks1) return wide ? launch_h8<2, 2, 3, 1, 0, false, false, 1>(p, st) : launch_h8<1, 2, 3, 1, 0, false, false, 1>(p, st);
+    if ((p.Cin % 32) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: Cin % 32 == 0 except for 3x3 stride-1 layers (Cin % 16 == 0)");
     if (p.KH == 3 && p.stride == 1) return wide ? launch_h8<2, 2, 3, 1, 0, false>(p, st) : launch_h8<1, 2, 3, 1, 0, false>(p, st);
     if (p.KH == 1 && p.stride == 1) return wide ? launch_h8<2, 2, 1, 1, 0, false>(p, st) : launch_h8<1, 2, 1, 1, 0, false>(p, st);
     if (p.KH == 3 && p.stride == 2) return wide ? launch_h8<2, 1, 3, 2, 0, false>(p, st) : launch_h8<1, 1, 3, 2, 0, false>(p, st);
@@ -461,6 +473,7 @@ extern "C" int l2i_conv_transpose2d_h8(const l2i_conv_params* pp, void* stream) 
     const l2i_conv_params& p = *pp;
     if (int rc = h8_common_checks(p, "conv_transpose2d_h8")) return rc;
     const int nat = (p.H - 1) * 2 - 2 * p.pad_y + 3, natw = (p.W - 1) * 2 - 2 * p.pad_x + 3;
+    if ((p.Cin % 32) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d_h8: Cin must be a multiple of 32");
     if (p.KH != 3 || p.KW != 3 || p.stride != 2 || p.pad_y != p.pad_x || p.pad_x < 0 || p.pad_x > 1 || p.OHf < nat || p.OHf > nat + 8 || p.OWf < natw || p.OWf > natw + 8 ||
         p.OH != (p.OHf + 1) / 2 || p.OW != (p.OWf + 1) / 2 || p.out_f32 || (p.Cout % 8) != 0 || p.sq_ref || p.in_mask)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d_h8: 3x3 stride-2 layer (pad 0 or 1), natural output size (or up to 8 larger), h8 output");

@@ -137,15 +137,109 @@ __global__ __launch_bounds__(256) void upfirdn2d_h8_kernel(u32x4* __restrict__ y
         y[i] = pack8(acc);
     }
 }
+// Separable 4x4 FIR without resampling (up = down = 1: the blurs of the generator's up layers and of the discriminator, forward and backward — 90 %
+// of the FIR bytes), register-streaming: a lane owns one output column and walks RB output rows downwards; per INPUT row it loads the four
+// slots of its horizontal window (neighbouring lanes overlap: L1 hits), forms the horizontal sum once and keeps the last four of them in
+// registers for the vertical sum — 4 loads and 8 multiply-adds per output instead of 16 and 16.  Same fused epilogue as the generic kernel.
+template <int RB>
+__global__ __launch_bounds__(256) void upfirdn2d_h8_sep4_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ x, float4 ty, float4 tx, long long planes, int G8, int in_h, int in_w,
+                                                                int out_h, int out_w, int pad_x0, int pad_y0, const float* __restrict__ noise, float noise_w,
+                                                                const float* __restrict__ bias, int act, float slope, float gain, const u32x4* __restrict__ mask, float mpos,
+                                                                float mneg, const u32x4* __restrict__ addend) {
+    const int bands = (out_h + RB - 1) / RB;
+    const long long total = planes * bands * out_w;
+    const float txa[4] = {tx.x, tx.y, tx.z, tx.w}, tya[4] = {ty.x, ty.y, ty.z, ty.w};
+    for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long long)gridDim.x * 256) {
+        const int ox = (int)(u % out_w);
+        const long long pb = u / out_w;
+        const int band = (int)(pb % bands);
+        const long long pl = pb / bands;
+        const int r0 = band * RB;
+        const u32x4* xp = x + pl * in_h * in_w;
+        const int ix0 = ox - pad_x0;
+        const int g = (int)(pl % G8);
+        const long long b = pl / G8;
+        float bs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] = bias ? bias[8 * g + e] : 0.f;
+        float ring[4][8];
+#pragma unroll
+        for (int r = 0; r < RB + 3; ++r) {
+            const int iy = r0 - pad_y0 + r;
+            float hrow[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hrow[e] = 0.f;
+            if (iy >= 0 && iy < in_h && r0 + r - 3 < out_h + 3) {
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int ix = ix0 + kx;
+                    if (ix >= 0 && ix < in_w) {
+                        float v[8];
+                        unpack8(xp[(long long)iy * in_w + ix], v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hrow[e] += txa[kx] * v[e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ring[r & 3][e] = hrow[e];
+            if (r >= 3) {
+                const int oy = r0 + r - 3;
+                if (oy < out_h) {
+                    float acc[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        acc[e] = tya[0] * ring[(r - 3) & 3][e] + tya[1] * ring[(r - 2) & 3][e] + tya[2] * ring[(r - 1) & 3][e] + tya[3] * ring[r & 3][e];
+                    const long long o = (pl * out_h + oy) * out_w + ox;
+                    if (noise || bias || act != L2I_ACT_NONE || gain != 1.f) {
+                        const float nz = noise ? noise[(b * out_h + oy) * out_w + ox] * noise_w : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float v = acc[e] + nz + bs[e];
+                            if (act == L2I_ACT_LRELU) v = v > 0.f ? v : v * slope;
+                            else if (act == L2I_ACT_RELU) v = v > 0.f ? v : 0.f;
+                            acc[e] = v * gain;
+                        }
+                    }
+                    if (mask) {
+                        float m[8];
+                        unpack8(mask[o], m);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] *= m[e] > 0.f ? mpos : mneg;
+                    }
+                    if (addend) {
+                        float a[8];
+                        unpack8(addend[o], a);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] += a[e];
+                    }
+                    y[o] = pack8(acc);
+                }
+            }
+        }
+    }
+}
+
 extern "C" int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
                                 int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
-                                float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, void* stream) {
+                                float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, void* stream) {
     if (!y || !x || !k) return l2i_set_error(L2I_E_ARG, "upfirdn2d_h8: null tensor");
     if (planes <= 0 || channels <= 0 || (channels % 8) != 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0 || kh > 4 || kw > 4 || (up != 1 && up != 2) || (down != 1 && down != 2))
         return l2i_set_error(L2I_E_ARG, "upfirdn2d_h8: kernels up to 4x4, up / down in {1, 2}, channels % 8 == 0");
     const int out_h = (in_h * up + pad_y0 + pad_y1 - kh) / down + 1, out_w = (in_w * up + pad_x0 + pad_x1 - kw) / down + 1;
     if (out_h <= 0 || out_w <= 0) return l2i_set_error(L2I_E_ARG, "upfirdn2d_h8: empty output");
     const long long total = (long long)planes * out_h * out_w;
+    if (k1y && k1x && kh == 4 && kw == 4 && up == 1 && down == 1) {
+        // the caller vouches that k = outer(k1y, k1x) (the path's blurs: [1,3,3,1] x [1,3,3,1] * gain); taps of the flipped kernel
+        constexpr int RB = 16;
+        const float4 ty = make_float4(k1y[3], k1y[2], k1y[1], k1y[0]), tx = make_float4(k1x[3], k1x[2], k1x[1], k1x[0]);
+        const long long units = (long long)planes * ((out_h + RB - 1) / RB) * out_w;
+        hipLaunchKernelGGL((upfirdn2d_h8_sep4_kernel<RB>), dim3(l2i_grid_for(units, 256, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)x, ty, tx,
+                           (long long)planes, channels / 8, in_h, in_w, out_h, out_w, pad_x0, pad_y0, noise, noise_w, bias, act, act_slope, act_gain, (const u32x4*)mask,
+                           mask_pos, mask_neg, (const u32x4*)addend);
+        L2I_CHECK_LAUNCH();
+        return L2I_OK;
+    }
     hipLaunchKernelGGL(upfirdn2d_h8_kernel, dim3(l2i_grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)x, k, (long long)planes,
                        channels / 8, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_x0, pad_y0, noise, noise_w, bias, act, act_slope, act_gain, (const u32x4*)mask, mask_pos,
                        mask_neg, (const u32x4*)addend);

@@ -1,11 +1,30 @@
 """Python call wrappers for the streaming kernels of the 16-bit path (csrc/l2i_stream_h8.hip, include/l2i.h): bf16 tensors in the
 channel-blocked h8 layout [B, C/8, H, W, 8] in, out; fp32 for images, noise, bias, per-sample vectors and reductions.  No autograd here."""
+import ctypes
+
 import torch
 
 from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU  # noqa: F401
 
 BF = torch.bfloat16
+
+
+def separable(kernel):
+    """(k1y, k1x) with kernel == outer(k1y, k1x) (to float32 rounding), or None: computed ONCE from a host copy of a constant FIR kernel (the
+    networks do it at construction: [1,3,3,1] x [1,3,3,1] / 64 times the up-sampling gain) and handed to ``upfirdn2d(..., sep=...)``, which then
+    takes the register-streaming separable kernel; nothing is read back from the device per call."""
+    import numpy as np
+    k = np.asarray(kernel.detach().float().cpu().numpy() if torch.is_tensor(kernel) else kernel, dtype=np.float64)
+    if k.shape != (4, 4):
+        return None
+    i, j = divmod(int(np.abs(k).argmax()), 4)
+    if k[i, j] == 0:
+        return None
+    ky, kx = k[:, j] / k[i, j], k[i, :].copy()
+    if not np.allclose(np.outer(ky, kx), k, rtol=1e-6, atol=0):
+        return None
+    return [float(v) for v in ky], [float(v) for v in kx]
 
 
 def _h8(t):
@@ -33,18 +52,22 @@ def cast_from_h8(t, channels=None):
 
 
 def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0, 0, 0), noise=None, noise_w=0.0, bias=None, act=ACT_NONE, slope=0.2, gain=1.0, mask=None, mask_vals=(1.0, 0.0),
-              addend=None):
+              addend=None, sep=None):
     """x h8; pad = (x0, x1, y0, y1) as in op/upfirdn2d.cpp:12-23; optional fused epilogue act(fir(x) + noise*noise_w + bias[c]) * gain, then
-    * (mask > 0 ? mask_vals[0] : mask_vals[1]) and + addend (both h8, shaped like the output)."""
+    * (mask > 0 ? mask_vals[0] : mask_vals[1]) and + addend (both h8, shaped like the output).  ``sep`` = separable(kernel) (4x4, no resampling): the
+    register-streaming separable kernel."""
     lib = _lib.load()
     B, G8, H, W, _ = x.shape
     kh, kw = kernel.shape
     oh = (H * up + pad[2] + pad[3] - kh) // down + 1
     ow = (W * up + pad[0] + pad[1] - kw) // down + 1
     y = torch.empty(B, G8, oh, ow, 8, device=x.device, dtype=BF)
+    use_sep = sep is not None and kh == 4 and kw == 4 and up == 1 and down == 1
+    k1y = (ctypes.c_float * 4)(*sep[0]) if use_sep else None
+    k1x = (ctypes.c_float * 4)(*sep[1]) if use_sep else None
     _lib.check(lib.l2i_upfirdn2d_h8(_lib.ptr(y), _h8(x), _lib.fptr(kernel.contiguous()), B * G8, G8 * 8, H, W, kh, kw, up, down, pad[0], pad[1], pad[2], pad[3],
                                     _lib.fptr(noise), float(noise_w), _lib.fptr(bias), int(act), float(slope), float(gain), None if mask is None else _h8(mask),
-                                    float(mask_vals[0]), float(mask_vals[1]), None if addend is None else _h8(addend), _lib.stream_ptr()), 'l2i_upfirdn2d_h8')
+                                    float(mask_vals[0]), float(mask_vals[1]), None if addend is None else _h8(addend), k1y, k1x, _lib.stream_ptr()), 'l2i_upfirdn2d_h8')
     assert (mask is None or mask.shape == y.shape) and (addend is None or addend.shape == y.shape)
     return y
 

@@ -212,6 +212,7 @@ class Discriminator(_Discriminator32):
                        c2=_eq16(P, p + '.conv2.1.weight', 2, 0, device), b2=_vec(P, p + '.conv2.2.bias', device),
                        sk1=_eq16(P, p + '.skip.1.weight', 1, 0, device), k=_vec(P, p + '.conv2.0.kernel', device))
             blk['kf'] = torch.flip(blk['k'], [0, 1]).contiguous()
+            blk['ksep'], blk['kfsep'] = K16.separable(np.asarray(P[p + '.conv2.0.kernel'])), K16.separable(np.asarray(P[p + '.conv2.0.kernel'])[::-1, ::-1])
             self.blocks.append(blk)
         self.final_conv = _eq_conv(P, 'final_conv.0.weight', 1, 1, device)
         self.final_bias = _vec(P, 'final_conv.1.bias', device)
@@ -238,7 +239,7 @@ class _DBody16Fn(torch.autograd.Function):
         for blk in net.blocks:
             h = cur.shape[2]
             y1 = blk['c1'].forward(cur, bias=blk['b1'], **lr)
-            t = K16.upfirdn2d(y1, blk['k'], pad=(2, 2, 2, 2))                    # Blur before the stride-2 3x3 (networks.py:530-536): (h+1)^2
+            t = K16.upfirdn2d(y1, blk['k'], pad=(2, 2, 2, 2), sep=blk['ksep'])  # Blur before the stride-2 3x3 (networks.py:530-536): (h+1)^2
             y2 = blk['c2'].forward(t, bias=blk['b2'], **lr)
             del t
             ts = K16.upfirdn2d(cur, blk['k'], down=2, pad=(1, 1, 1, 1))          # skip (networks.py:586-590): the blur only where the stride-2 1x1 samples it
@@ -261,7 +262,7 @@ class _DBody16Fn(torch.autograd.Function):
             gm = K16.mask_mul(g, y2, 1.0, 0.2)                                    # 1/sqrt2 * lrelu' * sqrt2 on the conv2 branch (g also feeds the skip branch)
             g_t = blk['c2'].dgrad(gm, (h + 1, h + 1))
             del gm
-            g_y1 = K16.upfirdn2d(g_t, blk['kf'], pad=(1, 1, 1, 1), mask=y1, mask_vals=LRELU_MASK)
+            g_y1 = K16.upfirdn2d(g_t, blk['kf'], pad=(1, 1, 1, 1), mask=y1, mask_vals=LRELU_MASK, sep=blk['kfsep'])
             del g_t
             g_a = blk['c1'].dgrad(g_y1, in_hw)
             del g_y1
@@ -293,6 +294,8 @@ class _StyledLayer16:
         if upsample:
             self.blur_k = _t(P[prefix + '.conv.blur.kernel'], device)
             self.blur_k_flip = torch.flip(self.blur_k, [0, 1]).contiguous()
+            kk = np.asarray(P[prefix + '.conv.blur.kernel'])
+            self.blur_sep, self.blur_flip_sep = K16.separable(kk), K16.separable(kk[::-1, ::-1])
 
 
 class Generator(_Generator32):
@@ -342,7 +345,7 @@ class _Synthesis16Fn(torch.autograd.Function):
             bstride = planes[0].numel() * 2
             if L.up:
                 t = L.conv.forward(x, planes=planes, w_bstride=bstride, out_scale=demod)          # (2H+1)^2
-                y = K16.upfirdn2d(t, L.blur_k, pad=(1, 1, 1, 1), noise=nz, noise_w=L.noise_w, bias=L.bias, **lr)
+                y = K16.upfirdn2d(t, L.blur_k, pad=(1, 1, 1, 1), noise=nz, noise_w=L.noise_w, bias=L.bias, sep=L.blur_sep, **lr)
                 del t
             else:
                 y = L.conv.forward(x, planes=planes, w_bstride=bstride, out_scale=demod, noise=nz, noise_w=L.noise_w, bias=L.bias, **lr)
@@ -389,7 +392,7 @@ class _Synthesis16Fn(torch.autograd.Function):
             planes = K16.modulate_planes(L.w32_bwd, demod)                     # the gradient conv's weights carry the demodulation factor
             bstride = planes[0].numel() * 2
             if L.up:
-                dt = K16.upfirdn2d(dz, L.blur_k_flip, pad=(2, 2, 2, 2))        # gradient of the (2H+1)^2 map under the blur
+                dt = K16.upfirdn2d(dz, L.blur_k_flip, pad=(2, 2, 2, 2), sep=L.blur_flip_sep)        # gradient of the (2H+1)^2 map under the blur
                 del dz
                 dxmod = L.conv.dgrad(dt, hw, planes=planes, w_bstride=bstride)
                 del dt
