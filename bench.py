@@ -151,7 +151,7 @@ def main():
     ap.add_argument('--dump_launches', type=str, default=None, help='write the per-launch table of the event pass (shape, family, ms, TFLOP/s) to this JSON file')
     ap.add_argument('--noise_strength', type=float, default=NOISE_STRENGTH, help='generator NoiseInjection weights (0: no noise drawn)')
     ap.add_argument('--sweep', type=str, default='1,2,4,8,16', help="batch sweep (BASELINE metric: 'batch sweep'): per-GPU batches timed eagerly after the "
-                    "headline, reported as `batch_sweep`; '' = off")
+                    "headline, reported as `batch_sweep`; 'none' = off")
     ap.add_argument('--sweep_steps', type=int, default=3)
     ap.add_argument('--rank_timeout_s', type=float, default=3600.0, help='--gpus N without a launcher: give up on the rank processes after this long')
     a = ap.parse_args()
@@ -251,7 +251,7 @@ def main():
 
     # batch sweep (the BASELINE metric is quoted over a batch sweep): the same eager step at other per-GPU batches, every rank
     sweep = None
-    if a.sweep:
+    if a.sweep and a.sweep not in ('0', 'none', 'off'):
         import gc
         captured = None
         gc.collect()

@@ -515,12 +515,12 @@ def pack_weight_h8_f32(w):
     return full.reshape(coutp, cinp // 16, 2, 8, kh * kw).permute(1, 4, 2, 0, 3).contiguous()
 
 
-def pack_weight_h8(w):
+def pack_weight_h8(w, cin_pad=32):
     """[Cout, Cin, KH, KW] fp32 -> bf16 plane [Cin/16][KH*KW][2][CoutP][8] (int16 view): the LDS image order of csrc/l2i_conv_h8.hip.
-    Cin is zero-padded to a multiple of 32 (the kernel's K chunk)."""
+    Cin is zero-padded to a multiple of ``cin_pad`` (32: the kernel's K chunk; 16 is enough for 3x3 stride-1 layers)."""
     w = torch.as_tensor(w, dtype=torch.float32)
     cout, cin, kh, kw = w.shape
-    cinp = (cin + 31) // 32 * 32
+    cinp = (cin + cin_pad - 1) // cin_pad * cin_pad
     if cinp != cin:
         w = torch.cat([w, w.new_zeros(cout, cinp - cin, kh, kw)], 1)
     return pack_weight_bf16x3(w)[0]
@@ -531,14 +531,14 @@ class H8Conv:
     TRANSPOSED conv (``transposed=True``: y[co, 2i+k-pad] += x[ci, i] w[co, ci, k], as FrozenConv2d).  Forward and input-gradient both run on
     l2i_conv2d_h8 / l2i_conv_transpose2d_h8; no weight gradients (the walk is the only trainable tensor)."""
 
-    def __init__(self, weight, stride=1, padding=0, transposed=False, device='cuda'):
+    def __init__(self, weight, stride=1, padding=0, transposed=False, device='cuda', cin_pad=32):
         w = torch.as_tensor(np.asarray(weight) if not torch.is_tensor(weight) else weight, dtype=torch.float32).cpu()
         self.cout, self.cin, self.k, _ = w.shape
         self.stride, self.padding, self.transposed, self.device = stride, padding, transposed, device
-        self.cinp, self.coutp_in = (self.cin + 31) // 32 * 32, (self.cout + 31) // 32 * 32
+        assert cin_pad == 32 or (cin_pad == 16 and self.k == 3 and stride == 1 and not transposed), 'a 16-channel chunk exists for 3x3 stride-1 layers only'
+        self.cinp, self.coutp_in = (self.cin + cin_pad - 1) // cin_pad * cin_pad, (self.cout + 31) // 32 * 32
         wt = w.transpose(0, 1).contiguous()
-        self.w_f32 = w                                               # kept for per-sample modulation (generator)
-        self.fwd_planes = pack_weight_h8(w).to(device)
+        self.fwd_planes = pack_weight_h8(w, cin_pad).to(device)
         if transposed or stride == 2:
             self.bwd_planes = pack_weight_h8(wt).to(device)          # transposed fwd: dx = corr_s2(gy, wt); stride-2 fwd: dx = transposed(gy, wt)
         else:
@@ -593,7 +593,7 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
     """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels."""
     lib = _lib.load()
     B, cg, H, W, _ = x.shape
-    assert x.dtype == torch.bfloat16 and cg * 8 == cin and cin % 32 == 0, (x.shape, cin)
+    assert x.dtype == torch.bfloat16 and cg * 8 == cin and cin % 16 == 0, (x.shape, cin)
     coutp = planes.shape[-2]
     assert planes.shape[-5] == cin // 16 and planes.shape[-4] == k * k and coutp >= cout, (planes.shape, cin, k, cout)
     if out_f32:

@@ -174,7 +174,7 @@ __device__ __forceinline__ void h8_gather(const f32x16& a, int pr, int half, flo
 // and the backward masks need in HBM): four v_pk_max_i16 per fragment — a negative bf16 is a negative int16, so the integer max with 0 is
 // the ReLU (and -0 -> +0) — beside the bf16 MFMAs, whose pipe the VALU does not share
 template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false, int KS = 2>
-__global__ __launch_bounds__(256, (KS == 1 && TR == 0) ? 4 : 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
+__global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
     using G = g8::Geo<WN, K, S, TR, KS>;
     constexpr int NACC = TR ? 4 : 1;
     constexpr int DMIN = (TR == 1) ? -1 : 0;
@@ -464,7 +464,11 @@ extern "C" int l2i_conv2d_h8(const l2i_conv_params* pp, void* stream) {
     if ((p.Cin % 32) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: Cin % 32 == 0 except for 3x3 stride-1 layers (Cin % 16 == 0)");
     if (p.KH == 3 && p.stride == 1) return wide ? launch_h8<2, 2, 3, 1, 0, false>(p, st) : launch_h8<1, 2, 3, 1, 0, false>(p, st);
     if (p.KH == 1 && p.stride == 1) return wide ? launch_h8<2, 2, 1, 1, 0, false>(p, st) : launch_h8<1, 2, 1, 1, 0, false>(p, st);
-    if (p.KH == 3 && p.stride == 2) return wide ? launch_h8<2, 1, 3, 2, 0, false>(p, st) : launch_h8<1, 1, 3, 2, 0, false>(p, st);
+    if (p.KH == 3 && p.stride == 2) {                      // 16-channel chunks: the 9 x 65-slot tile of a 32-channel chunk leaves one block per CU
+        static const int s2_env = getenv("L2I_H8_S2KS") ? atoi(getenv("L2I_H8_S2KS")) : 1;
+        if (s2_env == 1) return wide ? launch_h8<2, 1, 3, 2, 0, false, false, 1>(p, st) : launch_h8<1, 1, 3, 2, 0, false, false, 1>(p, st);
+        return wide ? launch_h8<2, 1, 3, 2, 0, false>(p, st) : launch_h8<1, 1, 3, 2, 0, false>(p, st);
+    }
     return wide ? launch_h8<2, 2, 1, 2, 0, false>(p, st) : launch_h8<1, 2, 1, 2, 0, false>(p, st);
 }
 

@@ -42,7 +42,7 @@ class VGG19Prefix:
         w0 = torch.as_tensor(np.asarray(P['0.weight']), dtype=torch.float32)
         w0 = w0 / torch.tensor(VGG_STD, dtype=torch.float32).reshape(1, 3, 1, 1)
         ws = [w0] + [torch.as_tensor(np.asarray(P['%d.weight' % i]), dtype=torch.float32) for i in (2, 5, 7)]
-        self.convs = [C.H8Conv(w, 1, 1, device=device) for w in ws]
+        self.convs = [C.H8Conv(w, 1, 1, device=device, cin_pad=16 if i == 0 else 32) for i, w in enumerate(ws)]      # conv1_1: three real channels of ONE 16-channel chunk
         self.biases = [torch.as_tensor(np.asarray(P['%d.bias' % i]), dtype=torch.float32).contiguous().to(device) for i in (0, 2, 5, 7)]
         self.neg_mean = (-torch.tensor(VGG_MEAN, dtype=torch.float32)).to(device)
 
@@ -50,7 +50,7 @@ class VGG19Prefix:
         """[B,3,H,W] fp32 -> (c1, c2, p, c3, c4, pool_idx) h8: pre-ReLU conv outputs conv_1..conv_4, p = relu(maxpool(c2)).  ``org`` = the four
         taps of the original image: a seventh element, the four sums of (c_k - org_k)^2, formed in the conv epilogues."""
         xc = K.fused_bias_act(img.contiguous(), self.neg_mean, None, 1, 0, 0.0, 1.0)        # x - mean (fp32: the padding stays exactly zero)
-        xh = K16.cast_to_h8(xc, 32)                                # three real channels of a 32-channel chunk
+        xh = K16.cast_to_h8(xc, 16)                                # three real channels of a 16-channel chunk
         sq = [None] * 4
         if org is not None:
             acc = torch.zeros(4, C._lib.SQ_SLOTS, device=img.device, dtype=torch.float32)

@@ -5,13 +5,13 @@
 set -u
 CFG=${1:-c3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r02_$CFG
+OUT=$R/gpurun_out/r03_$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 EXTRA=""
 if [ "$CFG" = "c5" ]; then EXTRA="--config c5 --hip_graph 0"; fi
-COMMON="--serial_streams --cpu_baseline_s 0 --no_alt_precision"
+COMMON="--serial_streams --cpu_baseline_s 0 --no_alt_precision --sweep none"
 # 1. kernel trace + stats over the full default step counts (2 warm-up + 5 timed + 5 with per-launch events = 12 steps)
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 bench.py $EXTRA $COMMON > $OUT/bench_serial_streams.json 2> $OUT/bench_serial_streams.err
 # 2. HBM traffic: FETCH_SIZE and WRITE_SIZE do not fit one pass

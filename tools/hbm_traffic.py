@@ -9,7 +9,7 @@ FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes 
 doubled; both factors are checked on a streaming kernel of known byte count in the same run (maxpool2x2_bwd_add_diff_kernel:
 9.25 B read, 4 B written per element; an earlier build's axpby_kernel gave 2.00 and 1.00).
 
-    python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_c3_hbm_traffic.json [c3|c5]
+    python tools/hbm_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r03_c3_hbm_traffic.json [c3|c5|c5x3]
 
 Round 2: the summary also carries the bytes per launch of every conv kernel FAMILY (the unit bench.py's roofline.traffic reports for the
 dominant family), the sha256 of the libl2i_hip.so that was profiled and the workload key; bench.py drops the figure when either differs.
@@ -22,9 +22,10 @@ import os
 import sys
 
 CONV = ('conv_wino_kernel', 'conv_mfma_kernel', 'gemm1x1_kernel', 'convt_mfma_kernel', 'conv_direct_small_kernel',
-        'conv_bf16x3_pipe_kernel', 'conv_cin3_kernel', 'splitk_epilogue_kernel')
+        'conv_bf16x3_pipe_kernel', 'conv_cin3_kernel', 'splitk_epilogue_kernel', 'conv_h8_kernel')
 WORKLOADS = {'c3': [1024, 8, ['Smiling'], 'f32', False],
-             'c5': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'bf16x3', False]}
+             'c5': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'bf16', False],
+             'c5x3': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'bf16x3', False]}
 
 
 def family_of(kernel):
@@ -41,6 +42,9 @@ def family_of(kernel):
         return 'cin3_f32'
     if kernel.startswith('conv_direct_small_kernel'):
         return 'direct_small_valu'
+    if kernel.startswith('conv_h8_kernel'):               # <WM, WN, K, S, TR, OUT32, RELU_IN, KS>
+        args = kernel[kernel.index('<') + 1:kernel.rindex('>')].split(',')
+        return 'transposed_h8' if args[4].strip() != '0' else 'conv_h8'
     if kernel.startswith('conv_bf16x3_pipe_kernel'):
         args = kernel[kernel.index('<') + 1:kernel.rindex('>')].split(',')
         return 'transposed_bf16x3' if len(args) > 5 and args[5].strip() not in ('0',) else 'implicit_gemm_bf16x3'

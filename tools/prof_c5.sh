@@ -5,7 +5,7 @@ OUT=$R/gpurun_out/prof_c5
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 bench.py --config c5 --hip_graph 0 --serial_streams --cpu_baseline_s 0 --no_alt_precision --sweep "" --steps 3 --warmup 1 --no_kernel_events > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 bench.py --config c5 --hip_graph 0 --serial_streams --cpu_baseline_s 0 --no_alt_precision --sweep none --steps 3 --warmup 1 --no_kernel_events > $OUT/bench.json 2> $OUT/bench.err
 python3 - <<'PY'
 import csv, glob, os
 out = os.environ.get('GRAFT_REPO_ROOT', os.getcwd()) + '/gpurun_out/prof_c5'
