@@ -248,10 +248,34 @@ class Generator:
         return conv_idx, rgb_idx
 
 
-def _noise_for(gen, noise, li, b, res, device):
+def _draw_noise(gen, noise, b, device):
+    """Per-layer noise maps of one pass (networks.py:281-286: a fresh N(0,1) map per NoiseInjection call): the caller's explicit list, or — with
+    ``randomize_noise`` — ONE normal draw for the whole pass cut into the per-layer maps (17 launches less per pass than a draw per layer; every
+    element is still an independent N(0,1) sample), or nothing."""
+    if noise is not None or not gen.randomize_noise:
+        return None
+    sizes = []
+    for li, L in enumerate(gen.layers):
+        res = 4 << ((li + 1) // 2)                          # conv1 at 4, then (up, conv) pairs at 8, 16, ...
+        sizes.append(b * res * res if L.noise_w != 0.0 else 0)
+    if sum(sizes) == 0:
+        return None
+    flat = torch.randn(sum(sizes), device=device)
+    out, off = [], 0
+    for li, n in enumerate(sizes):
+        res = 4 << ((li + 1) // 2)
+        out.append(flat[off:off + n].view(b, 1, res, res) if n else None)
+        off += n
+    return out
+
+
+def _noise_for(gen, noise, li, b, res, device, drawn=None):
     L = gen.layers[li]
     if noise is not None:
         return noise[li].contiguous() if L.noise_w != 0.0 else None
+    if drawn is not None:
+        assert drawn[li] is None or drawn[li].shape[2] == res
+        return drawn[li]
     if gen.randomize_noise and L.noise_w != 0.0:
         return torch.randn(b, 1, res, res, device=device)
     return None
@@ -270,11 +294,12 @@ class _SynthesisFn(torch.autograd.Function):
         skip = None
         plan = gen.modplan
         s_all, d_all, w_all = plan.forward(lat.contiguous())       # every modulation / demodulation / ToRGB weight of the pass: two launches
+        drawn = _draw_noise(gen, noise, B, dev)
         for li, L in enumerate(gen.layers):
             s, demod = plan.s(s_all, B, li), plan.demod(d_all, B, li)
             h = x.shape[2]
             res = h * 2 if L.up else h
-            nz = _noise_for(gen, noise, li, B, res, dev)
+            nz = _noise_for(gen, noise, li, B, res, dev, drawn)
             if L.up:
                 # the (2H+1)^2 map of the transposed conv is produced (2H+4)^2 (three zero rows / columns at the far edge, cropped by the
                 # blur's negative far pad): whole 16-byte rows for the conv's stores and the FIR's row vectors

@@ -44,6 +44,10 @@ class WalkLinearMultiW(nn.Module):
     def forward(self, input, alpha, layers=None, name=None, index_=None):
         al = alpha.to(self.w.device)
         dirs = torch.matmul(al, self.w.permute(1, 0, 2))                 # [n_latent, B, dim_z] in one batched GEMM
+        if layers is None and len(input) == dirs.shape[0] and all(t is input[0] for t in input):
+            # get_w hands the SAME tensor n_latent times (transform_base.py:372-378): one broadcast add instead of n_latent, the list entries are
+            # views of its result (same values, same list-of-[B,512] contract)
+            return list((input[0].unsqueeze(0) + dirs).unbind(0))
         w_transformed = []
         for i in range(len(input)):
             if layers is None or i in layers:

@@ -23,7 +23,7 @@ from . import kernels as K
 from . import kernels16 as K16
 from . import specs
 from .discriminator import Discriminator as _Discriminator32, _ConvLReLUFn, _eq_conv, _vec
-from .generator import Generator as _Generator32, _ModPlan, _Mod, _ToRGB, _noise_for, _t
+from .generator import Generator as _Generator32, _ModPlan, _Mod, _ToRGB, _draw_noise, _noise_for, _t
 from .perceptual import VGG_STD, VGG_MEAN
 from .regressor import _CB, _fold_bn
 from .specs import RESNET50_LAYERS
@@ -336,11 +336,12 @@ class _Synthesis16Fn(torch.autograd.Function):
         x = gen.const16.expand(B, -1, -1, -1, -1).contiguous()
         skip = None
         lr = dict(act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
+        drawn = _draw_noise(gen, noise, B, dev)
         for li, L in enumerate(gen.layers):
             s, demod = plan.s(s_all, B, li), plan.demod(d_all, B, li)
             h = x.shape[2]
             res = h * 2 if L.up else h
-            nz = _noise_for(gen, noise, li, B, res, dev)
+            nz = _noise_for(gen, noise, li, B, res, dev, drawn)
             planes = K16.modulate_planes(L.w32_fwd, s)                         # weight * style, one plane set per sample (networks.py:234-235)
             bstride = planes[0].numel() * 2
             if L.up:
