@@ -47,8 +47,9 @@ class TrainOptions:
         p.add_argument('--no_log_sync', action='store_true', help='do not read the loss back every step (train.py:110)')
         p.add_argument('--hip_graph', action='store_true',
                        help='record forward+backward of the step once and replay it from one hipGraph per iteration (static batch size)')
-        p.add_argument('--precision', type=str, default=None, choices=['f32', 'bf16x3'],
-                       help='matrix path of the frozen convolutions: exact fp32 MFMA (default) or the 3-term bf16 split (fp32 accumulation)')
+        p.add_argument('--precision', type=str, default=None, choices=['f32', 'bf16x3', 'bf16'],
+                       help='matrix path of the frozen networks: exact fp32 MFMA (default), the 3-term bf16 split on fp32 tensors (fp32 accuracy), '
+                            'or the 16-bit path (bf16 feature maps in HBM, one bf16 MFMA per MAC, fp32 accumulation; BASELINE config 5)')
         p.add_argument('--synthetic_weights', action='store_true',
                        help='run on seeded random-init G / regressor / VGG when the checkpoint paths of constants.py do not exist '
                             '(default: a missing checkpoint is an error, as in the reference)')
