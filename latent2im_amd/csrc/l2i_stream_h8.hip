@@ -138,84 +138,115 @@ __global__ __launch_bounds__(256) void upfirdn2d_h8_kernel(u32x4* __restrict__ y
     }
 }
 // Separable 4x4 FIR without resampling (up = down = 1: the blurs of the generator's up layers and of the discriminator, forward and backward — 90 %
-// of the FIR bytes), register-streaming: a lane owns one output column and walks RB output rows downwards; per INPUT row it loads the four
-// slots of its horizontal window (neighbouring lanes overlap: L1 hits), forms the horizontal sum once and keeps the last four of them in
-// registers for the vertical sum — 4 loads and 8 multiply-adds per output instead of 16 and 16.  Same fused epilogue as the generic kernel.
+// of the FIR bytes), register-streaming.  A WAVE owns 61 output columns of a band of RB output rows: lane l loads input column c0 + l of every
+// input row ONCE (one 16-byte buffer load per lane and row; out-of-image rows and columns read zeros through the descriptor's range check) and
+// the horizontal sum of output column c0 + l - 3 + pad is built by passing partial sums one lane to the right three times (DPP wave_shr:1, no LDS,
+// no second load):  a = t0 v;  b = t1 v + a(l-1);  c = t2 v + b(l-1);  h = t3 v + c(l-1)  =  sum_k t_k v(l - 3 + k).
+// Lanes 0-2 of a wave only feed their neighbours (61 of 64 lanes store).  The last four horizontal sums stay in registers for the vertical sum;
+// input rows are requested PF rows ahead of their use (the first version loaded its four window slots per row with nothing in flight behind
+// them: 2.8 TB/s, latency bound).  Same fused epilogue as the generic kernel.
+__device__ __forceinline__ float lane_shr1(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x138, 0xf, 0xf, false));   // wave_shr:1 (lane 0 gets 0)
+}
 template <int RB>
 __global__ __launch_bounds__(256) void upfirdn2d_h8_sep4_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ x, float4 ty, float4 tx, long long planes, int G8, int in_h, int in_w,
                                                                 int out_h, int out_w, int pad_x0, int pad_y0, const float* __restrict__ noise, float noise_w,
                                                                 const float* __restrict__ bias, int act, float slope, float gain, const u32x4* __restrict__ mask, float mpos,
                                                                 float mneg, const u32x4* __restrict__ addend) {
-    const int bands = (out_h + RB - 1) / RB;
-    const long long total = planes * bands * out_w;
-    const float txa[4] = {tx.x, tx.y, tx.z, tx.w}, tya[4] = {ty.x, ty.y, ty.z, ty.w};
-    for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long long)gridDim.x * 256) {
-        const int ox = (int)(u % out_w);
-        const long long pb = u / out_w;
+    constexpr int PF = 4, EP = 4;                            // input rows / epilogue-operand rows in flight per lane
+    constexpr int NR = RB + 3;
+    const int lane = threadIdx.x & 63;
+    const int chunks = (out_w + 60) / 61, bands = (out_h + RB - 1) / RB;
+    const long long total = planes * bands * chunks;
+    const unsigned plane_bytes = (unsigned)in_h * (unsigned)in_w * 16u;
+    const bool epi = noise || bias || act != L2I_ACT_NONE || gain != 1.f;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform unit index: the buffer descriptor lives in SGPRs
+    for (long long u = (long long)blockIdx.x * 4 + wv; u < total; u += (long long)gridDim.x * 4) {
+        const int chunk = (int)(u % chunks);
+        const long long pb = u / chunks;
         const int band = (int)(pb % bands);
         const long long pl = pb / bands;
         const int r0 = band * RB;
-        const u32x4* xp = x + pl * in_h * in_w;
-        const int ix0 = ox - pad_x0;
+        const int ox = chunk * 61 + lane - 3;                  // this lane's output column (lanes 0-2: none)
+        const int ix = ox - pad_x0 + 3;                        // its input column: the LAST tap of its window
+        const bool colok = ix >= 0 && ix < in_w;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + pl * (long long)in_h * in_w), 0, plane_bytes, 0x00020000);
         const int g = (int)(pl % G8);
         const long long b = pl / G8;
         float bs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs[e] = bias ? bias[8 * g + e] : 0.f;
+        const int iy0 = r0 - pad_y0;
+        // byte offset of (row, this lane's column); rows above / below the image and columns outside it land outside the descriptor's range: zeros
+        auto off = [&](int r) -> int { return colok ? ((iy0 + r) * in_w + ix) * 16 : -1; };
+        // epilogue operands of an output row (noise, mask, addend) are requested EP rows ahead as well: loads return in order, so an operand
+        // fetched at its point of use would wait for every input row in flight behind it
+        const bool lane_out = lane >= 3 && ox < out_w;
+        float nzq[EP];
+        u32x4 mq[EP], aq[EP];
+        auto issue_ops = [&](int j, int slot) {                     // slot = j % EP, a compile-time index at every call site
+            const int oy = r0 + j;
+            const bool ok = lane_out && oy < out_h;
+            const long long o = ok ? (pl * out_h + oy) * out_w + ox : 0;
+            if (noise) nzq[slot] = noise[ok ? (b * out_h + oy) * out_w + ox : 0];
+            if (mask) mq[slot] = mask[o];
+            if (addend) aq[slot] = addend[o];
+        };
+        u32x4 q[PF];
+#pragma unroll
+        for (int r = 0; r < PF; ++r) q[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off(r), 0, 0));
+#pragma unroll
+        for (int j = 0; j < EP; ++j) issue_ops(j, j);
         float ring[4][8];
+        // rows in groups of four: ring / prefetch slots are compile-time indices inside a group, the group loop is a real loop (a fully unrolled band
+        // with its runtime epilogue switches is 60 KB of code: past the instruction cache)
+        for (int rb = 0; rb < NR; rb += 4) {
 #pragma unroll
-        for (int r = 0; r < RB + 3; ++r) {
-            const int iy = r0 - pad_y0 + r;
-            float hrow[8];
+          for (int i = 0; i < 4; ++i) {
+            const int r = rb + i;
+            if (r >= NR) break;
+            float v[8];
+            unpack8(q[i], v);
+            q[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, r + PF < NR ? off(r + PF) : -1, 0, 0));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hrow[e] = 0.f;
-            if (iy >= 0 && iy < in_h && r0 + r - 3 < out_h + 3) {
-#pragma unroll
-                for (int kx = 0; kx < 4; ++kx) {
-                    const int ix = ix0 + kx;
-                    if (ix >= 0 && ix < in_w) {
-                        float v[8];
-                        unpack8(xp[(long long)iy * in_w + ix], v);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) hrow[e] += txa[kx] * v[e];
-                    }
-                }
+            for (int e = 0; e < 8; ++e) {
+                const float a = tx.x * v[e];
+                const float bq = fmaf(tx.y, v[e], lane_shr1(a));
+                const float c = fmaf(tx.z, v[e], lane_shr1(bq));
+                ring[i][e] = fmaf(tx.w, v[e], lane_shr1(c));
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ring[r & 3][e] = hrow[e];
             if (r >= 3) {
-                const int oy = r0 + r - 3;
-                if (oy < out_h) {
-                    float acc[8];
+                const int j = r - 3, oy = r0 + j;
+                float acc[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        acc[e] = tya[0] * ring[(r - 3) & 3][e] + tya[1] * ring[(r - 2) & 3][e] + tya[2] * ring[(r - 1) & 3][e] + tya[3] * ring[r & 3][e];
-                    const long long o = (pl * out_h + oy) * out_w + ox;
-                    if (noise || bias || act != L2I_ACT_NONE || gain != 1.f) {
-                        const float nz = noise ? noise[(b * out_h + oy) * out_w + ox] * noise_w : 0.f;
+                for (int e = 0; e < 8; ++e)
+                    acc[e] = ty.x * ring[(i + 1) & 3][e] + ty.y * ring[(i + 2) & 3][e] + ty.z * ring[(i + 3) & 3][e] + ty.w * ring[i][e];
+                if (epi) {
+                    const float nz = noise ? nzq[(i + 1) & 3] * noise_w : 0.f;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float v = acc[e] + nz + bs[e];
-                            if (act == L2I_ACT_LRELU) v = v > 0.f ? v : v * slope;
-                            else if (act == L2I_ACT_RELU) v = v > 0.f ? v : 0.f;
-                            acc[e] = v * gain;
-                        }
+                    for (int e = 0; e < 8; ++e) {
+                        float w = acc[e] + nz + bs[e];
+                        if (act == L2I_ACT_LRELU) w = w > 0.f ? w : w * slope;
+                        else if (act == L2I_ACT_RELU) w = w > 0.f ? w : 0.f;
+                        acc[e] = w * gain;
                     }
-                    if (mask) {
-                        float m[8];
-                        unpack8(mask[o], m);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[e] *= m[e] > 0.f ? mpos : mneg;
-                    }
-                    if (addend) {
-                        float a[8];
-                        unpack8(addend[o], a);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[e] += a[e];
-                    }
-                    y[o] = pack8(acc);
                 }
+                if (mask) {
+                    float m[8];
+                    unpack8(mq[(i + 1) & 3], m);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] *= m[e] > 0.f ? mpos : mneg;
+                }
+                if (addend) {
+                    float a2[8];
+                    unpack8(aq[(i + 1) & 3], a2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += a2[e];
+                }
+                if (j + EP < RB) issue_ops(j + EP, (i + 1) & 3);
+                if (lane_out && oy < out_h) y[(pl * out_h + oy) * out_w + ox] = pack8(acc);
             }
+          }
         }
     }
 }
@@ -233,8 +264,8 @@ extern "C" int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t 
         // the caller vouches that k = outer(k1y, k1x) (the path's blurs: [1,3,3,1] x [1,3,3,1] * gain); taps of the flipped kernel
         constexpr int RB = 16;
         const float4 ty = make_float4(k1y[3], k1y[2], k1y[1], k1y[0]), tx = make_float4(k1x[3], k1x[2], k1x[1], k1x[0]);
-        const long long units = (long long)planes * ((out_h + RB - 1) / RB) * out_w;
-        hipLaunchKernelGGL((upfirdn2d_h8_sep4_kernel<RB>), dim3(l2i_grid_for(units, 256, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)x, ty, tx,
+        const long long waves = (long long)planes * ((out_h + RB - 1) / RB) * ((out_w + 60) / 61);
+        hipLaunchKernelGGL((upfirdn2d_h8_sep4_kernel<RB>), dim3(l2i_grid_for(waves, 4, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)x, ty, tx,
                            (long long)planes, channels / 8, in_h, in_w, out_h, out_w, pad_x0, pad_y0, noise, noise_w, bias, act, act_slope, act_gain, (const u32x4*)mask,
                            mask_pos, mask_neg, (const u32x4*)addend);
         L2I_CHECK_LAUNCH();
@@ -277,6 +308,17 @@ extern "C" int l2i_torgb_fwd_h8(float* rgb, const void* x, const float* wmod, co
     return L2I_OK;
 }
 
+// strips per (sample, channel group) of the reducing kernels: about 4096 blocks in flight in total (16 per CU), never fewer than 2048 pixel slots per
+// strip (one atomic per block and sum: the fewer strips, the fewer same-address atomics)
+static int h8_strips(long long groups, long long HW) {
+    long long s = (4096 + groups - 1) / groups;
+    const long long cap = (HW + 2047) / 2048;
+    if (s > cap) s = cap;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
 // ---- fused elementwise backward of a styled conv output (l2i_sg2_act_bwd_f32 on h8 maps) -------------------------------------------------
 //   g    = gin[idx] * gin_scale[b,c] + sum_o wmod_rgb[b,o,c] * grgb[b,o,p]              (gin h8 or NULL; grgb fp32 [B,3,HW] or NULL)
 //   dz   = g * (y > 0 ? gain : gain * slope)                                              -> dz h8
@@ -305,47 +347,71 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_h8_kernel(u32x4* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) { r1[e] = 0.f; r2[0][e] = r2[1][e] = r2[2][e] = 0.f; }
     const float gp = gain, gn = gain * slope, ip = 1.f / gain, in_ = 1.f / (gain * slope);
-    for (long long pix = (long long)strip * 256 + threadIdx.x; pix < HW; pix += (long long)strips * 256) {
-        float yv[8], gv[8];
-        unpack8(y[base + pix], yv);
-        if (gin) unpack8(gin[base + pix], gv);
-        float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-        if (grgb) { q0 = grgb[((size_t)b * 3 + 0) * HW + pix]; q1 = grgb[((size_t)b * 3 + 1) * HW + pix]; q2 = grgb[((size_t)b * 3 + 2) * HW + pix]; }
-        const float nz = noise ? noise[(size_t)b * HW + pix] * noise_w : 0.f;
-        float d[8];
+    const long long step = (long long)strips * 256;
+    // two pixel slots per iteration, all loads of both issued before the arithmetic (a lane's second slot is `step` further: both coalesced)
+    for (long long pix = (long long)strip * 256 + threadIdx.x; pix < HW; pix += 2 * step) {
+        const long long pix2 = pix + step;
+        const bool two = pix2 < HW;
+        const long long p2 = two ? pix2 : pix;
+        const u32x4 yq0 = y[base + pix], yq1 = y[base + p2];
+        u32x4 gq0 = u32x4{0, 0, 0, 0}, gq1 = u32x4{0, 0, 0, 0};
+        if (gin) { gq0 = gin[base + pix]; gq1 = gin[base + p2]; }
+        float q[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        if (grgb) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float gg = gin ? gv[e] * sc[e] : 0.f;
-            gg += wr[0][e] * q0 + wr[1][e] * q1 + wr[2][e] * q2;
-            const bool pos = yv[e] > 0.f;
-            d[e] = gg * (pos ? gp : gn);
-            const float zpre = yv[e] * (pos ? ip : in_) - bs[e] - nz;
-            r1[e] += d[e] * zpre;
-            r2[0][e] += yv[e] * q0; r2[1][e] += yv[e] * q1; r2[2][e] += yv[e] * q2;
+            for (int o = 0; o < 3; ++o) { q[0][o] = grgb[((size_t)b * 3 + o) * HW + pix]; q[1][o] = grgb[((size_t)b * 3 + o) * HW + p2]; }
         }
-        dz[base + pix] = pack8(d);
+        float nz[2] = {0.f, 0.f};
+        if (noise) { nz[0] = noise[(size_t)b * HW + pix] * noise_w; nz[1] = noise[(size_t)b * HW + p2] * noise_w; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            float yv[8], gv[8], d[8];
+            unpack8(h ? yq1 : yq0, yv);
+            unpack8(h ? gq1 : gq0, gv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float gg = gv[e] * sc[e];
+                gg += wr[0][e] * q[h][0] + wr[1][e] * q[h][1] + wr[2][e] * q[h][2];
+                const bool pos = yv[e] > 0.f;
+                d[e] = gg * (pos ? gp : gn);
+                const float zpre = yv[e] * (pos ? ip : in_) - bs[e] - nz[h];
+                r1[e] += d[e] * zpre;
+                r2[0][e] += yv[e] * q[h][0]; r2[1][e] += yv[e] * q[h][1]; r2[2][e] += yv[e] * q[h][2];
+            }
+            dz[base + (h ? pix2 : pix)] = pack8(d);
+        }
     }
-    const int lane = threadIdx.x & 63;
+    // block-level reduction: wave sums meet in LDS, ONE atomic per block and sum (the per-wave atomics of the first version were the
+    // kernel's bound on the mid-resolution layers: 0.5 M same-address atomics per launch)
+    __shared__ float part[4][32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float s = wave_sum(r1[e]);
-        if (lane == 0) atomicAdd(red_dz_z + (size_t)b * C + 8 * g + e, s);
+        const float s0 = wave_sum(r1[e]);
+        if (lane == 0) part[wv][e] = s0;
         if (red_x_grgb) {
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
                 const float t = wave_sum(r2[o][e]);
-                if (lane == 0) atomicAdd(red_x_grgb + ((size_t)b * C + 8 * g + e) * 3 + o, t);
+                if (lane == 0) part[wv][8 + 3 * e + o] = t;
             }
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int e = threadIdx.x;
+        atomicAdd(red_dz_z + (size_t)b * C + 8 * g + e, part[0][e] + part[1][e] + part[2][e] + part[3][e]);
+    } else if (threadIdx.x < 32 && red_x_grgb) {
+        const int i = threadIdx.x;                              // 8 + 3 e + o
+        atomicAdd(red_x_grgb + ((size_t)b * C + 8 * g) * 3 + (i - 8), part[0][i] + part[1][i] + part[2][i] + part[3][i]);
     }
 }
 extern "C" int l2i_sg2_act_bwd_h8(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
                                   const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream) {
     if (!dz || !y || !red_dz_z || B <= 0 || C <= 0 || (C % 8) != 0 || HW <= 0) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd_h8: bad arguments");
     if ((grgb != nullptr) != (wmod_rgb != nullptr)) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd_h8: grgb and wmod_rgb go together");
-    int strips = (int)((HW + 256 * 8 - 1) / (256 * 8));
-    if (strips < 1) strips = 1;
-    if (strips > 64) strips = 64;
+    const int strips = h8_strips(B * (C / 8), HW);
     hipLaunchKernelGGL(sg2_act_bwd_h8_kernel, dim3((unsigned)(B * (C / 8) * strips)), dim3(256), 0, (hipStream_t)stream, (u32x4*)dz, (const u32x4*)gin, gin_scale, grgb, wmod_rgb,
                        (const u32x4*)y, bias, noise, noise_w, slope, gain, red_dz_z, grgb ? red_x_grgb : nullptr, C, (long long)HW, strips);
     L2I_CHECK_LAUNCH();
@@ -362,29 +428,40 @@ __global__ __launch_bounds__(256) void dot_reduce_h8_kernel(float* __restrict__ 
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = 0.f;
-    for (long long pix = (long long)strip * 256 + threadIdx.x; pix < HW; pix += (long long)strips * 256) {
-        float av[8], bv[8];
-        unpack8(a[base + pix], av);
+    const long long step = (long long)strips * 256;
+    for (long long pix = (long long)strip * 256 + threadIdx.x; pix < HW; pix += 2 * step) {
+        const long long pix2 = pix + step;
+        const bool two = pix2 < HW;
+        const long long p2 = two ? pix2 : pix;
+        const u32x4 a0 = a[base + pix], a1 = a[base + p2];
+        float av[8], bv[8], cv[8], dv[8];
+        unpack8(a0, av);
+        unpack8(a1, cv);
+        const float w2 = two ? 1.f : 0.f;
         if (bb) {
-            unpack8(bb[base + pix], bv);
+            const u32x4 b0 = bb[base + pix], b1 = bb[base + p2];
+            unpack8(b0, bv);
+            unpack8(b1, dv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r[e] += av[e] * bv[e];
+            for (int e = 0; e < 8; ++e) r[e] += av[e] * bv[e] + w2 * (cv[e] * dv[e]);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r[e] += av[e];
+            for (int e = 0; e < 8; ++e) r[e] += av[e] + w2 * cv[e];
         }
     }
+    __shared__ float part[4][8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float s = wave_sum(r[e]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(out + (size_t)b * C + 8 * g + e, s);
+        const float t = wave_sum(r[e]);
+        if (lane == 0) part[wv][e] = t;
     }
+    __syncthreads();
+    if (threadIdx.x < 8) atomicAdd(out + (size_t)b * C + 8 * g + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 extern "C" int l2i_dot_reduce_h8(float* out, const void* a, const void* b, int B, int C, int64_t HW, void* stream) {
     if (!out || !a || B <= 0 || C <= 0 || (C % 8) != 0 || HW <= 0) return l2i_set_error(L2I_E_ARG, "dot_reduce_h8: bad arguments");
-    int strips = (int)((HW + 256 * 8 - 1) / (256 * 8));
-    if (strips < 1) strips = 1;
-    if (strips > 64) strips = 64;
+    const int strips = h8_strips(B * (C / 8), HW);
     hipLaunchKernelGGL(dot_reduce_h8_kernel, dim3((unsigned)(B * (C / 8) * strips)), dim3(256), 0, (hipStream_t)stream, out, (const u32x4*)a, (const u32x4*)b, C, (long long)HW, strips);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
