@@ -30,6 +30,7 @@
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
 
 namespace g8 {
 template <int WN, int K, int S, int TR, int KS_ = 2> struct Geo {
@@ -55,6 +56,7 @@ template <int WN, int K, int S, int TR, int KS_ = 2> struct Geo {
 struct H8Launch {
     int tiles_x, tiles_y, mblocks, total, nchunks;
     int vec_epi;                       // fp32 NCHW output: the LDS-transposed epilogue with 16-byte accesses applies
+    int lean_epi;                      // h8 output without per-pixel operand maps (no out_mask / residual / accumulate / sq_ref): the lean epilogue
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16_h8(float lo, float hi) {
@@ -141,6 +143,9 @@ struct H8Out {
             for (int e = 0; e < 8; ++e) v[e] += o[e];
         }
         const u32x4 out = {cvt_pk_bf16_h8(v[0], v[1]), cvt_pk_bf16_h8(v[2], v[3]), cvt_pk_bf16_h8(v[4], v[5]), cvt_pk_bf16_h8(v[6], v[7])};
+#ifdef L2I_H8_ABLATE_STORE                                 // timing ablation: the epilogue's arithmetic without its global store
+        if (out.x == 0x12345678u && out.y == 0x9abcdef0u)
+#endif
         reinterpret_cast<u32x4*>(p.y)[slot] = out;
         if (p.sq_ref) {                                            // ContentLoss value of a VGG tap on the ROUNDED output (what the next layer reads)
             float rf[8], w[8];
@@ -173,6 +178,12 @@ __device__ __forceinline__ void h8_gather(const f32x16& a, int pr, int half, flo
 // RELU_IN: pro(x) = max(x, 0) on the B fragments (VGG-19: a conv reads the PRE-ReLU tap of the layer below, which is what the ContentLoss
 // and the backward masks need in HBM): four v_pk_max_i16 per fragment — a negative bf16 is a negative int16, so the integer max with 0 is
 // the ReLU (and -0 -> +0) — beside the bf16 MFMAs, whose pipe the VALU does not share
+// Measured, not kept (round 3, tools/probes/h8_ablate*.sh): a "deep" variant for the low-Cin 3x3 layers — three tile stages requested two chunks ahead,
+// a chunk's whole 3x3 weight slice per stage with ONE barrier per chunk, tile DMA issued by waves 0-1 and weight DMA by waves 2-3 so that a wave's
+// in-order vmcnt never makes an L2-hit weight slice wait behind an HBM tile.  72 KB of LDS = two blocks per CU instead of four: 9-15 % SLOWER
+// on every layer (64 -> 64 @1024^2 0.94 against 0.83 ms).  The timing ablations say why nothing memory-side helps: with no DMA at all the launch
+// still takes 0.64 ms, with no DMA and no MFMA 0.37, with the stores gone too 0.30 — the parts add instead of overlapping, and four co-resident
+// blocks hide more of that than a deeper pipeline in two.
 template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false, int KS = 2>
 __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
     using G = g8::Geo<WN, K, S, TR, KS>;
@@ -181,11 +192,14 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
     constexpr int BM = WM * 32;
     constexpr int WSLOTS = K * G::KS * 2 * BM;             // slots per phase: K taps x KS steps x 2 halves x BM channels
     constexpr int WPIECES = WSLOTS / 64;
-    constexpr int WPW = (WPIECES + 3) / 4;
+    constexpr int TW = 4;                                  // waves that issue tile pieces / weight pieces
+    constexpr int WPW = (WPIECES + TW - 1) / TW;
+    constexpr int NPT = 4 * G::NPW / TW;                   // tile pieces per issuing wave and chunk
     constexpr int IN_STAGE = G::IN_STAGE;
+    constexpr int NST = 2;                                 // tile stages
     extern __shared__ __attribute__((aligned(16))) u32x4 smem4[];
-    u32x4* const in_st = smem4;                            // 2 stages x [group][row][slot]
-    u32x4* const w_st = smem4 + 2 * IN_STAGE;              // 2 stages x [tap][step][half][channel]
+    u32x4* const in_st = smem4;                            // NST stages x [group][row][slot]
+    u32x4* const w_st = smem4 + NST * IN_STAGE;            // 2 stages x [tap][step][half][channel]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -210,10 +224,11 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, wpl_bytes, 0x00020000);
 
     // ---- tile DMA: piece q = wave + 4 t covers LDS slots [64 q, 64 q + 64) of the stage; slot -> (group, row, column) ----
-    unsigned ivoff[G::NPW];
+    const int tw = wave, tw_u = wave_u;
+    unsigned ivoff[NPT];
 #pragma unroll
-    for (int t = 0; t < G::NPW; ++t) {
-        const int sl = (wave + 4 * t) * 64 + lane;
+    for (int t = 0; t < NPT; ++t) {
+        const int sl = (tw + TW * t) * 64 + lane;
         ivoff[t] = in_bytes;                                                           // out of range: the DMA writes zeros (= the padding)
         if (sl < G::IN_SLOTS) {
             const int nh = sl / G::HSTRIDE, r2 = sl - nh * G::HSTRIDE;
@@ -224,14 +239,17 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
         }
     }
     auto dma_in = [&](int chunk, int stage) {
+#ifdef L2I_H8_ABLATE_TILE                                  // timing ablation: no tile traffic (the MFMAs run on whatever the LDS holds)
+        return;
+#endif
         const unsigned soff = (unsigned)chunk * G::NH * plane_b;
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(in_st + stage * IN_STAGE);
 #pragma unroll
-        for (int t = 0; t < G::NPW; ++t) {
+        for (int t = 0; t < NPT; ++t) {
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
-                         : "v"(ivoff[t]), "s"(rs_x), "s"(__builtin_amdgcn_readfirstlane(lds0 + (wave_u + 4 * t) * 1024)), "s"(soff)
+                         : "v"(ivoff[t]), "s"(rs_x), "s"(__builtin_amdgcn_readfirstlane(lds0 + (tw_u + TW * t) * 1024)), "s"(soff)
                          : "memory");
         }
     };
@@ -239,17 +257,20 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
     unsigned wvoff[WPW];
 #pragma unroll
     for (int t = 0; t < WPW; ++t) {
-        const int sl = ((wave + 4 * t) * 64 + lane) % WSLOTS;
+        const int sl = ((tw + TW * t) * 64 + lane) % WSLOTS;
         const int r = sl / BM, i = sl - r * BM;                            // r = (tap * KS + step) * 2 + half
         const int hf = r & 1, st = (r >> 1) % G::KS, tap = (r >> 1) / G::KS;
         wvoff[t] = (unsigned)((((st * K * K + tap) * 2 + hf) * p.CoutP + m0 + i) * 16);
     }
-    auto dma_w = [&](int chunk, int ky, int stage) {
+    auto dma_w = [&](int chunk, int ky, int stage_slot) {       // stage_slot: first LDS slot of the phase's weights (relative to w_st)
+#ifdef L2I_H8_ABLATE_W                                     // timing ablation: no weight traffic
+        return;
+#endif
         const unsigned soff = (unsigned)((((size_t)chunk * G::KS * K * K + ky * K) * 2) * p.CoutP * 16);
-        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(w_st + stage * WSLOTS);
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(w_st + stage_slot);
 #pragma unroll
         for (int t = 0; t < WPW; ++t) {
-            const int q = wave_u + 4 * t;                  // wave-uniform: a scalar branch
+            const int q = tw_u + TW * t;                   // wave-uniform: a scalar branch
             if (q < WPIECES) {
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
@@ -275,13 +296,13 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
     const int bbase = half * G::HSTRIDE + wave * WN * rstep_out * G::RP + j;
     const int abase = half * BM + j;
 
-    auto mfma_phase = [&](int in_stage, int w_stage, auto ky_t) {
+    auto mfma_phase = [&](int in_stage, int w_slot, auto ky_t) {     // w_slot: first LDS slot of the phase's weights (relative to w_st)
         constexpr int ky = decltype(ky_t)::value;
         constexpr int PADT = (TR == 2) ? 1 : 0;
         constexpr int py = (ky + PADT) & 1;
         constexpr int rowoff = TR ? (py + PADT - ky) / 2 - DMIN : (G::GATHER ? 0 : ky);
         const u32x4* ih = in_st + in_stage * IN_STAGE + bbase + rowoff * G::RP;
-        const u32x4* wh = w_st + w_stage * WSLOTS + abase;
+        const u32x4* wh = w_st + w_slot + abase;
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
             // transposed: tap kx feeds output parity px = (kx + pad) & 1 from input column s + dx, dx = (px + pad - kx) / 2; staged column dx - DMIN
@@ -305,12 +326,20 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
                 for (int m = 0; m < WM; ++m)
 #pragma unroll
                     for (int n = 0; n < WN; ++n)
+#ifdef L2I_H8_ABLATE_MFMA                                  // timing ablation (tools/probes/h8_ablate.sh): fragments are read, no matrix work
+                        acc[TR ? py * 2 + ((kx + PADT) & 1) : 0][m][n][0] += __builtin_bit_cast(f32x4_, af[m])[0] * __builtin_bit_cast(f32x4_, bf[n])[0];
+#else
                         acc[TR ? py * 2 + ((kx + PADT) & 1) : 0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[TR ? py * 2 + ((kx + PADT) & 1) : 0][m][n], 0, 0, 0);
+#endif
             }
         }
     };
 
     // ---- pipeline ----
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    {
     const int nphases = L.nchunks * K;
     dma_w(0, 0, 0);
     dma_in(0, 0);
@@ -321,28 +350,90 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
         if (K > 1 && ky == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ph + 1 < nphases) dma_w(ky + 1 < K ? ch : ch + 1, ky + 1 < K ? ky + 1 : 0, (ph + 1) & 1);
+        if (ph + 1 < nphases) dma_w(ky + 1 < K ? ch : ch + 1, ky + 1 < K ? ky + 1 : 0, ((ph + 1) & 1) * WSLOTS);
         if (ky == 0 && more) dma_in(ch + 1, (ch + 1) & 1);
     };
     for (int ch = 0; ch < L.nchunks; ++ch) {
         const bool more = ch + 1 < L.nchunks;
-        using K0 = std::integral_constant<int, 0>;
-        using K1 = std::integral_constant<int, 1>;
-        using K2 = std::integral_constant<int, 2>;
         phase_head(ch, 0, more);
-        mfma_phase(ch & 1, (ch * K) & 1, K0());
+        mfma_phase(ch & 1, ((ch * K) & 1) * WSLOTS, K0());
         if constexpr (K == 3) {
             phase_head(ch, 1, more);
-            mfma_phase(ch & 1, (ch * K + 1) & 1, K1());
+            mfma_phase(ch & 1, ((ch * K + 1) & 1) * WSLOTS, K1());
             phase_head(ch, 2, more);
-            mfma_phase(ch & 1, (ch * K + 2) & 1, K2());
+            mfma_phase(ch & 1, ((ch * K + 2) & 1) * WSLOTS, K2());
         }
+    }
     }
 
     if constexpr (OUT32) {
         static_assert(!OUT32 || TR == 0, "fp32 NCHW output: correlations only");
         __syncthreads();                                   // the stages become the epilogue's transpose strips
         l2i_epilogue_32x32<WM, WN>(p, acc[0], reinterpret_cast<float*>(smem4), b, m0, oy0, ox0, L.vec_epi != 0);
+    } else if (L.lean_epi) {
+        // Lean epilogue (forward layers and plain gradient convs: per-channel vectors and the per-pixel noise only).  On the low-Cin layers the
+        // general epilogue below was as many VALU instructions as the K loop was MFMA cycles (7 VALU per MFMA on 64 -> 64 @1024^2, SQ counters:
+        // eight `finish` calls per wave, each with its own 64-bit slot arithmetic, operand switches and dependent loads) and the two do not
+        // overlap.  Here: one base pointer per wave, the channel vectors of a group fetched once for its WN rows, noise fetched
+        // up front, no per-slot branches beyond the store predicate.
+        const int cg_out = p.Cout / 8;
+        const size_t plane = (size_t)p.OHf * p.OWf;
+        const int sx = ox0 + j;
+        const int g0 = (m0 >> 3) + half;                               // this lane's group for (m, pr) = (0, 0); (m, pr) adds 4 m + 2 pr
+        u32x4* const yb = reinterpret_cast<u32x4*>(p.y) + ((size_t)b * cg_out + g0) * plane;
+        float nz[WN][NACC];
+        auto pix = [&](int n, int a, unsigned& off) -> bool {          // store predicate and slot offset of the pixel inside a group plane
+            const int t = oy0 + wave * WN + n;
+            const int oy = TR ? 2 * t + (a >> 1) : t + p.oy_off, ox = TR ? 2 * sx + (a & 1) : sx + p.ox_off;
+            const bool ok = TR ? (oy < p.OHf && ox < p.OWf) : (t < p.OH && sx < p.OW);
+            off = ok ? (unsigned)oy * (unsigned)p.OWf + (unsigned)ox : 0u;
+            return ok;
+        };
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+                unsigned off;
+                pix(n, a, off);
+                nz[n][a] = p.noise ? p.noise[(size_t)b * plane + off] * p.noise_w : 0.f;
+            }
+        constexpr int NQ = WM * 2;
+        const float gpos = (p.act == L2I_ACT_LRELU ? p.act_gain : 1.f) * p.out_gain;
+        const float gneg = p.act == L2I_ACT_LRELU ? p.act_slope * p.act_gain * p.out_gain : (p.act == L2I_ACT_RELU ? 0.f : p.out_gain);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int m = q >> 1, pr = q & 1;
+            const int co0 = (g0 + 4 * m + 2 * pr) * 8;
+            const bool gok = co0 < p.Cout;
+            const int cc = gok ? co0 : 0;
+            float4 s0, s1, b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (p.out_scale) {
+                const float* sp = p.out_scale + (size_t)b * p.Cout + cc;
+                s0 = *reinterpret_cast<const float4*>(sp); s1 = *reinterpret_cast<const float4*>(sp + 4);
+            }
+            if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + cc); b1 = *reinterpret_cast<const float4*>(p.bias + cc + 4); }
+            u32x4* const yq = yb + (size_t)(4 * m + 2 * pr) * plane;
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) {
+                    float g[8];
+                    h8_gather(acc[a][m][n], pr, half, g);
+                    if (p.out_scale) { g[0] *= s0.x; g[1] *= s0.y; g[2] *= s0.z; g[3] *= s0.w; g[4] *= s1.x; g[5] *= s1.y; g[6] *= s1.z; g[7] *= s1.w; }
+                    const float z = nz[n][a];
+                    g[0] += b0.x + z; g[1] += b0.y + z; g[2] += b0.z + z; g[3] += b0.w + z; g[4] += b1.x + z; g[5] += b1.y + z; g[6] += b1.z + z; g[7] += b1.w + z;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = fmaxf(g[e] * gpos, g[e] * gneg);       // identity / ReLU / leaky ReLU with the gains folded (gpos >= gneg >= 0)
+                    const u32x4 out = {cvt_pk_bf16_h8(g[0], g[1]), cvt_pk_bf16_h8(g[2], g[3]), cvt_pk_bf16_h8(g[4], g[5]), cvt_pk_bf16_h8(g[6], g[7])};
+                    unsigned off;
+                    const bool ok = pix(n, a, off);
+#ifdef L2I_H8_ABLATE_STORE
+                    if (out.x == 0x12345678u && out.y == 0x9abcdef0u)
+#endif
+                    if (ok && gok) yq[off] = out;
+                }
+            }
+        }
     } else {
         H8Out o{p, b, p.Cout / 8, p.res_sub ? p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) : 1.f, 0.f};
 #pragma unroll
@@ -394,6 +485,10 @@ static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
     L.total = (int)total;
     L.nchunks = p.Cin / G::CK;
     L.vec_epi = (OUT32 && l2i_epilogue_vec_ok(p)) ? 1 : 0;
+    static const int lean_env = getenv("L2I_H8_LEAN") ? atoi(getenv("L2I_H8_LEAN")) : 1;
+    // identity / ReLU / leaky ReLU as max(g * gpos, g * gneg) needs 0 <= gneg <= gpos
+    const bool gains_ok = p.out_gain > 0.f && (p.act != L2I_ACT_LRELU || (p.act_gain > 0.f && p.act_slope >= 0.f && p.act_slope <= 1.f));
+    L.lean_epi = (!OUT32 && lean_env && !p.out_mask && !p.residual && !p.accumulate && !p.sq_ref && gains_ok && (size_t)p.OHf * p.OWf < 0xFFFFFFFFull) ? 1 : 0;
     size_t lds = (size_t)(2 * G::IN_STAGE + 2 * WSLOTS) * 16;
     if (OUT32 && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: tile does not fit the LDS");
