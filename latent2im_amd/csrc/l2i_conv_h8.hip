@@ -89,36 +89,41 @@ struct H8Out {
         const int co0 = grp * 8;
         const size_t slot = (((size_t)b * cg_out + grp) * p.OHf + oy) * p.OWf + ox;
         const u32x4* y4 = reinterpret_cast<const u32x4*>(p.y);
-        if (p.out_scale) {
-            const float4 s0 = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Cout + co0), s1 = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Cout + co0 + 4);
-            v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w; v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
-        }
+        // every operand of the slot is requested before the first one is used: the first version loaded and consumed them one by one, up to five
+        // dependent memory round trips per slot and eight slots per wave
+        u32x4 q_mask, q_res, q_sub, q_rmask, q_old;
+        float4 s0, s1, b0, b1;
+        if (p.out_mask) q_mask = reinterpret_cast<const u32x4*>(p.out_mask)[slot];
+        if (p.residual) q_res = reinterpret_cast<const u32x4*>(p.residual)[slot];
+        if (p.res_sub) q_sub = reinterpret_cast<const u32x4*>(p.res_sub)[slot];
+        if (p.res_mask) q_rmask = reinterpret_cast<const u32x4*>(p.res_mask)[slot];
+        if (p.accumulate) q_old = y4[slot];
+        if (p.out_scale) { s0 = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Cout + co0); s1 = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Cout + co0 + 4); }
+        if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + co0); b1 = *reinterpret_cast<const float4*>(p.bias + co0 + 4); }
+        if (p.out_scale) { v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w; v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w; }
         if (p.out_mask) {
             float m[8];
-            h8_unpack(reinterpret_cast<const u32x4*>(p.out_mask)[slot], m);
+            h8_unpack(q_mask, m);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= m[e] > 0.f ? p.mask_pos : p.mask_neg;   // (1, 0): a ReLU mask; (1, 0.2) / (sqrt2, 0.2 sqrt2): leaky ReLU'
         }
-        if (p.bias) {
-            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co0), b1 = *reinterpret_cast<const float4*>(p.bias + co0 + 4);
-            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
+        if (p.bias) { v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w; }
         if (p.noise) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += nz;
         }
         if (p.residual) {
             float r[8];
-            h8_unpack(reinterpret_cast<const u32x4*>(p.residual)[slot], r);
+            h8_unpack(q_res, r);
             if (p.res_sub) {
                 float s[8];
-                h8_unpack(reinterpret_cast<const u32x4*>(p.res_sub)[slot], s);
+                h8_unpack(q_sub, s);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r[e] = rc * (r[e] - s[e]);
             }
             if (p.res_mask) {
                 float m[8];
-                h8_unpack(reinterpret_cast<const u32x4*>(p.res_mask)[slot], m);
+                h8_unpack(q_rmask, m);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r[e] = m[e] > 0.f ? r[e] : 0.f;
             }
@@ -138,7 +143,7 @@ struct H8Out {
         }
         if (p.accumulate) {
             float o[8];
-            h8_unpack(y4[slot], o);
+            h8_unpack(q_old, o);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += o[e];
         }

@@ -26,7 +26,16 @@ for cin, cout, k, s, pad, tr, res in CASES:
     oh, ow = hc.out_hw(res, res)
     y = torch.empty(b, cout // 8, oh, ow, 8, device='cuda', dtype=torch.bfloat16)
     bias = torch.randn(cout, device='cuda')
+    epi = os.environ.get('H8_EPI', 'b')                 # epilogue of the launch: b | br | o | rmo | ros (bias, residual, out_mask, res_mask, res_sub)
     kw = dict(bias=bias, act=conv.ACT_RELU)
+    if epi != 'b':
+        mk = lambda: torch.randn_like(y, dtype=torch.float32).to(torch.bfloat16)
+        kw = {}
+        if 'b' in epi: kw.update(bias=bias, act=conv.ACT_RELU)
+        if 'r' in epi: kw.update(residual=mk())
+        if 'o' in epi: kw.update(out_mask=mk(), mask=(1.0, 0.0))
+        if 'm' in epi: kw.update(res_mask=mk())
+        if 's' in epi: kw.update(res_sub=mk(), res_coef=0.5)
     for _ in range(3):
         hc.forward(x, out=y, **kw)
     torch.cuda.synchronize()
@@ -40,7 +49,7 @@ for cin, cout, k, s, pad, tr, res in CASES:
         ts.append(e0.elapsed_time(e1) / 3)
     ms = float(np.median(ts))
     fl = 2.0 * b * cout * cin * k * k * (res * res if tr else oh * ow)
-    by = 2.0 * (x.numel() + y.numel())
+    by = 2.0 * (x.numel() + y.numel() * (1 + sum(c in epi for c in 'roms')))
     print('%4d->%-4d k%d s%d %s @%-4d  %.4f ms  %.0f TFLOP/s  %.0f GB/s' % (cin, cout, k, s, 'T' if tr else ' ', res, ms, fl / ms / 1e9, by / ms / 1e6), flush=True)
     del x, y, hc
     torch.cuda.empty_cache()
