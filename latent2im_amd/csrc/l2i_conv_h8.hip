@@ -188,7 +188,16 @@ __device__ __forceinline__ void h8_gather(const f32x16& a, int pr, int half, flo
 // in-order vmcnt never makes an L2-hit weight slice wait behind an HBM tile.  72 KB of LDS = two blocks per CU instead of four: 9-15 % SLOWER
 // on every layer (64 -> 64 @1024^2 0.94 against 0.83 ms).  The timing ablations say why nothing memory-side helps: with no DMA at all the launch
 // still takes 0.64 ms, with no DMA and no MFMA 0.37, with the stores gone too 0.30 — the parts add instead of overlapping, and four co-resident
-// blocks hide more of that than a deeper pipeline in two.
+// blocks hide more of that than a deeper pipeline in two.  Also measured, no effect (inside +-1 %): the same wave roles at four blocks per CU (two tile
+// stages: a tile wave waits for its tile only at the chunk's first phase, a weight wave never behind a tile), starting the four first-generation
+// blocks of a CU a quarter of a block time apart (s_sleep sweep 0 ... 12 x 2048 cycles per slot), and removing every barrier (timing only).
+// Finer ablations of the no-DMA / no-MFMA / no-store skeleton (profiles/r03_h8_conv3x3_timing_ablations.txt): the epilogue is 0.25 ms of the
+// 0.83 ms launch (0.12 of it the stores), the fragment reads + barriers of the K loop another 0.2.
+// What all of these have in common (tools/probes/h8_clocks.sh, profiles/r03_h8_power_clocks.txt): while this kernel runs the package sits AT its
+// 1400 W power limit and the shader clock is throttled from 2.40 to 1.80-1.97 GHz (the fp32 kernels run at 1.19-1.34 kW and 2.40 GHz, the 1x1 layers
+// at 1.21 kW).  Under a power cap time follows energy: every part that is removed gives its share back, nothing overlaps "for free", and
+// re-arranging the same work (deeper pipeline, roles, stagger, a 16-row register tile with half the weight traffic: 0.790 against 0.795 ms) changes
+// nothing.  What moves it is less energy per output: fewer bytes (this path), fewer VALU instructions (the lean epilogue), fewer MFMA passes.
 template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false, int KS = 2>
 __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
     using G = g8::Geo<WN, K, S, TR, KS>;
@@ -317,10 +326,18 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
             for (int ks = 0; ks < G::KS; ++ks) {
                 bf16x8 af[WM], bf[WN];
 #pragma unroll
+#ifdef L2I_H8_ABLATE_LDSREAD                               // timing ablation: no fragment reads
+                for (int m = 0; m < WM; ++m) af[m] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)kx, (unsigned)ks, (unsigned)m, (unsigned)lane});
+#else
                 for (int m = 0; m < WM; ++m) af[m] = __builtin_bit_cast(bf16x8, wh[((kx * G::KS + ks) * 2) * BM + m * 32]);
+#endif
 #pragma unroll
                 for (int n = 0; n < WN; ++n) {
+#ifdef L2I_H8_ABLATE_LDSREAD
+                    u32x4 raw = u32x4{(unsigned)n, (unsigned)kx, (unsigned)j, 7u};
+#else
                     u32x4 raw = ih[ks * 2 * G::HSTRIDE + n * rstep_out * G::RP + coloff];
+#endif
                     if constexpr (RELU_IN) {
                         asm("v_pk_max_i16 %0, %0, 0" : "+v"(raw.x)); asm("v_pk_max_i16 %0, %0, 0" : "+v"(raw.y));
                         asm("v_pk_max_i16 %0, %0, 0" : "+v"(raw.z)); asm("v_pk_max_i16 %0, %0, 0" : "+v"(raw.w));
@@ -354,7 +371,9 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
         // weights of phase (ch, 1), stays in flight across that phase's barrier
         if (K > 1 && ky == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef L2I_H8_ABLATE_BARRIER
         __syncthreads();
+#endif
         if (ph + 1 < nphases) dma_w(ky + 1 < K ? ch : ch + 1, ky + 1 < K ? ky + 1 : 0, ((ph + 1) & 1) * WSLOTS);
         if (ky == 0 && more) dma_in(ch + 1, (ch + 1) & 1);
     };
@@ -375,6 +394,19 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
         static_assert(!OUT32 || TR == 0, "fp32 NCHW output: correlations only");
         __syncthreads();                                   // the stages become the epilogue's transpose strips
         l2i_epilogue_32x32<WM, WN>(p, acc[0], reinterpret_cast<float*>(smem4), b, m0, oy0, ox0, L.vec_epi != 0);
+#ifdef L2I_H8_ABLATE_EPI                                   // timing ablation: no epilogue (one dword per lane keeps the accumulators alive)
+    } else if (true) {
+        float t = 0.f;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[a][m][n][r];
+        if (t == 12345.678f) reinterpret_cast<float*>(p.y)[tid] = t;
+#endif
     } else if (L.lean_epi) {
         // Lean epilogue (forward layers and plain gradient convs: per-channel vectors and the per-pixel noise only).  On the low-Cin layers the
         // general epilogue below was as many VALU instructions as the K loop was MFMA cycles (7 VALU per MFMA on 64 -> 64 @1024^2, SQ counters:
