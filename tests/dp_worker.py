@@ -40,7 +40,8 @@ def main(out, size, global_batch, steps, no_gan, walk='linear'):
     if rk == 0:
         np.savez(out, walk=np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in g.walk.parameters()]), grads=np.stack(grads),
                  losses=np.stack(losses), world=world,
-                 backend=np.asarray(torch.distributed.get_backend() if dist.is_initialized() else 'none'))
+                 backend=np.asarray(torch.distributed.get_backend() if dist.is_initialized() else 'none'),
+                 precision=np.asarray(__import__('latent2im_amd.conv', fromlist=['conv']).PRECISION))
     dist.barrier()
     dist.shutdown()
 

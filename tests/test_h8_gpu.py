@@ -266,3 +266,77 @@ def test_bf16_training_step_vs_float64_oracle(size, batch):
     assert r["loss_rel"] < 5e-3 and r["reg_rel"] < 5e-3 and r["gan_rel"] < 2e-2          # (the GAN term passes nine bf16 residual blocks at 1024^2: measured 8e-3 there)
     assert max(r['per_attr_reg_loss_delta']) < 1e-3
     assert r['grad_cos'] > 0.95
+
+
+def test_bf16_hipgraph_replay_matches_eager_1024_batch8():
+    """BASELINE config 5 exactly as bench.py --config c5 times it: SceneGraph, five scene attributes, clamp flow, the 16-bit path, forward +
+    backward REPLAYED from one hipGraph (capture.CapturedStep) at 1024^2, batch 8 — against the same step launched eagerly from the same state.
+    The forward has no atomics (images agree to the last bf16 bit or one rounding step); the reductions' atomics reorder fp32 sums, so the loss
+    is held to 1e-4 relative and the walk gradient to a cosine of 0.9999 and 2e-2 of its largest entry."""
+    import gc
+    from latent2im_amd import capture, constants, selfcheck, synth
+    old = conv.PRECISION
+    try:
+        conv.PRECISION = 'bf16'
+        attrs = ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk']
+        size, batch = 1024, 8
+        zs = synth.z_sample(batch, seed=17)
+        alpha = np.ones((batch, 5)) * np.random.RandomState(18).uniform(-1, 1, 5)
+        ge = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform='scene')
+        assert type(ge.module.netG).__module__.endswith('nets16')
+        e = selfcheck.run_step(ge, zs, alpha, clamp=True, optimize=False)
+        e = {k: (v.detach().float().clone() if torch.is_tensor(v) else v) for k, v in e.items()}
+        del ge
+        gc.collect()
+        torch.cuda.empty_cache()
+        gr = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform='scene')
+        step = capture.CapturedStep(gr, batch, 5, clamp=True)
+        r = step(zs, alpha, optimize=False)
+        r2 = step(zs, alpha, optimize=False)                     # a second replay of the same inputs: the graph holds no state of its own
+        torch.cuda.synchronize()
+        for res in (r, r2):
+            x1, g = res['x1'].detach().float(), res['grad'].detach().float()
+            assert float((x1 - e['x1']).abs().max()) <= 2.0 ** -7 * float(e['x1'].abs().max())
+            assert abs(float(res['loss']) - float(e['loss'])) <= 1e-4 * abs(float(e['loss']))
+            assert float((res['eps'].float() - e['eps']).abs().max()) < 1e-4
+            cos = float((g * e['grad']).sum() / (g.norm() * e['grad'].norm()))
+            assert cos > 0.9999, cos
+            assert float((g - e['grad']).abs().max()) < 2e-2 * float(e['grad'].abs().max())
+        del step, gr
+        gc.collect()
+        torch.cuda.empty_cache()
+    finally:
+        conv.PRECISION = old
+        constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
+def test_bf16_data_parallel_matches_single_process(tmp_path):
+    """SURVEY 8(e) on the 16-bit path: two rank processes (one GPU here, process group over gloo; RCCL on a node) run the product graph with
+    L2I_PRECISION=bf16 for two optimizeParametersAll steps on strided shards of a global batch of 8, full loss; a single process runs the
+    global batch.  Sharding changes which samples share a launch, not a sample's arithmetic (bf16 rounding is per element, the discriminator's
+    minibatch-stddev groups stay intact), so the total, regressor and GAN terms agree to 1e-3 (the content term, a difference of rounded maps, to 5e-2) and the all-reduced walk
+    gradient to a cosine of 0.999."""
+    import os
+    import subprocess
+    import sys
+    from latent2im_amd import dist
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dp_worker.py')
+    args = ['64', '8', '2', '0']
+    env = dict(os.environ, L2I_DIST_BACKEND='gloo', L2I_PRECISION='bf16')
+    env.pop('WORLD_SIZE', None)
+    single, multi = str(tmp_path / 'single.npz'), str(tmp_path / 'dp2.npz')
+    r = subprocess.run([sys.executable, worker, single] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    codes, _ = dist.spawn_local(2, [sys.executable, worker, multi] + args, env=env, timeout=600)
+    assert codes == [0, 0], codes
+    a, b = np.load(single), np.load(multi)
+    assert int(a['world']) == 1 and int(b['world']) == 2
+    assert str(a['precision']) == 'bf16' and str(b['precision']) == 'bf16'
+    la, lb = a['losses'][0], b['losses'][0]                            # total, regressor, content, GAN
+    print('bf16 DP losses: single', la, 'two ranks', lb)
+    np.testing.assert_allclose(lb[[0, 1, 3]], la[[0, 1, 3]], rtol=1e-3, atol=1e-5)
+    # the content term is a mean squared DIFFERENCE of bf16-rounded feature maps (DESIGN.md section 2): a different launch shape rounds differently
+    np.testing.assert_allclose(lb[2], la[2], rtol=5e-2, atol=1e-5)
+    ga, gb = a['grads'][0].reshape(-1), b['grads'][0].reshape(-1)
+    cos = float((ga * gb).sum() / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+    assert cos > 0.999, cos
