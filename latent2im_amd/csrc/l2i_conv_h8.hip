@@ -31,6 +31,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
 
 namespace g8 {
 template <int WN, int K, int S, int TR, int KS_ = 2> struct Geo {
@@ -437,18 +438,24 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
         constexpr int NQ = WM * 2;
         const float gpos = (p.act == L2I_ACT_LRELU ? p.act_gain : 1.f) * p.out_gain;
         const float gneg = p.act == L2I_ACT_LRELU ? p.act_slope * p.act_gain * p.out_gain : (p.act == L2I_ACT_RELU ? 0.f : p.out_gain);
+        const bool plain_relu = p.act == L2I_ACT_RELU && p.out_gain == 1.f, identity = p.act == L2I_ACT_NONE && p.out_gain == 1.f;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int m = q >> 1, pr = q & 1;
             const int co0 = (g0 + 4 * m + 2 * pr) * 8;
             const bool gok = co0 < p.Cout;
             const int cc = gok ? co0 : 0;
-            float4 s0, s1, b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            // scale (1 when absent) and bias (0 when absent) as four channel pairs: g * s + b is one packed FMA per pair
+            f32x2_ sc2[4] = {{1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}}, bs2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
             if (p.out_scale) {
                 const float* sp = p.out_scale + (size_t)b * p.Cout + cc;
-                s0 = *reinterpret_cast<const float4*>(sp); s1 = *reinterpret_cast<const float4*>(sp + 4);
+                const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+                sc2[0] = f32x2_{s0.x, s0.y}; sc2[1] = f32x2_{s0.z, s0.w}; sc2[2] = f32x2_{s1.x, s1.y}; sc2[3] = f32x2_{s1.z, s1.w};
             }
-            if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + cc); b1 = *reinterpret_cast<const float4*>(p.bias + cc + 4); }
+            if (p.bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cc), b1 = *reinterpret_cast<const float4*>(p.bias + cc + 4);
+                bs2[0] = f32x2_{b0.x, b0.y}; bs2[1] = f32x2_{b0.z, b0.w}; bs2[2] = f32x2_{b1.x, b1.y}; bs2[3] = f32x2_{b1.z, b1.w};
+            }
             u32x4* const yq = yb + (size_t)(4 * m + 2 * pr) * plane;
 #pragma unroll
             for (int n = 0; n < WN; ++n) {
@@ -456,11 +463,26 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
                 for (int a = 0; a < NACC; ++a) {
                     float g[8];
                     h8_gather(acc[a][m][n], pr, half, g);
-                    if (p.out_scale) { g[0] *= s0.x; g[1] *= s0.y; g[2] *= s0.z; g[3] *= s0.w; g[4] *= s1.x; g[5] *= s1.y; g[6] *= s1.z; g[7] *= s1.w; }
-                    const float z = nz[n][a];
-                    g[0] += b0.x + z; g[1] += b0.y + z; g[2] += b0.z + z; g[3] += b0.w + z; g[4] += b1.x + z; g[5] += b1.y + z; g[6] += b1.z + z; g[7] += b1.w + z;
+                    f32x2_ v[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) g[e] = fmaxf(g[e] * gpos, g[e] * gneg);       // identity / ReLU / leaky ReLU with the gains folded (gpos >= gneg >= 0)
+                    for (int i = 0; i < 4; ++i) v[i] = f32x2_{g[2 * i], g[2 * i + 1]} * sc2[i] + bs2[i];
+                    if (p.noise) {
+                        const f32x2_ z = {nz[n][a], nz[n][a]};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += z;
+                    }
+                    if (plain_relu) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); }
+                    } else if (!identity) {                     // leaky ReLU / gains: max(v * gpos, v * gneg), gpos >= gneg >= 0
+                        const f32x2_ gp2 = {gpos, gpos}, gn2 = {gneg, gneg};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x2_ hi = v[i] * gp2, lo = v[i] * gn2;
+                            v[i].x = fmaxf(hi.x, lo.x); v[i].y = fmaxf(hi.y, lo.y);
+                        }
+                    }
+                    g[0] = v[0].x; g[1] = v[0].y; g[2] = v[1].x; g[3] = v[1].y; g[4] = v[2].x; g[5] = v[2].y; g[6] = v[3].x; g[7] = v[3].y;
                     const u32x4 out = {cvt_pk_bf16_h8(g[0], g[1]), cvt_pk_bf16_h8(g[2], g[3]), cvt_pk_bf16_h8(g[4], g[5]), cvt_pk_bf16_h8(g[6], g[7])};
                     unsigned off;
                     const bool ok = pix(n, a, off);

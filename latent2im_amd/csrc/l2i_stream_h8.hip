@@ -251,6 +251,149 @@ __global__ __launch_bounds__(256) void upfirdn2d_h8_sep4_kernel(u32x4* __restric
     }
 }
 
+// The discriminator's skip path (networks.py:586-590) in the same register-streaming form.  Down: blur with pad (1, 1) evaluated at every second
+// pixel — a lane owns one OUTPUT column, loads its two input columns 2 ox, 2 ox + 1 of every input row once and takes column 2 ox - 1 from its
+// left neighbour and 2 ox + 2 from its right one (DPP wave_shr:1 / wave_shl:1); 62 of 64 lanes store.  Up: its adjoint, zero insertion + blur with
+// pad (2, 1) — a lane owns one INPUT column j and produces output columns 2 j (t0 in[j-1] + t2 in[j]) and 2 j + 1 (t1 in[j] + t3 in[j+1]) of
+// output rows 2 i (t0 H[i-1] + t2 H[i]) and 2 i + 1 (t1 H[i] + t3 H[i+1]): every input slot is loaded once, every output slot (and addend slot)
+// touched once, no tap is multiplied by an inserted zero.
+__device__ __forceinline__ float lane_shl1(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x130, 0xf, 0xf, false));   // wave_shl:1 (lane 63 gets 0)
+}
+template <int RB>
+__global__ __launch_bounds__(256) void upfirdn2d_h8_sep4_down2_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ x, float4 ty, float4 tx, long long planes, int in_h, int in_w,
+                                                                      int out_h, int out_w) {
+    constexpr int PF = 4, NR = 2 * RB + 2;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int chunks = (out_w + 61) / 62, bands = (out_h + RB - 1) / RB;
+    const long long total = planes * bands * chunks;
+    const unsigned plane_bytes = (unsigned)in_h * (unsigned)in_w * 16u;
+    for (long long u = (long long)blockIdx.x * 4 + wv; u < total; u += (long long)gridDim.x * 4) {
+        const int chunk = (int)(u % chunks);
+        const long long pb = u / chunks;
+        const int band = (int)(pb % bands);
+        const long long pl = pb / bands;
+        const int r0 = band * RB;
+        const int ox = chunk * 62 + lane - 1;                  // lanes 1 .. 62 store
+        const int ixa = 2 * ox, ixb = 2 * ox + 1;
+        const bool oka = ixa >= 0 && ixa < in_w, okb = ixb >= 0 && ixb < in_w;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + pl * (long long)in_h * in_w), 0, plane_bytes, 0x00020000);
+        const int iy0 = 2 * r0 - 1;
+        auto offa = [&](int r) -> int { return oka ? ((iy0 + r) * in_w + ixa) * 16 : -1; };
+        auto offb = [&](int r) -> int { return okb ? ((iy0 + r) * in_w + ixb) * 16 : -1; };
+        u32x4 qa[PF], qb[PF];
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            qa[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, offa(r), 0, 0));
+            qb[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, offb(r), 0, 0));
+        }
+        float ring[4][8];
+        const bool lane_out = lane >= 1 && lane <= 62 && ox < out_w;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float va[8], vb[8];
+            unpack8(qa[r % PF], va);
+            unpack8(qb[r % PF], vb);
+            if (r + PF < NR) {
+                qa[r % PF] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, offa(r + PF), 0, 0));
+                qb[r % PF] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, offb(r + PF), 0, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                ring[r & 3][e] = fmaf(tx.x, lane_shr1(vb[e]), fmaf(tx.y, va[e], fmaf(tx.z, vb[e], tx.w * lane_shl1(va[e]))));
+            if (r >= 3 && ((r - 3) & 1) == 0) {
+                const int oy = r0 + (r - 3) / 2;
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    acc[e] = ty.x * ring[(r - 3) & 3][e] + ty.y * ring[(r - 2) & 3][e] + ty.z * ring[(r - 1) & 3][e] + ty.w * ring[r & 3][e];
+                if (lane_out && oy < out_h) y[(pl * out_h + oy) * out_w + ox] = pack8(acc);
+            }
+        }
+    }
+}
+template <int RB>
+__global__ __launch_bounds__(256) void upfirdn2d_h8_sep4_up2_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ x, float4 ty, float4 tx, long long planes, int in_h, int in_w,
+                                                                    int out_h, int out_w, const u32x4* __restrict__ addend) {
+    constexpr int PF = 4, NR = RB + 2;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int chunks = (in_w + 61) / 62, bands = (in_h + RB - 1) / RB;
+    const long long total = planes * bands * chunks;
+    const unsigned plane_bytes = (unsigned)in_h * (unsigned)in_w * 16u;
+    for (long long u = (long long)blockIdx.x * 4 + wv; u < total; u += (long long)gridDim.x * 4) {
+        const int chunk = (int)(u % chunks);
+        const long long pb = u / chunks;
+        const int band = (int)(pb % bands);
+        const long long pl = pb / bands;
+        const int r0 = band * RB;
+        const int jx = chunk * 62 + lane - 1;                  // this lane's input column; lanes 1 .. 62 store output columns 2 jx, 2 jx + 1
+        const bool ok = jx >= 0 && jx < in_w;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + pl * (long long)in_h * in_w), 0, plane_bytes, 0x00020000);
+        auto off = [&](int r) -> int { return ok ? ((r0 - 1 + r) * in_w + jx) * 16 : -1; };      // rows above / below the map: out of range, zeros
+        const bool lane_out = lane >= 1 && lane <= 62 && ok;
+        u32x4* const yp = y + pl * (long long)out_h * out_w + 2 * jx;
+        const u32x4* const ap = addend ? addend + pl * (long long)out_h * out_w + 2 * jx : nullptr;
+        u32x4 q[PF];
+#pragma unroll
+        for (int r = 0; r < PF; ++r) q[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off(r), 0, 0));
+        // addend slots of the rows a step emits (odd row of input row i - 1, even row of input row i), requested one step ahead
+        u32x4 ad[2][4];
+        auto issue_add = [&](int r, int slot) {                 // step r: input row i = r0 - 1 + r; rows 2 i - 1 (r >= 2) and 2 i (1 <= r <= RB)
+            const int i = r0 - 1 + r;
+            const int oyo = 2 * i - 1, oye = 2 * i;
+            const bool vo = lane_out && r >= 2 && r <= RB + 1 && oyo < out_h, ve = lane_out && r >= 1 && r <= RB && oye < out_h;
+            const long long bo = vo ? (long long)oyo * out_w : -2LL * jx, be = ve ? (long long)oye * out_w : -2LL * jx;      // invalid: slot 0 of the plane
+            ad[slot][0] = ap[bo]; ad[slot][1] = ap[bo + (vo ? 1 : 0)]; ad[slot][2] = ap[be]; ad[slot][3] = ap[be + (ve ? 1 : 0)];
+        };
+        float pe[8], po[8];                                     // horizontal sums of the previous input row: even / odd output columns
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pe[e] = po[e] = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float v[8], he[8], ho[8];
+            unpack8(q[r % PF], v);
+            if (r + PF < NR) q[r % PF] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off(r + PF), 0, 0));
+            if (ap && r + 1 < NR) issue_add(r + 1, (r + 1) & 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                he[e] = fmaf(tx.x, lane_shr1(v[e]), tx.z * v[e]);
+                ho[e] = fmaf(tx.y, v[e], tx.w * lane_shl1(v[e]));
+            }
+            const int i = r0 - 1 + r;
+            if (r >= 2) {                                       // odd output row of input row i - 1: t1 H[i-1] + t3 H[i]
+                const int oy = 2 * i - 1;
+                float a0[8], a1[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a0[e] = fmaf(ty.y, pe[e], ty.w * he[e]); a1[e] = fmaf(ty.y, po[e], ty.w * ho[e]); }
+                if (ap) {
+                    float t0[8], t1[8];
+                    unpack8(ad[r & 1][0], t0); unpack8(ad[r & 1][1], t1);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { a0[e] += t0[e]; a1[e] += t1[e]; }
+                }
+                if (lane_out && oy < out_h) { yp[(long long)oy * out_w] = pack8(a0); yp[(long long)oy * out_w + 1] = pack8(a1); }
+            }
+            if (r >= 1 && r <= RB) {                            // even output row of input row i: t0 H[i-1] + t2 H[i]
+                const int oy = 2 * i;
+                float a0[8], a1[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a0[e] = fmaf(ty.x, pe[e], ty.z * he[e]); a1[e] = fmaf(ty.x, po[e], ty.z * ho[e]); }
+                if (ap) {
+                    float t0[8], t1[8];
+                    unpack8(ad[r & 1][2], t0); unpack8(ad[r & 1][3], t1);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { a0[e] += t0[e]; a1[e] += t1[e]; }
+                }
+                if (lane_out && oy < out_h) { yp[(long long)oy * out_w] = pack8(a0); yp[(long long)oy * out_w + 1] = pack8(a1); }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pe[e] = he[e]; po[e] = ho[e]; }
+        }
+    }
+}
+
 extern "C" int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
                                 int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
                                 float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, void* stream) {
@@ -268,6 +411,26 @@ extern "C" int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t 
         hipLaunchKernelGGL((upfirdn2d_h8_sep4_kernel<RB>), dim3(l2i_grid_for(waves, 4, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)x, ty, tx,
                            (long long)planes, channels / 8, in_h, in_w, out_h, out_w, pad_x0, pad_y0, noise, noise_w, bias, act, act_slope, act_gain, (const u32x4*)mask,
                            mask_pos, mask_neg, (const u32x4*)addend);
+        L2I_CHECK_LAUNCH();
+        return L2I_OK;
+    }
+    const bool plain = !noise && !bias && act == L2I_ACT_NONE && act_gain == 1.f && !mask;
+    if (k1y && k1x && kh == 4 && kw == 4 && plain && up == 1 && down == 2 && !addend && pad_x0 == 1 && pad_y0 == 1 && (long long)in_h * in_w * 16 < 0x7fffffffLL) {
+        constexpr int RB = 8;                              // the discriminator's skip blur, evaluated where the stride-2 1x1 samples it
+        const float4 ty = make_float4(k1y[3], k1y[2], k1y[1], k1y[0]), tx = make_float4(k1x[3], k1x[2], k1x[1], k1x[0]);
+        const long long waves = (long long)planes * ((out_h + RB - 1) / RB) * ((out_w + 61) / 62);
+        hipLaunchKernelGGL((upfirdn2d_h8_sep4_down2_kernel<RB>), dim3(l2i_grid_for(waves, 4, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)x, ty, tx,
+                           (long long)planes, in_h, in_w, out_h, out_w);
+        L2I_CHECK_LAUNCH();
+        return L2I_OK;
+    }
+    if (k1y && k1x && kh == 4 && kw == 4 && plain && up == 2 && down == 1 && pad_x0 == 2 && pad_y0 == 2 && out_h == 2 * in_h && out_w == 2 * in_w &&
+        (long long)in_h * in_w * 16 < 0x7fffffffLL) {
+        constexpr int RB = 8;                              // its adjoint (zero insertion + blur), with the skip sum as addend
+        const float4 ty = make_float4(k1y[3], k1y[2], k1y[1], k1y[0]), tx = make_float4(k1x[3], k1x[2], k1x[1], k1x[0]);
+        const long long waves = (long long)planes * ((in_h + RB - 1) / RB) * ((in_w + 61) / 62);
+        hipLaunchKernelGGL((upfirdn2d_h8_sep4_up2_kernel<RB>), dim3(l2i_grid_for(waves, 4, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)x, ty, tx,
+                           (long long)planes, in_h, in_w, out_h, out_w, (const u32x4*)addend);
         L2I_CHECK_LAUNCH();
         return L2I_OK;
     }

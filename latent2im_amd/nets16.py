@@ -242,7 +242,7 @@ class _DBody16Fn(torch.autograd.Function):
             t = K16.upfirdn2d(y1, blk['k'], pad=(2, 2, 2, 2), sep=blk['ksep'])  # Blur before the stride-2 3x3 (networks.py:530-536): (h+1)^2
             y2 = blk['c2'].forward(t, bias=blk['b2'], **lr)
             del t
-            ts = K16.upfirdn2d(cur, blk['k'], down=2, pad=(1, 1, 1, 1))          # skip (networks.py:586-590): the blur only where the stride-2 1x1 samples it
+            ts = K16.upfirdn2d(cur, blk['k'], down=2, pad=(1, 1, 1, 1), sep=blk['ksep'])          # skip (networks.py:586-590): the blur only where the stride-2 1x1 samples it
             out = blk['sk1'].forward(ts, residual=y2, out_gain=1.0 / SQRT2)      # (conv2 + skip) / sqrt2
             del ts
             if keep:
@@ -267,7 +267,7 @@ class _DBody16Fn(torch.autograd.Function):
             g_a = blk['c1'].dgrad(g_y1, in_hw)
             del g_y1
             g_ts = blk['sk1'].dgrad(g, (h // 2, h // 2), out_gain=1.0 / SQRT2)
-            g = K16.upfirdn2d(g_ts, blk['kf'], up=2, pad=(2, 1, 2, 1), addend=g_a)      # adjoint of (blur, every second pixel): zero-insertion FIR
+            g = K16.upfirdn2d(g_ts, blk['kf'], up=2, pad=(2, 1, 2, 1), addend=g_a, sep=blk['kfsep'])      # adjoint of (blur, every second pixel): zero-insertion FIR
             del g_ts, g_a
         g_img = net.conv0.dgrad(K16.mask_mul(g, saved[0], *LRELU_MASK), ctx.in_hw, out_f32=True)
         ctx.saved = None

@@ -137,6 +137,17 @@ def test_h8_upfirdn2d_all_path_geometries():
     x = T(rs.randn(1, 8, 70, 19))
     y = K16.upfirdn2d(conv.to_h8(x.to(DEV)), k.to(DEV), pad=(2, 2, 2, 2), sep=K16.separable(k))
     close16(conv.from_h8(y, 8), sg2.upfirdn2d(rb(x).double(), k.double(), pad=(2, 2)), 'upfirdn tall')
+    # the discriminator's skip pair on maps spanning several 62-column chunks and 8-row bands (ragged ends): blur + every second pixel, and its
+    # adjoint (zero insertion + blur) with the skip sum as addend
+    x = T(rs.randn(1, 8, 140, 150))
+    y = K16.upfirdn2d(conv.to_h8(x.to(DEV)), k.to(DEV), down=2, pad=(1, 1, 1, 1), sep=K16.separable(k))
+    close16(conv.from_h8(y, 8), sg2.upfirdn2d(rb(x).double(), k.double(), down=2, pad=(1, 1)), 'upfirdn down 2, wide')
+    x, add = T(rs.randn(2, 8, 70, 75)), T(rs.randn(2, 8, 140, 150))
+    kk = k * 4
+    for a in (None, add):
+        y = K16.upfirdn2d(conv.to_h8(x.to(DEV)), kk.to(DEV), up=2, pad=(2, 1, 2, 1), addend=None if a is None else conv.to_h8(a.to(DEV)), sep=K16.separable(kk))
+        ref = sg2.upfirdn2d(rb(x).double(), kk.double(), up=2, pad=(2, 1)) + (0 if a is None else rb(a).double())
+        close16(conv.from_h8(y, 8), ref, 'upfirdn up 2, wide, addend %s' % (a is not None))
     # fused epilogue of the generator's up layers: noise, bias, leaky ReLU * sqrt(2)
     x, nz, bias = T(rs.randn(2, 16, 33, 33)), T(rs.randn(2, 1, 32, 32)), T(rs.randn(16))
     kk = k * 4
