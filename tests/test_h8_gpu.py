@@ -351,3 +351,32 @@ def test_bf16_data_parallel_matches_single_process(tmp_path):
     ga, gb = a['grads'][0].reshape(-1), b['grads'][0].reshape(-1)
     cos = float((ga * gb).sum() / (np.linalg.norm(ga) * np.linalg.norm(gb)))
     assert cos > 0.999, cos
+
+
+def test_train_multi_attr_cli_config5_flow_bf16_hipgraph(tmp_path):
+    """BASELINE config 5 through the drop-in driver: train_multi_attr.py --transform scene with five transient-scene attributes,
+    --precision bf16 --hip_graph (16-bit path, forward + backward replayed from the captured graph), 64^2, two iterations: log and checkpoints
+    under the reference's names, a finite walk that moved."""
+    import os
+    from latent2im_amd import constants, trainer
+    os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    models = str(tmp_path / 'models')
+    argv = ['--model', 'stylegan_v2_real', '--transform', 'scene', '--num_samples', '8', '--learning_rate', '1e-3', '--latent', 'w',
+            '--walk_type', 'linear', '--loss', 'l2', '--attrList', 'dirty,daylight,night,sunrisesunset,dawndusk',
+            '--attrPath', './dataset/attributes_scene.txt', '--models_dir', models, '--overwrite_config', '--resolution', '64',
+            '--batch_size', '4', '--n_epoch', '1', '--seed', '3', '--model_save_freq', '1', '--synthetic_weights', '--precision', 'bf16', '--hip_graph']
+    old = conv.PRECISION
+    try:
+        trainer.main(multi_attr=True, argv=argv)
+        out = os.path.join(models, 'stylegan_v2_real_scene_linear_lr0.001_l2_w')
+        last = torch.load(os.path.join(out, 'model_w_1_final_walk_module.ckpt'), map_location='cpu', weights_only=False)
+        assert tuple(last.w.shape)[0] == 5 and torch.isfinite(last.w).all()
+        assert float(last.w.detach().std()) > 0.01
+        log = open(os.path.join(out, 'log.txt')).read()
+        assert 'T, epc, bst, lss, alpha:' in log
+        import yaml
+        opt = yaml.safe_load(open(os.path.join(out, 'opt.yml')))
+        assert opt.get('precision') == 'bf16' and opt.get('hip_graph') is True
+    finally:
+        conv.PRECISION = old
+        constants.resolution, constants.BATCH_SIZE = 256, 4

@@ -756,7 +756,10 @@ def test_data_parallel_product_graph_matches_single_process(tmp_path, no_gan):
     # zero may have stepped the other way (see below) and the small content term sees it at the 1e-4 level
     close(b['losses'][1], a['losses'][1], 1e-3, 1e-6)
     for s in range(2):
-        grad_ok(T(b['grads'][s]), T(a['grads'][s]))                   # same samples, different tile shapes: a few flipped masks at most
+        # same samples, different launch shapes: at 64^2 most maps are <= 16 x 16, where a batch-4 and a batch-8 launch pack different samples
+        # into a tile and sum in a different order, so ReLU / max-pool masks within rounding of zero flip between the two runs (they do not
+        # between either run and the oracle's bar at the bench shapes): 1 % of the entries may be off by more than 2e-3 of the largest, none by 10 %
+        grad_ok(T(b['grads'][s]), T(a['grads'][s]), frac_tol=1e-2)
         assert relmax(T(b['grads'][s]), T(a['grads'][s])) < 2e-2
     step = np.abs(a['walk'] - synth.walk_init(2, 10, seed=7).reshape(-1)).max()
     assert step > 1e-4                                                # Adam moved the walk ...
