@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libl2i_hip.so')
+LIB_PATH = os.environ.get('L2I_LIB') or os.path.join(_HERE, 'libl2i_hip.so')      # L2I_LIB: another build of the library (A/B probes)
 
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 

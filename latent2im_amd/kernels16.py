@@ -1,6 +1,7 @@
 """Python call wrappers for the streaming kernels of the 16-bit path (csrc/l2i_stream_h8.hip, include/l2i.h): bf16 tensors in the
 channel-blocked h8 layout [B, C/8, H, W, 8] in, out; fp32 for images, noise, bias, per-sample vectors and reductions.  No autograd here."""
 import ctypes
+import os
 
 import torch
 
@@ -62,7 +63,7 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0, 0, 0), noise=None, noise_w=0.0
     oh = (H * up + pad[2] + pad[3] - kh) // down + 1
     ow = (W * up + pad[0] + pad[1] - kw) // down + 1
     y = torch.empty(B, G8, oh, ow, 8, device=x.device, dtype=BF)
-    use_sep = sep is not None and kh == 4 and kw == 4            # the library picks its separable register-streaming kernels (no resampling, down 2, up 2) where they apply
+    use_sep = sep is not None and kh == 4 and kw == 4 and not os.environ.get('L2I_H8_NOSEP')            # the library picks its separable register-streaming kernels (no resampling, down 2, up 2) where they apply
     k1y = (ctypes.c_float * 4)(*sep[0]) if use_sep else None
     k1x = (ctypes.c_float * 4)(*sep[1]) if use_sep else None
     _lib.check(lib.l2i_upfirdn2d_h8(_lib.ptr(y), _h8(x), _lib.fptr(kernel.contiguous()), B * G8, G8 * 8, H, W, kh, kw, up, down, pad[0], pad[1], pad[2], pad[3],

@@ -350,6 +350,7 @@ def test_bf16_data_parallel_matches_single_process(tmp_path):
     np.testing.assert_allclose(lb[2], la[2], rtol=5e-2, atol=1e-5)
     ga, gb = a['grads'][0].reshape(-1), b['grads'][0].reshape(-1)
     cos = float((ga * gb).sum() / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+    print('bf16 DP walk-gradient cosine', cos)
     assert cos > 0.999, cos
 
 

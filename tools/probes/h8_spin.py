@@ -1,7 +1,9 @@
 """Keeps one l2i_conv2d_h8 shape running for a few seconds (for clock / power sampling beside it): python h8_spin.py cin cout k stride res seconds"""
 import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from latent2im_amd import conv
+from latent2im_amd import conv, _lib
+if os.environ.get('L2I_ALT_LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['L2I_ALT_LIB'])      # e.g. a timing-ablation build (tools/probes/h8_ablate.sh)
 cin, cout, k, stride, res = (int(v) for v in sys.argv[1:6])
 secs = float(sys.argv[6])
 b = 8
