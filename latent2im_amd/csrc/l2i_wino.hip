@@ -45,16 +45,19 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_a
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // pk_mul_op: the product feeds an MFMA next, the 2 wait states of "VALU write -> MFMA read" ride in the same asm statement
 __device__ __forceinline__ f32x2 pk_mul_op(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// (a.lo + b.hi, a.lo - b.hi)
+// (a.lo + b.hi, a.lo - b.hi).  The half selection sits on SRC0 (b first: the sum commutes, the bits are the same): packed fp32 with op_sel set on
+// src1 (the first form of this helper, and what hipcc's SLP vectorizer emits) returns sporadically wrong results while a bf16-MFMA kernel is resident
+// on the same CUs; op_sel on src0, op_sel_hi and plain operands do not (tools/probes/pk_beside_conv_h8.py).  No configuration
+// of the step runs this kernel beside a bf16-MFMA one; tools/probes/wino_beside_conv_h8.py does: 170-197 distinct results in 200 before, 1 now.
 __device__ __forceinline__ f32x2 pk_lo_pm_hi(f32x2 a, f32x2 b) {
-    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(b), "v"(a)); return r;
 }
 // the same two with the "VALU write -> MFMA read" wait states attached (layers without a style scale feed them to the MFMAs directly)
 __device__ __forceinline__ f32x2 pk_sub_op(f32x2 a, f32x2 b) {
     f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
 __device__ __forceinline__ f32x2 pk_lo_pm_hi_op(f32x2 a, f32x2 b) {
-    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b)); return r;
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\ts_nop 1" : "=v"(r) : "v"(b), "v"(a)); return r;
 }
 
 struct WinoLaunch {
