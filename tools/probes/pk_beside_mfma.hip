@@ -2,6 +2,8 @@
 // kernel (another stream of the same process) keeps the matrix cores busy?  Found while chasing run-to-run differences of the 16-bit path
 // (tools/probes/h8_two_streams.py): the streaming kernels that hipcc had SLP-packed into v_pk_* gave sporadically different results beside
 // conv_h8_kernel; built with -fno-slp-vectorize they did not.
+// Result (MI355X, ROCm 7.2): only the forms with op_sel set on SRC1 (src1's high half for the low result) go wrong, and only beside an aggressor whose
+// bf16 MFMAs are fed from LDS (KIND 2 below; the register-only spinners KIND 0 / 1 leave every form intact): ~2e4 wrong results of 8.4e10.
 //   hipcc --offload-arch=gfx950 -O3 -o tools/probes/bin/pk_beside_mfma tools/probes/pk_beside_mfma.hip && tools/probes/bin/pk_beside_mfma
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -18,6 +20,21 @@ template <int KIND> __global__ __launch_bounds__(256) void mfma_spin(float* out,
         for (int i = 0; i < iters; ++i) {
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
             c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+        }
+    } else if (KIND == 2) {                              // bf16 32x32x16 with both operands re-read from LDS (ds_read_b128) every step, as conv_h8's K loop does
+        extern __shared__ __attribute__((aligned(16))) unsigned lds_u[];
+        for (int i = threadIdx.x; i < 9 * 1024; i += 256) lds_u[i] = 0x3c003c00u + (unsigned)i * 7u;
+        __syncthreads();
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* l4 = reinterpret_cast<const u32x4*>(lds_u);
+        const int lane = threadIdx.x & 63;
+        for (int i = 0; i < iters; ++i) {
+            const int o = (i & 7) * 256;
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, l4[o + lane]), a1 = __builtin_bit_cast(bf16x8, l4[o + 64 + lane]);
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, l4[o + 128 + lane]), b1 = __builtin_bit_cast(bf16x8, l4[o + 192 + lane]);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c3, 0, 0, 0);
+            if ((i & 15) == 15) __syncthreads();
         }
     } else {                                             // fp32 32x32x2
         const float a = 0.001f * threadIdx.x, b = 0.002f * threadIdx.x;
@@ -81,6 +98,7 @@ template <int OP> static unsigned long long run(int aggressor, const float* seed
         // 36 KiB of (unused) LDS per block: four blocks per CU, as conv_h8_kernel runs — half of every SIMD's wave slots stay free for the other stream
         if (aggressor == 0) hipLaunchKernelGGL(mfma_spin<0>, dim3(2048), dim3(256), 36 * 1024, sa, sink, 2000);
         if (aggressor == 1) hipLaunchKernelGGL(mfma_spin<1>, dim3(2048), dim3(256), 36 * 1024, sa, sink, 1000);
+        if (aggressor == 2) hipLaunchKernelGGL(mfma_spin<2>, dim3(2048), dim3(256), 36 * 1024, sa, sink, 2000);
         hipLaunchKernelGGL(pk_check<OP>, dim3(1024), dim3(256), 0, sb, bad, 4000, seed);
     }
     hipDeviceSynchronize();
@@ -96,10 +114,10 @@ int main() {
     hipMalloc(&seed, sizeof(hs)); hipMalloc(&sink, 2048 * 256 * 4); hipMalloc(&bad, 8);
     hipMemcpy(seed, hs, sizeof(hs), hipMemcpyHostToDevice);
     hipStream_t sa, sb; hipStreamCreate(&sa); hipStreamCreate(&sb);
-    const char* agg[3] = {"bf16 MFMA 32x32x16 on the other stream", "fp32 MFMA 32x32x2 on the other stream", "nothing on the other stream"};
+    const char* agg[4] = {"bf16 MFMA 32x32x16 on the other stream", "fp32 MFMA 32x32x2 on the other stream", "bf16 MFMA fed from LDS on the other stream", "nothing on the other stream"};
     const double total = 40.0 * 1024 * 256 * 4000 * 2;
-    for (int a = 0; a < 3; ++a) {
-        const int which = a == 2 ? -1 : a;
+    for (int a = 0; a < 4; ++a) {
+        const int which = a == 3 ? -1 : a;
         const unsigned long long r0 = run<0>(which, seed, sink, bad, sa, sb), r1 = run<1>(which, seed, sink, bad, sa, sb), r2 = run<2>(which, seed, sink, bad, sa, sb);
         const unsigned long long r3 = run<3>(which, seed, sink, bad, sa, sb), r4 = run<4>(which, seed, sink, bad, sa, sb), r5 = run<5>(which, seed, sink, bad, sa, sb);
         const unsigned long long r6 = run<6>(which, seed, sink, bad, sa, sb);
