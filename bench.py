@@ -13,6 +13,10 @@ sample z -> style MLP -> StyleGAN2 synthesis (original) -> ResNet-50 regressor -
   dataset/attributes_scene.txt, 5 attributes, train_multi_attr.py clamp flow), batch 8 per GPU, every contraction on the 16-bit
   matrix cores (3-term bf16 split, fp32 accumulation: fp32-class results), forward+backward replayed from ONE hipGraph.
 
+The line carries `step_ms` (one HIP event per timed step on the main stream: per-step times, median / min / max), `sensors`
+(shader clock and socket power before / during / after the timed region), `config5` (the c5 workload on the 16-bit path, hipGraph, with its
+own roofline) and `reg_only` (--no_content_loss --no_gan_loss: the one loss configuration SURVEY 8d calls jointly reachable) beside the headline.
+
 N > 1: one rank process per GPU (RCCL over xGMI).  `python bench.py --gpus N` starts the ranks itself; under
 torch.distributed.run (WORLD_SIZE set) it is one of them.  Weak scaling: the per-GPU batch is fixed; ranks draw identical z /
 alpha and take every N-th sample; the only collective is one all-reduce of the walk gradient per step.  Prints ONE JSON line
@@ -93,6 +97,86 @@ def lib_hash():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
+def source_hash():
+    from latent2im_amd import _lib
+    return _lib.source_hash()
+
+
+def gpu_sensors(index=0):
+    """{sclk_mhz, power_w, source}: current shader clock and socket power of the GPU, from amdgpu's sysfs files when readable (microseconds,
+    no subprocess: usable between steps), else one `rocm-smi --showclocks --showpower` call; fields are None when neither answers."""
+    import glob
+    out = dict(sclk_mhz=None, power_w=None, source=None)
+    cards = sorted(d for d in glob.glob('/sys/class/drm/card[0-9]*/device') if os.path.isfile(os.path.join(d, 'pp_dpm_sclk')))
+    if cards:
+        d = cards[min(index, len(cards) - 1)]
+        try:
+            for line in open(os.path.join(d, 'pp_dpm_sclk')):
+                if '*' in line:
+                    out['sclk_mhz'] = float(line.split(':')[1].lower().replace('mhz', '').replace('*', '').strip())
+            for pat in ('hwmon/hwmon*/power1_input', 'hwmon/hwmon*/power1_average'):
+                for f in glob.glob(os.path.join(d, pat)):
+                    out['power_w'] = float(open(f).read().strip()) / 1e6
+                    break
+                if out['power_w'] is not None:
+                    break
+            out['source'] = 'sysfs:' + d.split('/')[4]
+        except (OSError, ValueError, IndexError):
+            pass
+    if out['sclk_mhz'] is None and out['power_w'] is None and not os.environ.get('L2I_NO_ROCM_SMI'):
+        import re
+        import subprocess
+        try:
+            txt = subprocess.run(['rocm-smi', '-d', str(index), '--showclocks', '--showpower'], capture_output=True, text=True, timeout=10).stdout
+            m = re.search(r'sclk clock level:\s*\d+:?\s*\((\d+)Mhz\)', txt)
+            if m:
+                out['sclk_mhz'] = float(m.group(1))
+            m = re.search(r'Power \(W\):\s*([0-9.]+)', txt)
+            if m:
+                out['power_w'] = float(m.group(1))
+            out['source'] = 'rocm-smi'
+        except (OSError, subprocess.SubprocessError):
+            pass
+    return out
+
+
+def timed_steps(one_step, first, steps, max_ahead, sensor_index=None, sensor_every=5):
+    """EXACTLY `steps` steps bracketed by barrier + device synchronisation on both sides (wall clock = the reported time), with one HIP
+    event recorded on the main stream after every step (the step's last launches — all-reduce, Adam — are on it): per-step GPU times
+    without any host synchronisation of the newest `max_ahead` steps.  The host waits for step i - max_ahead before launching step i
+    (the reference synchronises every step, train.py:110; unbounded run-ahead only grows the caching allocator's footprint — blocks used on
+    the loss-branch streams are handed back when their events complete).  Returns (wall seconds, [ms per step], last result, sensors)."""
+    from latent2im_amd import dist
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    sens = []
+    cheap = sensor_index is not None and gpu_sensors.__dict__.get('cheap', False)
+    t0 = time.perf_counter()
+    evs[0].record()
+    r = None
+    for i in range(steps):
+        if max_ahead > 0 and i >= max_ahead:
+            evs[i - max_ahead + 1].synchronize()
+        r = one_step(first + i)
+        evs[i + 1].record()
+        if cheap and i % sensor_every == sensor_every - 1:
+            sens.append(dict(gpu_sensors(sensor_index), after_launching_step=i + 1))
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return elapsed, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)], r, sens
+
+
+def step_stats(ms):
+    srt = sorted(ms)
+    n = len(srt)
+    return dict(step_ms=[round(x, 2) for x in ms], median_ms=round(srt[n // 2] if n % 2 else 0.5 * (srt[n // 2 - 1] + srt[n // 2]), 2),
+                min_ms=round(srt[0], 2), max_ms=round(srt[-1], 2))
+
+
 def call_bytes(q):
     """Algorithmic HBM bytes of a conv call: input (+ its gradient mask) read once, output written once, every fused epilogue
     operand (residual, its mask, output mask, accumulate, res_sub) read once; weights / per-sample vectors are noise."""
@@ -128,24 +212,213 @@ def family_table(prof, steps):
     return rows
 
 
+def roofline_block(prof, steps, tag, workload_key, t_events):
+    """`roofline` object from the per-launch event pass (`prof`): dominant conv family, the roof it is nearer to, every family, the PMC
+    traffic figure of profiles/ when it was taken on these kernel sources and this workload."""
+    from latent2im_amd import conv
+    fams = family_table(prof, steps)
+    dom = fams[0]                                           # the family with the most GPU time per step
+    tot_ms = sum(q[0].elapsed_time(q[1]) for q in prof)
+    tot_flop = sum(q[2] for q in prof)
+    exe_flop = sum(q[2] * conv.FAMILY_INFO[q[5]][1] for q in prof)
+    peak_all = max(f['peak_tflops'] for f in fams)
+    traffic, traffic_note = None, 'no PMC summary under profiles/ for these kernel sources and this workload'
+    src = source_hash()
+    for rnd in ('r04', 'r03'):
+        tp = os.path.join(ROOT, 'profiles', '%s_%s_hbm_traffic.json' % (rnd, tag))
+        if not os.path.isfile(tp):
+            continue
+        tj = json.load(open(tp))
+        ent = tj.get('per_family', {}).get(dom['family'])
+        same_build = tj.get('src_sha256_16') == src or ('src_sha256_16' not in tj and tj.get('lib_sha256_16') == lib_hash())
+        if same_build and tj.get('workload') == workload_key and ent and abs(ent['launches_per_step'] - dom['launches_per_step']) < 0.5:
+            traffic = round(ent['bytes_per_launch'])
+            traffic_note = ('HBM bytes per launch of %s from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate) over this command with '
+                            '--serial_streams (profiles/%s, tools/hbm_traffic.py): KiB -> bytes, FETCH_SIZE doubled (gfx950), both factors checked on '
+                            'a kernel of known byte count in the same run; the summary carries the sha256 of the kernel SOURCES it was taken with '
+                            '(%s) and is dropped when they differ' % (dom['kernel'], os.path.basename(tp), src))
+            break
+        traffic_note = 'profiles/%s was taken with other kernel sources / workload (sources %s now): dropped' % (os.path.basename(tp), src)
+    hbm_frac = round(dom['hbm_GBs_algorithmic'] / HBM_PEAK_GBS, 4)
+    if hbm_frac > dom['frac']:                              # the 16-bit kernels: closer to the HBM roof than to the bf16 matrix roof
+        head = dict(bound='hbm', kernel=dom['kernel'], family=dom['family'], achieved=dom['hbm_GBs_algorithmic'], peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=hbm_frac, mfma_bound=dict(peak_TFLOPs=dom['peak_tflops'], achieved_TFLOPs_executed=dom['executed_tflops'], frac=dom['frac']))
+    else:
+        head = dict(bound='mfma', kernel=dom['kernel'], family=dom['family'], achieved=dom['executed_tflops'], peak=dom['peak_tflops'],
+                    unit='TFLOP/s', frac=dom['frac'])
+    return dict(head,
+                traffic=traffic, traffic_unit='bytes per launch', traffic_note=traffic_note,
+                algorithmic_tflops=dom['algorithmic_tflops'], algorithmic_flop_per_launch=dom['algorithmic_flop_per_launch'],
+                algorithmic_bytes_per_launch=dom['algorithmic_bytes_per_launch'], avg_launch_ms=dom['avg_launch_ms'],
+                launches_per_step=dom['launches_per_step'], kernel_ms_per_step=dom['ms_per_step'],
+                hbm_bound=dict(peak_GBs=HBM_PEAK_GBS, achieved_GBs_algorithmic=dom['hbm_GBs_algorithmic'], frac=hbm_frac),
+                families=fams,
+                all_conv=dict(launches_per_step=len(prof) // steps, ms_per_step=round(tot_ms / steps, 2),
+                              algorithmic_tflop_per_step=round(tot_flop / steps / 1e12, 3),
+                              algorithmic_tflops=round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
+                              executed_tflops=round(exe_flop / (tot_ms * 1e-3) / 1e12, 2),
+                              executed_frac_of_fastest_instruction_peak=round(exe_flop / (tot_ms * 1e-3) / 1e12 / peak_all, 4)),
+                ms_per_step_with_events=round(t_events, 2), library_sha256_16=lib_hash(), kernel_sources_sha256_16=src,
+                note='dominant kernel family = most GPU time per step; bound = the roof it is closer to (hbm: algorithmic bytes of its launches '
+                     '/ their HIP-event time against 8 TB/s).  mfma: achieved / frac = FLOPs the matrix cores EXECUTE in that family '
+                     '(Winograd F(2x2,3x3): 16/36, F(4x4,3x3): 36/144 of the dense correlation; 3-term bf16 split: 3 products per fp32 product) '
+                     '/ its HIP-event time / the dense peak of the MFMA instruction it runs on; algorithmic_tflops = 2*MAC of the dense '
+                     'correlation / the same time. Events: an eager repeat of the timed steps on ONE stream with an event pair per conv launch '
+                     '(the timed region has none). families: the same figures for every conv kernel family of the step; all_conv: their sum')
+
+
+class Workload:
+    """One benchmarked configuration: the graph on synthetic weights, its z stream and alpha draws, eager or hipGraph-replayed steps."""
+
+    def __init__(self, cfg, precision, resolution, batch, attrs, world, n_steps, use_graph):
+        from latent2im_amd import conv, selfcheck, synth, dist
+        self.c5 = cfg == 'c5'
+        self.precision, self.resolution, self.batch, self.world = precision, resolution, batch, world
+        self.attrs = attrs or (SCENE_ATTRS if self.c5 else ['Smiling'])
+        self.clamp = self.c5                                 # train_multi_attr.py:113 flow for the multi-attribute configs
+        self.use_graph = use_graph
+        conv.PRECISION = precision
+        np.random.seed(1234)
+        self.g = selfcheck.build_graph(resolution, self.attrs, batch * world, lr=1e-4, transform='scene' if self.c5 else 'face')
+        if world > 1:
+            dist.broadcast_parameters(self.g.walk.parameters())
+        self.global_b = batch * world
+        self.zs_all = synth.z_sample(self.global_b * n_steps, seed=0)
+        self.n_steps = n_steps
+        self.sl = dist.shard(self.global_b)
+        self.captured = {}
+
+    def key(self, reg_only=False):
+        return [self.resolution, self.batch, self.attrs, self.precision, bool(reg_only)]
+
+    def draw_alpha(self, batch=None):                        # Face/SceneTransform.get_train_alpha: one draw per step, shared by the batch
+        lo = -1.0 if self.c5 else 0.0
+        return np.ones((batch or self.batch, len(self.attrs))) * np.random.uniform(lo, 1, len(self.attrs))
+
+    def stepper(self, reg_only=False, graph=None):
+        """i -> one training step on batch i of the z stream (wrapping around), eager or replayed from the hipGraph captured for these flags."""
+        from latent2im_amd import capture, conv, selfcheck
+        conv.PRECISION = self.precision
+        flags = dict(no_content_loss=reg_only, no_gan_loss=reg_only)
+        graph = self.use_graph if graph is None else graph
+        cap = None
+        if graph:
+            if reg_only not in self.captured:
+                self.captured[reg_only] = capture.CapturedStep(self.g, self.batch, len(self.attrs), clamp=self.clamp, **flags)
+            cap = self.captured[reg_only]
+
+        def one_step(i):
+            i %= self.n_steps
+            zs = self.zs_all[i * self.global_b:(i + 1) * self.global_b][self.sl]
+            if cap is not None:
+                return cap(zs, self.draw_alpha())
+            return selfcheck.run_step(self.g, zs, self.draw_alpha(), clamp=self.clamp, **flags)
+        return one_step
+
+    def release(self):
+        import gc
+        self.captured = {}
+        self.g = None
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def describe(self, reg_only, noise, graph):
+        return ('StyleGAN2 FFHQ-shaped %d^2 generator (random-init, noise weights ~ %g: per-layer noise drawn every pass), ResNet-50 regressor, '
+                '%d %s attr (%s flow), %s, batch %d per GPU, linear W+ walk, %s launches'
+                % (self.resolution, noise, len(self.attrs), 'transient-scene' if self.c5 else 'CelebA',
+                   'train_multi_attr.py clamp' if self.clamp else 'train.py', 'reg-only loss' if reg_only else 'full loss (reg+content+GAN)',
+                   self.batch, 'hipGraph-replayed' if graph else 'eager'))
+
+
+def warm_up(one_step, count, seconds):
+    """`count` untimed steps, then more until `seconds` of wall time have passed (clocks, power state, allocator pools, lazily packed
+    weights settle on a time scale, not a step count).  Returns the number of steps run."""
+    t0 = time.perf_counter()
+    n = 0
+    while n < count or (time.perf_counter() - t0) < seconds:
+        one_step(n)
+        n += 1
+        if n >= count:
+            torch.cuda.synchronize()                       # bounded: the time test needs finished steps, not launched ones
+    torch.cuda.synchronize()
+    return n
+
+
+def event_pass(wl, one_step, first, steps):
+    """The same steps again, eager on ONE stream, with a HIP event pair around every conv launch on the launch stream (kept out of the timed
+    region: ~280 pairs per step cost ~7 % wall on their own, and concurrent streams make per-kernel durations overlap)."""
+    from latent2im_amd import constants, conv
+    concurrent, constants.CONCURRENT_LOSS_BRANCHES = constants.CONCURRENT_LOSS_BRANCHES, False
+    conv.PROFILE = []
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(steps):
+        one_step(first + i)
+    torch.cuda.synchronize()
+    t_events = (time.perf_counter() - t1) / steps * 1e3
+    prof, conv.PROFILE = conv.PROFILE, None
+    constants.CONCURRENT_LOSS_BRANCHES = concurrent
+    return prof, t_events
+
+
+def quick_rate(one_step, steps, global_b, dev, max_ahead):
+    """images/s of `steps` steps after one untimed one (the secondary figures of the line: reg-only, config 5's eager twin)."""
+    from latent2im_amd import dist
+    one_step(0)
+    el, ms, _, _ = timed_steps(one_step, 1, steps, max_ahead)
+    el = dist.max_over_ranks(el, dev)
+    return dict(value=round(global_b * steps / el, 3), unit='images/s', ms_per_step=round(el / steps * 1e3, 2), steps=steps, **step_stats(ms))
+
+
+def one_rank_allreduce_us(wgrad):
+    """N = 1 has no process group; the step's only collective is still rehearsed: a ONE-rank RCCL group is built after all timing, the
+    walk-gradient-shaped all-reduce is timed through it, and the group is destroyed.  (value or None, note)."""
+    from latent2im_amd import dist
+    import socket
+    try:
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        os.environ['L2I_FORCE_PG'] = '1'
+        dist.init_from_env()
+        us = dist.time_allreduce(wgrad.detach())
+        backend = torch.distributed.get_backend()
+        dist.shutdown()
+        return us, ('ONE-rank %s (RCCL) group built after the timed regions as a rehearsal of the step\'s only collective: median of 100 synchronised '
+                    'all-reduces of a walk-gradient-shaped tensor (%d bytes); says nothing about xGMI — the N > 1 figure is measured over the real group'
+                    % (backend, wgrad.numel() * 4))
+    except Exception as e:                                   # a box without a working RCCL must not lose the bench line
+        return None, 'one-rank RCCL rehearsal failed: %s: %s' % (type(e).__name__, str(e)[:200])
+    finally:
+        os.environ.pop('L2I_FORCE_PG', None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--warmup_s', type=float, default=3.0, help='keep warming up (beyond --warmup steps) until this many seconds have passed')
+    ap.add_argument('--max_ahead', type=int, default=2, help='host launches at most this many steps ahead of the GPU (0: unbounded)')
     ap.add_argument('--config', default='c3', choices=['c3', 'c5'], help='BASELINE.json configs[2] (headline) or configs[4] per-GPU shape')
     ap.add_argument('--resolution', type=int, default=1024)
     ap.add_argument('--batch', type=int, default=8, help='per-GPU batch')
     ap.add_argument('--attrs', type=str, default=None)
-    ap.add_argument('--reg_only', action='store_true', help='--no_content_loss --no_gan_loss')
+    ap.add_argument('--reg_only', action='store_true', help='--no_content_loss --no_gan_loss as the headline workload')
     ap.add_argument('--cpu_baseline_s', type=float, default=12.0, help='CPU-oracle time budget (0 = skip)')
     ap.add_argument('--no_kernel_events', action='store_true', help='do not bracket conv launches with events')
+    ap.add_argument('--event_steps', type=int, default=5, help='steps of the per-launch event pass (roofline)')
     ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
                     help="f32: exact fp32 MFMA, fp32 storage (c3 default); bf16: the 16-bit path — bf16 h8 storage, one bf16 MFMA per MAC, fp32 accumulation (c5 "
                          "default); bf16x3: fp32 storage, 3-term bf16 split on the matrix cores (fp32-class results)")
     ap.add_argument('--hip_graph', type=int, default=None, help='1: replay forward+backward from one hipGraph (c5 default), 0: eager launches')
-    ap.add_argument('--no_alt_precision', action='store_true', help='skip the extra timing of the other matrix path')
-    ap.add_argument('--direct_3x3', action='store_true', help='run 3x3 stride-1 layers on the direct implicit-GEMM kernel instead of Winograd F(2x2,3x3)')
+    ap.add_argument('--no_config5', action='store_true', help='skip the `config5` block (c5 workload, 16-bit path, hipGraph) of a c3 run')
+    ap.add_argument('--config5_steps', type=int, default=10)
+    ap.add_argument('--no_reg_only', action='store_true', help='skip the `reg_only` figures')
+    ap.add_argument('--direct_3x3', action='store_true', help='run 3x3 stride-1 layers on the direct implicit-GEMM kernel instead of Winograd')
     ap.add_argument('--serial_streams', action='store_true', help='run the three loss branches on one stream (profiling aid: with '
                     'concurrent streams the per-kernel durations rocprof reports include time shared with other kernels)')
     ap.add_argument('--dump_launches', type=str, default=None, help='write the per-launch table of the event pass (shape, family, ms, TFLOP/s) to this JSON file')
@@ -168,95 +441,66 @@ def main():
             raise SystemExit(1)
         print(lines[0], flush=True)
         return
+    t_start = time.perf_counter()
     c5 = a.config == 'c5'
     precision = a.precision or ('bf16' if c5 else 'f32')
     use_graph = bool(a.hip_graph) if a.hip_graph is not None else c5
-    transform = 'scene' if c5 else 'face'
-    attrs = a.attrs.split(',') if a.attrs else (SCENE_ATTRS if c5 else ['Smiling'])
-    clamp = c5                                              # train_multi_attr.py:113 flow for the multi-attribute configs
     if a.serial_streams:
         constants.CONCURRENT_LOSS_BRANCHES = False
     constants.SYNTH_NOISE_STRENGTH = a.noise_strength
-    conv.PRECISION = precision
     conv.USE_WINOGRAD = not a.direct_3x3
     rk, world, local = dist.init_from_env()
     if a.gpus != world:
         raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     assert torch.cuda.is_available(), 'bench.py needs the MI355X'
     dev = torch.device('cuda', torch.cuda.current_device())
-    np.random.seed(1234)
-    g = selfcheck.build_graph(a.resolution, attrs, a.batch * world, lr=1e-4, transform=transform)
-    if world > 1:
-        dist.broadcast_parameters(g.walk.parameters())
-    flags = dict(no_content_loss=a.reg_only, no_gan_loss=a.reg_only)
-    global_b = a.batch * world
-    zs_all = synth.z_sample(global_b * (a.steps + a.warmup), seed=0)
-    sl = dist.shard(global_b)
+    sens_idx = local
+    s0 = gpu_sensors(sens_idx)
+    gpu_sensors.cheap = bool(s0['source'] and s0['source'].startswith('sysfs'))
+    wl = Workload(a.config, precision, a.resolution, a.batch, a.attrs.split(',') if a.attrs else None, world, a.steps + a.warmup, use_graph)
+    global_b = wl.global_b
+    one_step = wl.stepper(reg_only=a.reg_only)
 
-    def draw_alpha():                                       # Face/SceneTransform.get_train_alpha: one draw per step, shared by the batch
-        lo = -1.0 if c5 else 0.0
-        return np.ones((a.batch, len(attrs))) * np.random.uniform(lo, 1, len(attrs))
-
-    captured = None
-
-    def one_step(i):
-        zs = zs_all[i * global_b:(i + 1) * global_b][sl]
-        if captured is not None:
-            return captured(zs, draw_alpha())
-        return selfcheck.run_step(g, zs, draw_alpha(), clamp=clamp, **flags)
-
-    def make_captured():
-        from latent2im_amd import capture
-        return capture.CapturedStep(g, a.batch, len(attrs), clamp=clamp, **flags)
-
-    if use_graph:
-        captured = make_captured()
-    for i in range(a.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        r = one_step(a.warmup + i)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # ---- the headline: W (+ time-based) warm-up steps, then EXACTLY K timed steps
+    warm_run = warm_up(one_step, a.warmup, a.warmup_s)
+    mem0 = torch.cuda.memory_stats()
+    sens_before = gpu_sensors(sens_idx)
+    elapsed, step_ms, r, sens_mid = timed_steps(one_step, a.warmup, a.steps, a.max_ahead, sens_idx)
+    sens_after = gpu_sensors(sens_idx)
+    mem1 = torch.cuda.memory_stats()
     per_rank_ms = [round(t / a.steps * 1e3, 3) for t in dist.gather_floats(elapsed)]
     elapsed = dist.max_over_ranks(elapsed, dev)
     loss_value = float(r['loss'])
-    # multi-GPU evidence that reports itself: which devices the ranks really ran on, and the latency of the step's only collective
     ranks = dist.ranks_seen()
-    wgrad = next(iter(g.walk.parameters()))
+    wgrad = next(iter(wl.g.walk.parameters()))
     allreduce_us = dist.time_allreduce(wgrad.detach())
+    allreduce_note = ('median of 100 synchronised all-reduces of a walk-gradient-shaped tensor (%d bytes) over the %s process group'
+                      % (wgrad.numel() * 4, torch.distributed.get_backend())) if allreduce_us is not None else None
+    alloc = dict(reserved_GB_before=round(mem0['reserved_bytes.all.current'] / 1e9, 2), reserved_GB_after=round(mem1['reserved_bytes.all.current'] / 1e9, 2),
+                 device_mallocs_in_timed_region=int(mem1['segment.all.allocated'] - mem0['segment.all.allocated']),
+                 alloc_retries=int(mem1['num_alloc_retries'] - mem0['num_alloc_retries']))
 
-    # roofline of the conv kernels: the same steps again, eager, with a HIP event pair around every conv launch on the launch
-    # stream.  Kept out of the timed region above because ~280 event pairs per step cost ~7 % wall on their own.
+    # ---- roofline of the conv kernels (every rank repeats the steps: the walk-gradient all-reduce is inside a step; rank 0 reports)
     prof, t_events = None, None
-    if not a.no_kernel_events:            # every rank repeats the steps (the walk-gradient all-reduce is inside a step); rank 0 reports
-        keep_captured, captured = captured, None
-        concurrent, constants.CONCURRENT_LOSS_BRANCHES = constants.CONCURRENT_LOSS_BRANCHES, False   # one stream: durations do not overlap
-        conv.PROFILE = []
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(a.steps):
-            one_step(a.warmup + i)
-        torch.cuda.synchronize()
-        t_events = (time.perf_counter() - t1) / a.steps * 1e3
-        prof, conv.PROFILE = conv.PROFILE, None
-        constants.CONCURRENT_LOSS_BRANCHES = concurrent
-        captured = keep_captured
+    if not a.no_kernel_events:
+        prof, t_events = event_pass(wl, wl.stepper(reg_only=a.reg_only, graph=False), a.warmup, min(a.event_steps, a.steps))
     dist.barrier()
 
-    # batch sweep (the BASELINE metric is quoted over a batch sweep): the same eager step at other per-GPU batches, every rank
+    # ---- reg-only loss (train.py:174-176 --no_content_loss --no_gan_loss) on the same graph
+    reg = None
+    if not a.no_reg_only and not a.reg_only:
+        reg = {precision: dict(quick_rate(wl.stepper(reg_only=True), 5, global_b, dev, a.max_ahead),
+                               workload=wl.describe(True, a.noise_strength, use_graph))}
+
+    # ---- batch sweep (the BASELINE metric is quoted over a batch sweep): the same eager step at other per-GPU batches, every rank
     sweep = None
     if a.sweep and a.sweep not in ('0', 'none', 'off'):
         import gc
-        captured = None
+        wl.captured = {}
         gc.collect()
         torch.cuda.empty_cache()
         sweep = []
+        flags = dict(no_content_loss=a.reg_only, no_gan_loss=a.reg_only)
         for bs in [int(x) for x in a.sweep.split(',') if x]:
             gb = bs * world
             zs_s = synth.z_sample(gb * (a.sweep_steps + 1), seed=1)
@@ -264,59 +508,45 @@ def main():
 
             def sweep_step(i):
                 zs = zs_s[i * gb:(i + 1) * gb][sl_s]
-                lo = -1.0 if c5 else 0.0
-                return selfcheck.run_step(g, zs, np.ones((bs, len(attrs))) * np.random.uniform(lo, 1, len(attrs)), clamp=clamp, **flags)
+                return selfcheck.run_step(wl.g, zs, wl.draw_alpha(bs), clamp=wl.clamp, **flags)
             try:
                 torch.cuda.reset_peak_memory_stats()
                 sweep_step(0)
-                torch.cuda.synchronize()
-                dist.barrier()
-                t3 = time.perf_counter()
-                for i in range(a.sweep_steps):
-                    sweep_step(1 + i)
-                torch.cuda.synchronize()
-                dist.barrier()
-                t_s = dist.max_over_ranks(time.perf_counter() - t3, dev)
+                el, ms, _, _ = timed_steps(sweep_step, 1, a.sweep_steps, a.max_ahead)
+                t_s = dist.max_over_ranks(el, dev)
                 sweep.append(dict(batch=bs, global_batch=gb, images_s=round(gb * a.sweep_steps / t_s, 3), ms_per_step=round(t_s / a.sweep_steps * 1e3, 2),
-                                  peak_mem_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1)))
+                                  min_ms=round(min(ms), 2), peak_mem_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1)))
             except torch.OutOfMemoryError as e:
                 sweep.append(dict(batch=bs, global_batch=gb, images_s=None, error='out of memory: %s' % str(e)[:120]))
             gc.collect()
             torch.cuda.empty_cache()
 
-    # the other matrix path, same steps, for the record (all ranks: the all-reduce is inside the step)
-    alt = None
-    if not a.no_alt_precision:
-        other = {'f32': 'bf16x3', 'bf16x3': 'f32', 'bf16': 'bf16x3'}[precision]
-        conv.PRECISION = other
-        if precision == 'bf16':                             # other network classes (fp32 storage): a second graph, the 16-bit one is released first
-            import gc
-            captured = None
-            g = None
-            gc.collect()
-            torch.cuda.empty_cache()
-            np.random.seed(1234)
-            g = selfcheck.build_graph(a.resolution, attrs, a.batch * world, lr=1e-4, transform=transform)
-            dist.broadcast_parameters(g.walk.parameters())
-        if use_graph:                                       # a graph holds the kernels of the precision it was captured with; its memory
-            import gc                                       # pool (every activation of a step) is released before the next one is built
-            captured = None
-            gc.collect()
-            torch.cuda.empty_cache()
-            captured = make_captured()
-        one_step(0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t2 = time.perf_counter()
-        for i in range(a.steps):
-            one_step(a.warmup + i)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t_alt = dist.max_over_ranks(time.perf_counter() - t2, dev)
+    # ---- config 5 (BASELINE configs[4] per-GPU shape) beside the headline: scene attributes, clamp flow, 16-bit path, hipGraph-replayed
+    cfg5 = None
+    if not c5 and not a.no_config5 and a.resolution == 1024:
+        wkey3, desc3 = wl.key(a.reg_only), wl.describe(a.reg_only, a.noise_strength, use_graph)
+        wl.release()
+        w5 = Workload('c5', 'bf16', a.resolution, a.batch, None, world, a.config5_steps + 2, True)
+        step5 = w5.stepper()
+        warm5 = warm_up(step5, 2, 1.0)
+        el5, ms5, r5, _ = timed_steps(step5, 2, a.config5_steps, a.max_ahead)
+        el5 = dist.max_over_ranks(el5, dev)
+        roof5 = None
+        if not a.no_kernel_events:
+            prof5, t_ev5 = event_pass(w5, w5.stepper(graph=False), 2, min(a.event_steps, a.config5_steps))
+            roof5 = roofline_block(prof5, min(a.event_steps, a.config5_steps), 'c5', w5.key(), t_ev5) if rk == 0 else None
+        cfg5 = dict(value=round(global_b * a.config5_steps / el5, 3), unit='images/s', ms_per_step=round(el5 / a.config5_steps * 1e3, 2),
+                    steps=a.config5_steps, warmup_steps_run=warm5, dtype='bf16', baseline_config='configs[4] per-GPU shape',
+                    workload=w5.describe(False, a.noise_strength, True), loss=float(r5['loss']), roofline=roof5, **step_stats(ms5))
+        if reg is not None:
+            reg['bf16'] = dict(quick_rate(w5.stepper(reg_only=True), 5, global_b, dev, a.max_ahead), workload=w5.describe(True, a.noise_strength, True))
+        w5.release()
         conv.PRECISION = precision
-        alt = dict(precision=other, value=round(global_b * a.steps / t_alt, 3), unit='images/s', ms_per_step=round(t_alt / a.steps * 1e3, 2),
-                   note='same workload and steps with the matrix path switched (see DESIGN.md section 2); not the headline value')
+    else:
+        wkey3, desc3 = wl.key(a.reg_only), wl.describe(a.reg_only, a.noise_strength, use_graph)
 
+    if world == 1 and allreduce_us is None:
+        allreduce_us, allreduce_note = one_rank_allreduce_us(wgrad)
     if rk != 0:
         dist.shutdown()
         return
@@ -329,80 +559,34 @@ def main():
             e = agg.setdefault((q[5],) + tuple(q[3]), [0, 0.0, q[2], call_bytes(q)])
             e[0] += 1
             e[1] += q[0].elapsed_time(q[1])
-        rows = [dict(family=k[0], shape=list(k[1:]), launches_per_step=v[0] / a.steps, ms_per_launch=round(v[1] / v[0], 4), ms_per_step=round(v[1] / a.steps, 3),
+        n_ev = min(a.event_steps, a.steps)
+        rows = [dict(family=k[0], shape=list(k[1:]), launches_per_step=v[0] / n_ev, ms_per_launch=round(v[1] / v[0], 4), ms_per_step=round(v[1] / n_ev, 3),
                      tflops=round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 1), GBs=round(v[3] / (v[1] / v[0] * 1e-3) / 1e9, 1)) for k, v in agg.items()]
         rows.sort(key=lambda r: -r['ms_per_step'])
         json.dump(rows, open(a.dump_launches, 'w'), indent=0)
     if prof:
-        fams = family_table(prof, a.steps)
-        dom = fams[0]                                       # the family with the most GPU time per step
-        tot_ms = sum(q[0].elapsed_time(q[1]) for q in prof)
-        tot_flop = sum(q[2] for q in prof)
-        exe_flop = sum(q[2] * conv.FAMILY_INFO[q[5]][1] for q in prof)
-        peak_all = max(f['peak_tflops'] for f in fams)
-        # HBM bytes of the dominant kernel from the PMC summary that was taken with THIS build of the library (else null)
-        traffic, traffic_note = None, 'no PMC summary under profiles/ for this build of libl2i_hip.so and this workload'
-        tag = 'c5' if c5 else 'c3'
-        tp = os.path.join(ROOT, 'profiles', 'r03_%s_hbm_traffic.json' % tag)
-        if os.path.isfile(tp):
-            tj = json.load(open(tp))
-            ent = tj.get('per_family', {}).get(dom['family'])
-            if tj.get('lib_sha256_16') == lib_hash() and tj.get('workload') == [a.resolution, a.batch, attrs, precision, bool(a.reg_only)] and ent \
-                    and abs(ent['launches_per_step'] - dom['launches_per_step']) < 0.5:
-                traffic = round(ent['bytes_per_launch'])
-                traffic_note = ('HBM bytes per launch of %s from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate) over this command with '
-                                '--serial_streams (profiles/%s, tools/hbm_traffic.py): KiB -> bytes, FETCH_SIZE doubled (gfx950), both factors checked on '
-                                'a kernel of known byte count in the same run; the summary carries the sha256 of the library it was taken with and is '
-                                'dropped when it differs' % (dom['kernel'], os.path.basename(tp)))
-            else:
-                traffic_note = 'profiles/%s was taken with another build / workload (library %s now): dropped' % (os.path.basename(tp), lib_hash())
-        hbm_frac = round(dom['hbm_GBs_algorithmic'] / HBM_PEAK_GBS, 4)
-        if hbm_frac > dom['frac']:                          # the 16-bit kernels: closer to the HBM roof than to the bf16 matrix roof
-            head = dict(bound='hbm', kernel=dom['kernel'], family=dom['family'], achieved=dom['hbm_GBs_algorithmic'], peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=hbm_frac, mfma_bound=dict(peak_TFLOPs=dom['peak_tflops'], achieved_TFLOPs_executed=dom['executed_tflops'], frac=dom['frac']))
-        else:
-            head = dict(bound='mfma', kernel=dom['kernel'], family=dom['family'], achieved=dom['executed_tflops'], peak=dom['peak_tflops'],
-                        unit='TFLOP/s', frac=dom['frac'])
-        roof = dict(head,
-                    traffic=traffic, traffic_unit='bytes per launch', traffic_note=traffic_note,
-                    algorithmic_tflops=dom['algorithmic_tflops'], algorithmic_flop_per_launch=dom['algorithmic_flop_per_launch'],
-                    algorithmic_bytes_per_launch=dom['algorithmic_bytes_per_launch'], avg_launch_ms=dom['avg_launch_ms'],
-                    launches_per_step=dom['launches_per_step'], kernel_ms_per_step=dom['ms_per_step'],
-                    hbm_bound=dict(peak_GBs=HBM_PEAK_GBS, achieved_GBs_algorithmic=dom['hbm_GBs_algorithmic'], frac=hbm_frac),
-                    families=fams,
-                    all_conv=dict(launches_per_step=len(prof) // a.steps, ms_per_step=round(tot_ms / a.steps, 2),
-                                  algorithmic_tflop_per_step=round(tot_flop / a.steps / 1e12, 3),
-                                  algorithmic_tflops=round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
-                                  executed_tflops=round(exe_flop / (tot_ms * 1e-3) / 1e12, 2),
-                                  executed_frac_of_fastest_instruction_peak=round(exe_flop / (tot_ms * 1e-3) / 1e12 / peak_all, 4)),
-                    ms_per_step_with_events=round(t_events, 2), library_sha256_16=lib_hash(),
-                    note='dominant kernel family = most GPU time per step; bound = the roof it is closer to (hbm: algorithmic bytes of its launches '
-                         '/ their HIP-event time against 8 TB/s).  mfma: achieved / frac = FLOPs the matrix cores EXECUTE in that family '
-                         '(Winograd F(2x2,3x3): 16/36 of the dense correlation; 3-term bf16 split: 3 products per fp32 product) / its HIP-event time '
-                         '/ the dense peak of the MFMA instruction it runs on; algorithmic_tflops = 2*MAC of the dense correlation / the same time. '
-                         'Events: an eager repeat of the timed steps on ONE stream with an event pair per conv launch (the timed region has none). '
-                         'families: the same figures for every conv kernel family of the step; all_conv: their sum')
-    wl = ('StyleGAN2 FFHQ-shaped %d^2 generator (random-init, noise weights ~ %g: per-layer noise drawn every pass), ResNet-50 regressor, '
-          '%d %s attr (%s flow), %s, batch %d per GPU, linear W+ walk, %s launches'
-          % (a.resolution, a.noise_strength, len(attrs), 'transient-scene' if c5 else 'CelebA', 'train_multi_attr.py clamp' if clamp else 'train.py',
-             'reg-only loss' if a.reg_only else 'full loss (reg+content+GAN)', a.batch, 'hipGraph-replayed' if use_graph else 'eager'))
+        roof = roofline_block(prof, min(a.event_steps, a.steps), 'c5' if c5 else 'c3', wkey3, t_events)
     out = dict(metric='edited images/sec', value=round(value, 3), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(ms_per_step, 2), higher_is_better=True, scaling='weak', vs_baseline=None, dtype=precision,
                data='synthetic',
-               config=dict(workload=wl, baseline_config='configs[4] per-GPU shape' if c5 else 'configs[2]',
-                           resolution=a.resolution, global_batch=global_b, per_gpu_batch=a.batch, attrs=attrs,
+               config=dict(workload=desc3, baseline_config='configs[4] per-GPU shape' if c5 else 'configs[2]',
+                           resolution=a.resolution, global_batch=global_b, per_gpu_batch=a.batch, attrs=wkey3[2],
                            losses='reg' if a.reg_only else 'reg+content+gan', parallelism='dp%d' % world,
                            loss_branch_streams=3 if constants.CONCURRENT_LOSS_BRANCHES else 1, hip_graph=use_graph,
                            noise_strength=a.noise_strength, loss=loss_value),
-               roofline=roof, alt_precision=alt, batch_sweep=sweep,
+               warmup_steps_run=warm_run, max_steps_ahead=a.max_ahead, **step_stats(step_ms),
+               sensors=dict(at_start=s0, before_timed=sens_before, during_timed=sens_mid, after_timed=sens_after,
+                            note='shader clock (MHz) / socket power (W) of this rank\'s GPU; during_timed only when the sysfs files are readable '
+                                 '(no subprocess between steps); the host is up to max_steps_ahead steps ahead of the GPU when it samples'),
+               allocator=alloc,
+               roofline=roof, config5=cfg5, reg_only=reg, batch_sweep=sweep,
                ranks_seen=ranks, per_rank_ms_per_step=per_rank_ms, allreduce_us=None if allreduce_us is None else round(allreduce_us, 1),
-               allreduce_note=('median of 100 synchronised all-reduces of a walk-gradient-shaped tensor (%d bytes) over the %s process group'
-                               % (wgrad.numel() * 4, torch.distributed.get_backend()) if allreduce_us is not None
-                               else 'no process group at N = 1 (L2I_FORCE_PG=1 builds a one-rank RCCL group as a rehearsal)'))
+               allreduce_note=allreduce_note)
     if world == 1 and a.cpu_baseline_s > 0:
-        out['cpu_baseline'] = cpu_baseline(a.resolution, len(attrs), a.cpu_baseline_s, full_loss=not a.reg_only, clamp=clamp)
+        out['cpu_baseline'] = cpu_baseline(a.resolution, len(wkey3[2]), a.cpu_baseline_s, full_loss=not a.reg_only, clamp=c5)
     else:
         out['cpu_baseline'] = None
+    out['bench_wall_s'] = round(time.perf_counter() - t_start, 1)
     print(json.dumps(out), flush=True)
     dist.shutdown()
 

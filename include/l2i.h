@@ -306,7 +306,11 @@ int l2i_segmented_matvec_f32(float* out, const float* in, const float* in2, cons
                              float* wmod, const float* wrgb, const l2i_segmv_seg* segs, const int32_t* block_seg, int nblocks, int B, void* stream);
 
 const char* l2i_last_error(void);
+/* Bumped whenever a struct of this header grows or an entry point changes meaning (1: round 1-2; 2: round 3, l2i_conv_params gained w_bstride /
+ * out_f32; 3: round 4).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
+#define L2I_ABI_VERSION 3
 int l2i_abi_version(void);
+int l2i_sizeof_conv_params(void);       /* sizeof(struct l2i_conv_params) of THIS build */
 
 #ifdef __cplusplus
 }

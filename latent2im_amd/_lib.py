@@ -101,11 +101,30 @@ _SIGNATURES = {
     'l2i_segmented_matvec_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     'l2i_last_error': (ctypes.c_char_p, []),
     'l2i_abi_version': (c_i, []),
+    'l2i_sizeof_conv_params': (c_i, []),
 }
+
+ABI_VERSION = 3          # L2I_ABI_VERSION of include/l2i.h this binding mirrors
 
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None
+
+
+def source_hash():
+    """sha256[:16] over the kernel SOURCES (csrc/*.hip, *.h, Makefile, include/l2i.h; names + contents, sorted).  The PMC traffic summaries
+    under profiles/ are keyed to this and not to the .so file: a rebuild of the same sources in another directory hashes the binary
+    differently, and the figure must survive the driver's own build()."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, 'csrc')
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.h')) or f == 'Makefile')
+    files.append(os.path.join(os.path.dirname(_HERE), 'include', 'l2i.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 class L2IError(RuntimeError):
@@ -124,6 +143,11 @@ def load():
             fn = getattr(lib, name)           # AttributeError if the export is absent
             fn.restype = res
             fn.argtypes = args
+        # L2I_LIB may point at a foreign build: a library with another struct layout must not be called through this mirror
+        if lib.l2i_abi_version() != ABI_VERSION or lib.l2i_sizeof_conv_params() != ctypes.sizeof(ConvParams):
+            raise L2IError('%s has ABI version %d / sizeof(l2i_conv_params) %d, this binding mirrors version %d / %d bytes: rebuild it '
+                           '(`python __graft_entry__.py build`)' % (LIB_PATH, lib.l2i_abi_version(), lib.l2i_sizeof_conv_params(), ABI_VERSION,
+                                                                    ctypes.sizeof(ConvParams)))
         _lib = lib
     return _lib
 

@@ -435,12 +435,10 @@ static int launch_pipe(const l2i_conv_params& p, hipStream_t st) {
     size_t lds = (size_t)(2 * 2 * G::IN_PLANE + 2 * 2 * WSLOTS) * 16;
     if (lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_bf16x3: tile does not fit the LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
+    L2I_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_pipe_kernel<WM, WN, K, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_pipe_kernel<WM, WN, K, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    });
     const unsigned grid = (unsigned)((total + 7) & ~7L);
     if (p.in_mask) hipLaunchKernelGGL((conv_bf16x3_pipe_kernel<WM, WN, K, S, true>), dim3(grid), dim3(256), lds, st, p, L);
     else hipLaunchKernelGGL((conv_bf16x3_pipe_kernel<WM, WN, K, S, false>), dim3(grid), dim3(256), lds, st, p, L);
@@ -465,12 +463,10 @@ static int launch_pipe_tr(const l2i_conv_params& p, hipStream_t st) {
     L.shift = (TR == 1) ? 3 : 0;
     L.vec_epi = 0;
     size_t lds = (size_t)(2 * 2 * G::IN_PLANE + 2 * 2 * WSLOTS) * 16;
-    static bool attr_done = false;
-    if (!attr_done) {
+    L2I_ONCE_PER_DEVICE({
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_pipe_kernel<WM, WN, 3, 1, false, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_pipe_kernel<WM, WN, 3, 1, true, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    });
     const unsigned grid = (unsigned)((total + 7) & ~7L);
     if (p.in_mask) hipLaunchKernelGGL((conv_bf16x3_pipe_kernel<WM, WN, 3, 1, true, TR>), dim3(grid), dim3(256), lds, st, p, L);
     else hipLaunchKernelGGL((conv_bf16x3_pipe_kernel<WM, WN, 3, 1, false, TR>), dim3(grid), dim3(256), lds, st, p, L);

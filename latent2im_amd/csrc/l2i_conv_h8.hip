@@ -551,11 +551,8 @@ static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
     size_t lds = (size_t)(2 * G::IN_STAGE + 2 * WSLOTS) * 16;
     if (OUT32 && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: tile does not fit the LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN, KS>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const unsigned grid = (unsigned)((total + 7) & ~7L);
     hipLaunchKernelGGL((conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN, KS>), dim3(grid), dim3(256), lds, st, p, L);
     L2I_CHECK_LAUNCH();

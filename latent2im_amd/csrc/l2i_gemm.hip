@@ -265,13 +265,9 @@ int l2i_launch_gemm1x1(const l2i_conv_params& p, hipStream_t st) {
     const dim3 g(grid), t(256);
 #define L2I_GEMM_LAUNCH(WM_, MASK_, NOPS_)                                                                                              \
     do {                                                                                                                                \
-        if (lds > 64 * 1024) {                                                                                                          \
-            static bool done = false;                                                                                                   \
-            if (!done) {                                                                                                                \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel<WM_, MASK_, NOPS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-                done = true;                                                                                                            \
-            }                                                                                                                           \
-        }                                                                                                                               \
+        if (lds > 64 * 1024)                                                                                                            \
+            L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm1x1_kernel<WM_, MASK_, NOPS_>),             \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                     \
         hipLaunchKernelGGL((gemm1x1_kernel<WM_, MASK_, NOPS_>), g, t, lds, st, p, tiles, mblocks, (int)total);                           \
     } while (0)
     if (wide) {

@@ -2,6 +2,8 @@
 #ifndef L2I_INTERNAL_H
 #define L2I_INTERNAL_H
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
 
 int l2i_set_error(int code, const char* msg);   // records msg for l2i_last_error(), returns code
 
@@ -18,6 +20,20 @@ int l2i_launch_splitk_epilogue(const l2i_conv_params& q, hipStream_t st);     //
     do {                                                                        \
         hipError_t e_ = hipGetLastError();                                      \
         if (e_ != hipSuccess) return l2i_set_error(L2I_E_LAUNCH, hipGetErrorString(e_)); \
+    } while (0)
+
+// A function attribute (dynamic LDS limit) is PER DEVICE, and launches may come from several host threads: one bit per device id in an
+// atomic word; the attribute is set before the bit (a racing thread at worst sets it a second time, which is harmless).
+#define L2I_ONCE_PER_DEVICE(stmt)                                                       \
+    do {                                                                                \
+        static std::atomic<uint64_t> done_mask_{0};                                     \
+        int dev_ = 0;                                                                   \
+        (void)hipGetDevice(&dev_);                                                      \
+        const uint64_t bit_ = 1ull << (dev_ & 63);                                      \
+        if (!(done_mask_.load(std::memory_order_acquire) & bit_)) {                     \
+            stmt;                                                                       \
+            done_mask_.fetch_or(bit_, std::memory_order_release);                       \
+        }                                                                               \
     } while (0)
 
 static inline int l2i_grid_for(long long work_items, int per_block, int cap = 256 * 8) {

@@ -18,7 +18,8 @@ int l2i_set_error(int code, const char* msg) {
     return code;
 }
 extern "C" const char* l2i_last_error(void) { return g_err; }
-extern "C" int l2i_abi_version(void) { return 1; }
+extern "C" int l2i_abi_version(void) { return L2I_ABI_VERSION; }
+extern "C" int l2i_sizeof_conv_params(void) { return (int)sizeof(l2i_conv_params); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

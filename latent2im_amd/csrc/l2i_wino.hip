@@ -442,11 +442,8 @@ static int launch_wino(const l2i_conv_params& p, hipStream_t st) {
     // > 64 KiB of dynamic LDS (three raw stages): the limit is raised once per instantiation
 #define L2I_WINO(M_, S_, R_)                                                                                                            \
     do {                                                                                                                                \
-        static bool done = false;                                                                                                       \
-        if (!done) {                                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<M_, S_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-            done = true;                                                                                                                \
-        }                                                                                                                               \
+        L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<M_, S_, R_>),                      \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                         \
         hipLaunchKernelGGL((conv_wino_kernel<M_, S_, R_>), dim3(grid), dim3(256), lds, st, p, L);                                        \
     } while (0)
     if (mask) { if (scale) L2I_WINO(true, true, false); else L2I_WINO(true, false, false); }

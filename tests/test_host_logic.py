@@ -134,7 +134,9 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.l2i_abi_version.restype = ctypes.c_int
-    assert lib.l2i_abi_version() == 1
+    assert lib.l2i_abi_version() == _lib.ABI_VERSION == int(re.search(r'#define L2I_ABI_VERSION (\d+)', hdr).group(1))
+    lib.l2i_sizeof_conv_params.restype = ctypes.c_int
+    assert lib.l2i_sizeof_conv_params() == ctypes.sizeof(_lib.ConvParams)
     # the struct mirror has the same size as the C struct (pointer/int/float layout rules are identical)
     assert ctypes.sizeof(_lib.ConvParams) % 8 == 0
 

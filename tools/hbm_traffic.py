@@ -93,7 +93,9 @@ def main(df, dw, dst, tag='c3', steps=2, cal_elems=8 * 64 * 1024 * 1024):
             per_family[f_]['launches'] += 0 if k.startswith('splitk_epilogue') else a['launches']
             per_family[f_]['bytes'] += fr * a['fetch_raw'] + fw * a['write_raw']
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'latent2im_amd', 'libl2i_hip.so')
-    out = dict(lib_sha256_16=hashlib.sha256(open(lib, 'rb').read()).hexdigest()[:16], workload=WORKLOADS[tag],
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from latent2im_amd import _lib as l2i_lib
+    out = dict(lib_sha256_16=hashlib.sha256(open(lib, 'rb').read()).hexdigest()[:16], src_sha256_16=l2i_lib.source_hash(), workload=WORKLOADS[tag],
                per_family={k: dict(launches_per_step=v['launches'] / steps, bytes_per_launch=v['bytes'] / max(v['launches'], 1),
                                    GB_per_step=round(v['bytes'] / steps / 1e9, 3)) for k, v in per_family.items()},
                source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --serial_streams, %d steps' % steps,
