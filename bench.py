@@ -319,6 +319,7 @@ class Workload:
         import gc
         self.captured = {}
         self.g = None
+        gc.unfreeze()                                        # (warm_up froze this graph's objects: a cycle among them must stay collectable)
         gc.collect()
         torch.cuda.empty_cache()
 
@@ -338,6 +339,9 @@ def warm_up(one_step, count, seconds):
     while n < count or (time.perf_counter() - t0) < seconds:
         one_step(n)
         n += 1
+        if n == 1:
+            from latent2im_amd import capture
+            capture.freeze_host_objects()                  # as trainer.train does after its first step
         if n >= count:
             torch.cuda.synchronize()                       # bounded: the time test needs finished steps, not launched ones
     torch.cuda.synchronize()
@@ -403,6 +407,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--warmup_s', type=float, default=3.0, help='keep warming up (beyond --warmup steps) until this many seconds have passed')
     ap.add_argument('--max_ahead', type=int, default=2, help='host launches at most this many steps ahead of the GPU (0: unbounded)')
+    ap.add_argument('--no_sensors', action='store_true', help='no clock / power reads at all (diagnostic: do the reads themselves disturb the GPU?)')
+    ap.add_argument('--no_gc', action='store_true', help='disable the Python garbage collector during the timed region (diagnostic)')
     ap.add_argument('--config', default='c3', choices=['c3', 'c5'], help='BASELINE.json configs[2] (headline) or configs[4] per-GPU shape')
     ap.add_argument('--resolution', type=int, default=1024)
     ap.add_argument('--batch', type=int, default=8, help='per-GPU batch')
@@ -455,7 +461,8 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs the MI355X'
     dev = torch.device('cuda', torch.cuda.current_device())
     sens_idx = local
-    s0 = gpu_sensors(sens_idx)
+    none = dict(sclk_mhz=None, power_w=None, source='off (--no_sensors)')
+    s0 = none if a.no_sensors else gpu_sensors(sens_idx)
     gpu_sensors.cheap = bool(s0['source'] and s0['source'].startswith('sysfs'))
     wl = Workload(a.config, precision, a.resolution, a.batch, a.attrs.split(',') if a.attrs else None, world, a.steps + a.warmup, use_graph)
     global_b = wl.global_b
@@ -464,9 +471,15 @@ def main():
     # ---- the headline: W (+ time-based) warm-up steps, then EXACTLY K timed steps
     warm_run = warm_up(one_step, a.warmup, a.warmup_s)
     mem0 = torch.cuda.memory_stats()
-    sens_before = gpu_sensors(sens_idx)
-    elapsed, step_ms, r, sens_mid = timed_steps(one_step, a.warmup, a.steps, a.max_ahead, sens_idx)
-    sens_after = gpu_sensors(sens_idx)
+    sens_before = none if a.no_sensors else gpu_sensors(sens_idx)
+    if a.no_gc:
+        import gc
+        gc.collect()
+        gc.disable()
+    elapsed, step_ms, r, sens_mid = timed_steps(one_step, a.warmup, a.steps, a.max_ahead, None if a.no_sensors else sens_idx)
+    if a.no_gc:
+        gc.enable()
+    sens_after = none if a.no_sensors else gpu_sensors(sens_idx)
     mem1 = torch.cuda.memory_stats()
     per_rank_ms = [round(t / a.steps * 1e3, 3) for t in dist.gather_floats(elapsed)]
     elapsed = dist.max_over_ranks(elapsed, dev)

@@ -93,6 +93,10 @@ typedef struct l2i_conv_params {
     int64_t w_bstride;      /* l2i_conv2d_h8 / l2i_conv_transpose2d_h8: bytes between the weight planes of consecutive samples (the generator's */
                             /* modulated convs: style and demodulation folded into one plane set per sample), 0 = one set for every sample    */
     int32_t out_f32;        /* l2i_conv2d_h8: 1 = the output (and residual / res_mask / out_mask / res_sub) is fp32 NCHW instead of bf16 h8      */
+    int32_t slot_f32;       /* l2i_conv2d_h8 / l2i_conv_transpose2d_h8 with bf16 h8 maps (out_f32 = 0), bit mask: 1 = `residual` is an fp32 tensor in */
+                            /* the h8 slot order [B][C/8][H][W][8] (32 bytes per pixel slot), 2 = so is `y` (and the old y of `accumulate`).  The     */
+                            /* residual-trunk gradient of ResNet-50 is carried this way: summed in fp32 through a stage, rounded to bf16 only as the  */
+                            /* operand of the next block's convs (latent2im_amd/nets16.py).  Masks / res_sub stay bf16 h8; sq_ref is refused with 2. */
 } l2i_conv_params;
 #define L2I_SQ_SLOTS 1024
 
@@ -138,6 +142,13 @@ int l2i_conv_transpose2d_bf16x3_f32(const l2i_conv_params* p, void* stream);
  * (latent2im_amd/conv.py:pack_weight_wino).  tile_hint must be 0.
  * Shapes outside the constraints return L2I_E_UNSUPPORTED (callers use l2i_conv2d_f32). */
 int l2i_conv2d_wino_f32(const l2i_conv_params* p, void* stream);
+
+/* The same layers as Winograd F(4x4,3x3): 36 multiplies per 4x4 output tile and (cin, cout) — 1.78x fewer than F(2x2,3x3), 4x fewer than the
+ * direct form; fp32 products and accumulation, error ~1e-6..1e-5 of max|y| against the exact correlation (F(2x2): 3e-7).  Unmasked launches
+ * only: `in_mask` must be NULL or the input itself with ReLU slopes (1, 0) (ReLU-on-load); Cin % 4 == 0.  `w` is the transformed pack
+ * U = G g G^T (6x6 per (cin, cout)) in the kernel's LDS image order [Cin/4][CoutP/16][ [6 i][4 cin][16 cout][4 j=0..3] ++ [6][4][16][2 j=4,5] ]
+ * (latent2im_amd/conv.py:pack_weight_wino4); CoutP = Cout rounded up to 16.  Same epilogue fusions as l2i_conv2d_wino_f32 (incl. sq_ref). */
+int l2i_conv2d_wino4_f32(const l2i_conv_params* p, void* stream);
 
 /* ---- the 16-bit path (BASELINE config 5: "fp16 MFMA"; bf16 here: fp32's exponent range, so gradients of 1e-9 need no loss scaling) ----
  * Tensors in the channel-blocked "h8" layout [B][C/8][H][W][8] bf16 (the 8 channels of a pixel = 16 contiguous bytes = one MFMA fragment);

@@ -35,7 +35,7 @@ class ConvParams(ctypes.Structure):
         ('w_hi', c_p), ('w_lo', c_p),
         ('ws', c_p), ('ksplit', c_i), ('res_sub', c_p), ('res_coef', c_f), ('res_coef_dev', c_p),
         ('sq_ref', c_p), ('sq_out', c_p),
-        ('w_bstride', c_l), ('out_f32', c_i),
+        ('w_bstride', c_l), ('out_f32', c_i), ('slot_f32', c_i),
     ]
 
 
@@ -61,6 +61,7 @@ _SIGNATURES = {
     'l2i_conv2d_bf16x3_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv_transpose2d_bf16x3_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_wino_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
+    'l2i_conv2d_wino4_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv_transpose2d_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_fused_bias_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),

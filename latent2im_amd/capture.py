@@ -20,6 +20,17 @@ import torch
 from . import dist
 
 
+def freeze_host_objects():
+    """Call once after the first training step(s): moves every Python object alive now — the networks' ~270 000 modules, launch plans, packed
+    weight handles — into the collector's permanent generation (``gc.freeze``).  A full collection otherwise walks all of them (measured
+    73 ms) whenever the young generations overflow, about once per 20 steps, on the thread that launches the step's ~650 kernels and is barely
+    ahead of the GPU: one 160-250 ms step among 120 ms ones (the +4 % between a 5-step and a 20-step timing of round 3).  Afterwards a full
+    pass only sees objects created since (0.01 ms).  The step itself leaves no reference cycles behind (tools/probes/gc_cycles.py)."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def forward(g, z, alpha_for_graph, clamp=False, layers=None):
     """train.py:56-101 on DEVICE inputs: both generator passes, the regressor on the original, epsilon and the walk; no host
     synchronisation.  Returns (feed_dict for optimizeParametersAll, dict of device tensors)."""

@@ -18,6 +18,24 @@ import os as _os
 
 PRECISION = _os.environ.get('L2I_PRECISION', 'f32')      # 'bf16x3': eligible stride-1 layers take the split-precision bf16 MFMA kernel (opt-in)
 USE_WINOGRAD = _os.environ.get('L2I_WINOGRAD', '1') != '0'    # 3x3 stride-1 layers on maps >= 32 wide take the F(2x2,3x3) fp32 kernel
+# [r4] Winograd F(4x4,3x3) (csrc/l2i_wino4.hip: 1.78x fewer MFMAs than F(2x2), error ~1e-6..1e-5 of max|y| instead of 3e-7) for the unmasked 3x3
+# stride-1 launches on maps >= 64 wide: 'all' = every eligible launch, 'nograd' = only launches made under `no_grad_pass()` (the first generator
+# / regressor pass of a step builds no graph: no mask of it ever feeds a backward), 'off'.  Which setting ships is decided by the parity suite.
+WINO4 = _os.environ.get('L2I_WINO4', 'all')
+NOGRAD_PASS = False
+
+
+class no_grad_pass:
+    """with conv.no_grad_pass(): launches inside belong to a pass whose activations feed no backward (policy 'nograd' of WINO4)."""
+
+    def __enter__(self):
+        global NOGRAD_PASS
+        self.prev, NOGRAD_PASS = NOGRAD_PASS, True
+
+    def __exit__(self, *a):
+        global NOGRAD_PASS
+        NOGRAD_PASS = self.prev
+
 SPLIT_K = _os.environ.get('L2I_SPLIT_K', '1') != '0'    # 4x4 .. 16x16 maps: cut Cin into ranges computed by separate blocks (l2i.h: ksplit / ws)
 _WS = {}            # split-K workspaces, one per (device, stream)
 USE_FUSED_TRANSPOSED = True     # False: issue stride-2 transposed convs as four per-parity launches
@@ -26,6 +44,7 @@ FAMILIES = ('implicit_gemm_f32', 'gemm1x1_f32', 'cin3_f32', 'direct_small_valu')
 # kernel family -> (kernel name in rocprof, MFMA FLOPs executed per algorithmic FLOP, peak TFLOP/s of the instruction it runs on)
 FAMILY_INFO = {
     'winograd_f32': ('conv_wino_kernel', 16.0 / 36.0, 157.3),
+    'winograd4_f32': ('conv_wino4_kernel', 36.0 / 144.0, 157.3),
     'implicit_gemm_f32': ('conv_mfma_kernel', 1.0, 157.3),
     'gemm1x1_f32': ('gemm1x1_kernel', 1.0, 157.3),
     'transposed_f32': ('convt_mfma_kernel', 1.0, 157.3),
@@ -84,9 +103,30 @@ def pack_weight_wino(w):
     return p.contiguous()
 
 
+_WINO4_G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+                    dtype=np.float64)
+
+
+def pack_weight_wino4(w):
+    """[Cout, Cin, 3, 3] -> Winograd F(4x4,3x3) weights U = G g G^T (6x6, computed in float64, stored fp32) in the LDS image order of
+    csrc/l2i_wino4.hip: [Cin/4][CoutP/16][ [6 i][4 cin][16 cout][4 (j = 0..3)] ++ [6 i][4 cin][16 cout][2 (j = 4, 5)] ], CoutP = Cout rounded
+    up to 16 — a block's slice of a 4-channel chunk is one contiguous 9216-byte image that goes global -> LDS by DMA."""
+    w = torch.as_tensor(w, dtype=torch.float64)
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cin % 4 == 0
+    G = torch.as_tensor(_WINO4_G, device=w.device)
+    coutp = (cout + 15) // 16 * 16
+    U = torch.zeros(coutp, cin, 6, 6, dtype=torch.float64, device=w.device)
+    U[:cout] = torch.einsum('ik,ockl,jl->ocij', G, w, G)
+    U = U.reshape(coutp // 16, 16, cin // 4, 4, 6, 6).permute(2, 0, 4, 3, 1, 5)          # [c4, mb, i, k, m, j]
+    a = U[..., :4].reshape(cin // 4, coutp // 16, -1)
+    b = U[..., 4:].reshape(cin // 4, coutp // 16, -1)
+    return torch.cat([a, b], dim=2).float().contiguous()
+
+
 class Launch:
     """One call of the kernel: a stride-1/2 correlation writing every (oy_step, ox_step)-th output pixel."""
-    __slots__ = ('w', 'cin', 'cout', 'kh', 'kw', 'stride', 'pad_y', 'pad_x', 'step', 'off_y', 'off_x', 'w16', 'w_src', 'wino', 'w4')
+    __slots__ = ('w', 'cin', 'cout', 'kh', 'kw', 'stride', 'pad_y', 'pad_x', 'step', 'off_y', 'off_x', 'w16', 'w_src', 'wino', 'w4', 'wino4')
 
     def __init__(self, w_oihw, stride, pad_y, pad_x, step=1, off_y=0, off_x=0, device=None):
         self.cout, self.cin, self.kh, self.kw = w_oihw.shape
@@ -99,6 +139,7 @@ class Launch:
             self.w4 = torch.zeros(self.cin, self.kh * self.kw, 4, dtype=torch.float32, device=self.w.device)
             self.w4[:, :, :self.cout] = self.w[:, :, :self.cout]
         self.wino = None                                       # Winograd pack, built on first use
+        self.wino4 = None                                      # F(4x4,3x3) pack, built on first use
         self.w_src = torch.as_tensor(w_oihw, dtype=torch.float32) if (self.cin % 8 == 0 and self.kh <= 3 and self.kw <= 3) else None
 
     def bf16x3_planes(self):
@@ -111,6 +152,11 @@ class Launch:
         if self.wino is None and self.w_src is not None and self.kh == 3 and self.kw == 3:
             self.wino = pack_weight_wino(self.w_src).to(self.w.device)
         return self.wino
+
+    def wino4_pack(self):
+        if self.wino4 is None and self.w_src is not None and self.kh == 3 and self.kw == 3:
+            self.wino4 = pack_weight_wino4(self.w_src).to(self.w.device)
+        return self.wino4
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -368,8 +414,14 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
             sq[2][0] = True
     elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
           and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise, res_sub)):
-        p.w = _lib.fptr(L.wino_pack())
-        entry, name = lib.l2i_conv2d_wino_f32, 'l2i_conv2d_wino_f32'
+        relu_in = in_mask is not None and in_mask.data_ptr() == x.data_ptr() and tuple(mask) == (1.0, 0.0)
+        if (WINO4 == 'all' or (WINO4 == 'nograd' and NOGRAD_PASS)) and OW >= 64 and (in_mask is None or relu_in):
+            pk = L.wino4_pack()
+            p.w, p.CoutP = _lib.fptr(pk), pk.shape[1] * 16
+            entry, name = lib.l2i_conv2d_wino4_f32, 'l2i_conv2d_wino4_f32'
+        else:
+            p.w = _lib.fptr(L.wino_pack())
+            entry, name = lib.l2i_conv2d_wino_f32, 'l2i_conv2d_wino_f32'
         if sq is not None and sq[0].data_ptr() % 16 == 0:    # sq = (reference like y, [SQ_SLOTS] zeroed accumulator, [fused flag]): sum (y - ref)^2 in the epilogue
             assert sq[0].shape == y.shape and sq[1].numel() == _lib.SQ_SLOTS
             p.sq_ref, p.sq_out = _lib.fptr(sq[0]), _lib.fptr(sq[1])
@@ -382,7 +434,7 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
         p.sq_ref, p.sq_out = _lib.fptr(sq[0]), _lib.fptr(sq[1])
         sq[2][0] = True
     if PROFILE is not None:
-        family = {'l2i_conv2d_wino_f32': 'winograd_f32', 'l2i_conv2d_bf16x3_f32': 'implicit_gemm_bf16x3'}.get(name)
+        family = {'l2i_conv2d_wino_f32': 'winograd_f32', 'l2i_conv2d_wino4_f32': 'winograd4_f32', 'l2i_conv2d_bf16x3_f32': 'implicit_gemm_bf16x3'}.get(name)
         if family is None:
             family = FAMILIES[lib.l2i_conv2d_family(p)]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -566,7 +618,8 @@ class H8Conv:
         out_f32 = kw.get('out_f32', False)
         if out is None:
             out = (torch.empty(B, self.cin, in_hw[0], in_hw[1], device=gy.device, dtype=torch.float32) if out_f32
-                   else torch.empty(B, (self.cin + 7) // 8, in_hw[0], in_hw[1], 8, device=gy.device, dtype=torch.bfloat16))
+                   else torch.empty(B, (self.cin + 7) // 8, in_hw[0], in_hw[1], 8, device=gy.device,
+                                    dtype=torch.float32 if kw.get('trunk_f32', 0) & 2 else torch.bfloat16))
         pl = planes if planes is not None else self.bwd_planes
         if self.transposed:                                   # dx[ci, i] = sum gy[co, 2i + k - pad] w[co, ci, k]: a stride-2 correlation
             return run_h8(pl, gy, out, self.coutp_in, self.cin, self.k, 2, self.padding, transposed=False, w_bstride=w_bstride, **kw)
@@ -589,8 +642,10 @@ H8Conv.dgrad_compact = _h8_dgrad_compact
 
 def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=0, out_f32=False, out_scale=None, noise=None, noise_w=0.0, bias=None,
            residual=None, res_mask=None, out_mask=None, mask=(1.0, 0.0), act=ACT_NONE, slope=0.2, gain=1.0, out_gain=1.0, accumulate=False, res_sub=None, res_coef=1.0,
-           res_coef_dev=None, sq=None, relu_in=False):
-    """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels."""
+           res_coef_dev=None, sq=None, relu_in=False, trunk_f32=0):
+    """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels.
+    ``trunk_f32`` (l2i_conv_params.slot_f32): bit 1 = ``residual`` is fp32 in the slot order of ``y``, bit 2 = ``y`` itself is (the fp32 residual trunk
+    of a gradient pass: summed without rounding, nets16._ResNet16Fn)."""
     lib = _lib.load()
     B, cg, H, W, _ = x.shape
     assert x.dtype == torch.bfloat16 and cg * 8 == cin and cin % 16 == 0, (x.shape, cin)
@@ -600,7 +655,7 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
         assert y.dtype == torch.float32 and y.shape[1] == cout
         OHf, OWf = y.shape[2], y.shape[3]
     else:
-        assert y.dtype == torch.bfloat16 and y.shape[1] * 8 >= cout and cout % 8 == 0, (y.shape, cout)
+        assert y.dtype == (torch.float32 if trunk_f32 & 2 else torch.bfloat16) and y.shape[1] * 8 >= cout and cout % 8 == 0, (y.shape, cout, y.dtype)
         OHf, OWf = y.shape[2], y.shape[3]
     p = ConvParams()
     p.x, p.w_hi, p.y = _lib.ptr(x), _lib.ptr(planes), _lib.ptr(y)
@@ -615,8 +670,10 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
         p.OH, p.OW = min(OHf, (H + 2 * pad - k) // stride + 1), min(OWf, (W + 2 * pad - k) // stride + 1)
         p.oy_step = p.ox_step = 1
     p.out_scale, p.noise, p.noise_w, p.bias = _lib.fptr(out_scale), _lib.fptr(noise), float(noise_w), _lib.fptr(bias)
-    for t in (residual, res_mask, out_mask, res_sub):
-        assert t is None or (t.shape == y.shape and t.dtype == y.dtype)
+    for t in (res_mask, out_mask, res_sub):
+        assert t is None or (t.shape == y.shape and t.dtype == (torch.float32 if out_f32 else torch.bfloat16))
+    assert residual is None or (residual.shape == y.shape and residual.dtype == (torch.float32 if (out_f32 or trunk_f32 & 1) else torch.bfloat16))
+    p.slot_f32 = int(trunk_f32)
     p.residual, p.res_mask, p.out_mask = _lib.ptr(residual), _lib.ptr(res_mask), _lib.ptr(out_mask)
     p.mask_pos, p.mask_neg = mask                                 # of the OUTPUT mask here: * (out_mask > 0 ? mask[0] : mask[1])
     if relu_in:                                                   # ReLU-on-load (VGG-19 reads pre-ReLU taps): in_mask == x, mask (1, 0)

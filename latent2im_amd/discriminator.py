@@ -90,12 +90,17 @@ class _ConvLReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, conv, bias):
         y = conv.forward(x.detach().contiguous(), bias=bias, act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
-        ctx.conv, ctx.y, ctx.in_hw = conv, y, (x.shape[2], x.shape[3])
+        # y is an OUTPUT of this node: saved through save_for_backward (a plain attribute would be a reference cycle node -> y -> node that keeps
+        # the whole discriminator graph of the step alive until the cyclic collector runs — 55 MB per 1024^2 step, and the collection it
+        # eventually triggers is a 70+ ms host stall)
+        ctx.save_for_backward(y)
+        ctx.conv, ctx.in_hw = conv, (x.shape[2], x.shape[3])
         return y
 
     @staticmethod
     def backward(ctx, g):
-        gx = ctx.conv.dgrad(g.contiguous(), ctx.in_hw, in_mask=ctx.y, mask=LRELU_MASK)
+        y, = ctx.saved_tensors
+        gx = ctx.conv.dgrad(g.contiguous(), ctx.in_hw, in_mask=y, mask=LRELU_MASK)
         return gx, None, None
 
 

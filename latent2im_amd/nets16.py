@@ -14,6 +14,7 @@ differences from the fp32 path, all forced by "no prologue in the conv kernel" (
   * VGG-19 reads pre-ReLU taps: ReLU-on-load inside the conv (four packed integer max per fragment).
 Reference call sites as in the fp32 modules."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -30,6 +31,7 @@ from .specs import RESNET50_LAYERS
 
 SQRT2 = math.sqrt(2.0)
 LRELU_MASK = (SQRT2, 0.2 * SQRT2)
+TRUNK_F32 = os.environ.get('L2I_TRUNK_F32', '1') != '0'        # ResNet-50's residual-trunk gradient in fp32 (_ResNet16Fn.backward); 0: the round-3 bf16 trunk
 
 
 # =====================================================================================================================================
@@ -160,26 +162,39 @@ class _ResNet16Fn(torch.autograd.Function):
             raise RuntimeError('regressor was run without a differentiable input')
         b, g8, h, w, _ = last.shape
         hw = lambda t: (t.shape[2], t.shape[3])
-        g = (g_feat * (1.0 / (h * w))).reshape(b, g8, 1, 1, 8).expand(b, g8, h, w, 8).contiguous().to(torch.bfloat16)
-        G = K16.mask_mul(g, last)                                                        # gradient w.r.t. the pre-ReLU sum of the last block
+        # [r4] The residual-trunk gradient G is carried in FP32 (slot order [B][C/8][H][W][8]) through the identity blocks of a stage:
+        # G <- mask * (c1^T g_y1 + G) is summed in the conv epilogue without rounding (l2i_conv_params.slot_f32), and G is rounded to bf16 only as
+        # the OPERAND of the next block's c3 gradient conv — one rounding of the exact sum per block instead of sixteen successive roundings of the
+        # running value (round 3: the h8 trunk lost the most direction of all four networks, cosine 0.953 at 256^2).  At the three stage
+        # boundaries (projection shortcut: no identity term) the sum is formed in bf16 as before and widened.
+        trunk32 = TRUNK_F32
+        g = (g_feat * (1.0 / (h * w))).reshape(b, g8, 1, 1, 8).expand(b, g8, h, w, 8).contiguous()
+        G = K16.mask_mul(g.to(torch.bfloat16), last)                                   # gradient w.r.t. the pre-ReLU sum of the last block
+        if trunk32:
+            G = G.float()
         n = len(net.blocks)
         for bi in range(n - 1, -1, -1):
             blk, (cur, y1, y2, out) = net.blocks[bi], saved['blocks'][bi]
             m = cur if bi > 0 else None                    # the block input is the previous block's ReLU output (the pooled stem map is not)
-            g_y2 = blk['c3'].conv.dgrad(G, hw(y2), out_mask=y2)
+            Gh = G.to(torch.bfloat16) if trunk32 else G    # the conv operand: ONE rounding of the fp32 sum
+            g_y2 = blk['c3'].conv.dgrad(Gh, hw(y2), out_mask=y2)
             g_y1 = blk['c2'].conv.dgrad(g_y2, hw(y1), out_mask=y1)
             del g_y2
             if blk['down'] is None:
-                Gp = blk['c1'].conv.dgrad(g_y1, hw(cur), residual=G, out_mask=m, res_mask=m)
+                Gp = blk['c1'].conv.dgrad(g_y1, hw(cur), residual=G, out_mask=m, res_mask=m, trunk_f32=3 if trunk32 else 0)
             elif blk['down'].conv.stride == 1:
                 t = blk['c1'].conv.dgrad(g_y1, hw(cur))
-                Gp = blk['down'].conv.dgrad(G, hw(cur), residual=t, out_mask=m, res_mask=m)
+                Gp = blk['down'].conv.dgrad(Gh, hw(cur), residual=t, out_mask=m, res_mask=m, trunk_f32=2 if trunk32 else 0)
                 del t
             else:
                 Gp = blk['c1'].conv.dgrad(g_y1, hw(cur), out_mask=m)
-                K16.add_zero_insert(Gp, blk['down'].conv.dgrad_compact(G), mask=m)       # strided 1x1: compact 1x1 conv + zero insertion
-            del g_y1
+                K16.add_zero_insert(Gp, blk['down'].conv.dgrad_compact(Gh), mask=m)      # strided 1x1: compact 1x1 conv + zero insertion
+                if trunk32:
+                    Gp = Gp.float()
+            del g_y1, Gh
             G = Gp
+        if trunk32:
+            G = G.to(torch.bfloat16)
         a0 = saved['a0']
         g_a0 = K16.cast_from_h8(K16.maxpool2d_bwd(G, saved['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1), a0.shape[1])
         g_img = net.stem.conv.dgrad(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0))

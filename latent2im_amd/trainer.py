@@ -109,6 +109,9 @@ def train(graphs, graph_inputs, output_dir, attrList, layers=None, save_freq=100
             s = slice(batch_start, min(num_samples, batch_start + batch_size))
             zs_batch = hostutil.batch_input(graph_inputs, s)['z'][sl]
             loss, at, out_zs, transformed = train_step(graphs, zs_batch, attrList, layers, trainEmbed, updateGAN, opt, multi_attr)
+            if epoch == 0 and i == 0:
+                from . import capture
+                capture.freeze_host_objects()                 # everything built lazily by the first step is long-lived: out of the collector's way
             if sync_log:
                 curr = loss.detach().cpu().item()                                             # train.py:110
                 loss_values.append(curr)

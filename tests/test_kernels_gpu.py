@@ -37,9 +37,26 @@ CONV_CASES = [  # cin, cout, k, stride, pad, transposed, h, w, batch
 ]
 
 
+@pytest.fixture(params=['off', 'all'])
+def wino4(request):
+    """Both Winograd kernels: F(2x2,3x3) everywhere ('off'), F(4x4,3x3) on the unmasked launches of maps >= 64 wide ('all')."""
+    prev, conv.WINO4 = conv.WINO4, request.param
+    yield request.param
+    conv.WINO4 = prev
+
+
+@pytest.fixture
+def wino4_off():
+    """The generic-kernel tests keep their fp32-exact bounds: 3x3 stride-1 shapes wide enough for F(4x4,3x3) run on the F(2x2) kernel here
+    (test_winograd_3x3_conv covers F(4x4) with its own bound)."""
+    prev, conv.WINO4 = conv.WINO4, 'off'
+    yield
+    conv.WINO4 = prev
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 @pytest.mark.parametrize('hint', [0, 1, 2, 3, 4, 5, 6, 7, 8])
-def test_conv_forward_dgrad_vs_torch(case, hint):
+def test_conv_forward_dgrad_vs_torch(case, hint, wino4_off):
     cin, cout, k, stride, pad, tr, h, w, b = case
     if hint and [4, 2, 1, 2, 1, 1, 4, 2][hint - 1] * 32 > (cout + 31) // 32 * 32 + 96:
         pytest.skip('tile much larger than the layer')
@@ -203,10 +220,14 @@ def test_bf16x3_split_precision_conv(cin, cout, k, stride, pad, h, w, b):
 
 
 @pytest.mark.parametrize('cin,cout,h,w,b', [(64, 64, 64, 64, 2), (32, 32, 40, 96, 1), (128, 96, 32, 64, 2), (16, 40, 36, 36, 1),
-                                            (512, 512, 32, 32, 1), (8, 64, 64, 128, 3), (64, 128, 128, 32, 1)])
-def test_winograd_3x3_conv(cin, cout, h, w, b):
-    """F(2x2,3x3) fp32 kernel vs a float64 reference: every prologue / epilogue fusion, partial tiles, channel counts that
-    do not fill a block, forward and input-gradient; the direct kernel on the same problem for scale."""
+                                            (512, 512, 32, 32, 1), (8, 64, 64, 128, 3), (64, 128, 128, 32, 1), (40, 24, 50, 132, 2)])
+def test_winograd_3x3_conv(cin, cout, h, w, b, wino4):
+    """F(2x2,3x3) / F(4x4,3x3) fp32 kernels vs a float64 reference: every prologue / epilogue fusion, partial tiles, channel counts that
+    do not fill a block, forward and input-gradient; the direct kernel on the same problem for scale.  Bound: 5e-6 of max|y| for F(2x2)
+    (measured 3e-7 .. 1e-6), 3e-5 for F(4x4) (its transforms carry constants up to 8: measured 1e-6 .. 1e-5)."""
+    if wino4 == 'all' and w < 64:
+        pytest.skip('F(4x4,3x3) takes maps >= 64 wide: this shape runs the F(2x2) kernel in both settings')
+    bound = 3e-5 if wino4 == 'all' else 5e-6
     rs = np.random.RandomState(cin + cout + h)
     wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
     x, s, d = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cin) + 0.5), T(rs.rand(b, cout) + 0.5)
@@ -217,6 +238,8 @@ def test_winograd_3x3_conv(cin, cout, h, w, b):
     g = lambda t: t.to(DEV)
     fc = conv.FrozenConv2d(wt, 1, 1, device=DEV)
     assert fc.fwd[0].wino_pack() is not None
+    if cin % 4 == 0:
+        assert fc.fwd[0].wino4_pack() is not None
     D = lambda t: t.double()
     c64 = lambda xx: F.conv2d(xx, D(wt), padding=1)
     ref1 = F.leaky_relu(c64(D(x) * D(s)[:, :, None, None]) * D(d)[:, :, None, None] + D(nz) * 0.3 + D(bias)[None, :, None, None], 0.2) * 2 ** 0.5
@@ -235,16 +258,28 @@ def test_winograd_3x3_conv(cin, cout, h, w, b):
         if got is None:
             continue
         err = float((got.double().cpu() - want).abs().max() / want.abs().max())
-        assert err < 5e-6, err
+        assert err < bound, err
     # the gradient mask IS the input (VGG-19: a conv reads the pre-ReLU tap of the layer below): pro(x) = max(x, 0) without a second tile stream
     xg = g(x)
     y5 = fc.forward(xg, in_mask=xg, mask=(1.0, 0.0), bias=g(bias))
     ref5 = c64(torch.relu(D(x))) + D(bias)[None, :, None, None]
-    assert float((y5.double().cpu() - ref5).abs().max() / ref5.abs().max()) < 5e-6
+    assert float((y5.double().cpu() - ref5).abs().max() / ref5.abs().max()) < bound
     # ContentLoss value fused into the epilogue (VGG taps): sum (y - reference)^2 over the launch, partial tiles and padded channels excluded
     sq_acc, fused = torch.zeros(_lib.SQ_SLOTS, device=DEV), [False]
     y4 = fc.forward(g(x), in_mask=g(msk), mask=(1.0, 0.0), bias=g(bias), sq=(g(res), sq_acc, fused))
     want_sq = float(((y4.double().cpu() - D(res)) ** 2).sum())
+    assert fused[0] and abs(float(sq_acc.double().sum()) - want_sq) <= 1e-5 * want_sq
+    # ... and on an unmasked launch (the F(4x4) kernel's own epilogue when it is on), with the noise / bias / residual operands beside it
+    sq_acc.zero_()
+    fused = [False]
+    y6 = fc.forward(xg, in_mask=xg, mask=(1.0, 0.0), bias=g(bias), noise=g(nz), noise_w=0.3, residual=g(res), sq=(g(rmk), sq_acc, fused))
+    ref6 = ref5 + D(nz) * 0.3 + D(res)
+    assert float((y6.double().cpu() - ref6).abs().max() / ref6.abs().max()) < bound
+    # the ContentLoss gradient term res_coef * res_coef_dev[0] * (residual - res_sub) with a residual mask, on an unmasked launch
+    y7 = fc.forward(xg, in_mask=xg, mask=(1.0, 0.0), residual=g(res), res_sub=g(rmk), res_coef=0.25, res_coef_dev=torch.full((1,), 2.0, device=DEV), res_mask=g(omk))
+    ref7 = c64(torch.relu(D(x))) + torch.where(omk > 0, 0.5 * (D(res) - D(rmk)), torch.zeros_like(D(res)))
+    assert float((y7.double().cpu() - ref7).abs().max() / ref7.abs().max()) < bound
+    want_sq = float(((y6.double().cpu() - D(rmk)) ** 2).sum())
     assert fused[0] and abs(float(sq_acc.double().sum()) - want_sq) <= 1e-5 * want_sq
     # the direct kernel on the same problem, for scale (and as a cross-check of the dispatch switch)
     conv.USE_WINOGRAD = False
@@ -464,7 +499,7 @@ def test_maxpool2x2_backward_fused_with_content_gradient(h, w):
                                                          (64, 64, 1, 32, 32, 2, 'f32'),      # DMA-fed 1x1 GEMM
                                                          (512, 64, 3, 8, 8, 2, 'f32'),       # split-K second pass
                                                          (64, 64, 3, 64, 64, 1, 'bf16x3')])
-def test_conv_epilogue_difference_residual(cin, cout, k, h, w, b, precision):
+def test_conv_epilogue_difference_residual(cin, cout, k, h, w, b, precision, wino4_off):
     """res_sub: the residual term becomes res_coef * res_coef_dev[0] * (residual - res_sub) (the ContentLoss gradient of a VGG
     tap formed inside the gradient conv), in every kernel family's epilogue, with and without the residual mask."""
     rs = np.random.RandomState(cin + cout + h + w)

@@ -237,7 +237,8 @@ def test_full_size_1024_forward_parity_and_consistency(precision):
     # every tile configuration computes the same convolution
     ref = c.forward(a)
     for hint in (1, 2, 3, 4, 8):
-        assert float((c.forward(a, tile_hint=hint) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        # (ref runs on the Winograd kernel the dispatch picks, the forced tiles on the direct kernel: 1e-5 for F(2x2,3x3), 3e-5 for F(4x4,3x3))
+        assert float((c.forward(a, tile_hint=hint) - ref).abs().max()) <= (1e-5 if conv.WINO4 == 'off' else 3e-5) * float(ref.abs().max())
 
 
 @pytest.mark.parametrize('size,batch,attrs,clamp', [(256, 16, ['Smiling'], False),
