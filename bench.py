@@ -102,14 +102,30 @@ def source_hash():
     return _lib.source_hash()
 
 
+def _drm_card_of(index):
+    """/sys/class/drm/cardN/device of HIP device `index`, matched by PCI address (a box can expose dozens of cards: card0 is NOT device 0)."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        want = '%04x:%02x:%02x.' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except (AttributeError, RuntimeError, AssertionError):
+        return None
+    for d in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
+        if os.path.basename(os.path.realpath(d)).startswith(want) and os.path.isfile(os.path.join(d, 'pp_dpm_sclk')):
+            return d
+    return None
+
+
 def gpu_sensors(index=0):
-    """{sclk_mhz, power_w, source}: current shader clock and socket power of the GPU, from amdgpu's sysfs files when readable (microseconds,
-    no subprocess: usable between steps), else one `rocm-smi --showclocks --showpower` call; fields are None when neither answers."""
+    """{sclk_mhz, power_w, source}: current shader clock and socket power of HIP device `index`, from amdgpu's sysfs files of the card with the
+    device's PCI address when readable (microseconds, no subprocess: usable between steps), else one `rocm-smi --showclocks --showpower` call;
+    fields are None when neither answers (never another card's numbers)."""
     import glob
     out = dict(sclk_mhz=None, power_w=None, source=None)
-    cards = sorted(d for d in glob.glob('/sys/class/drm/card[0-9]*/device') if os.path.isfile(os.path.join(d, 'pp_dpm_sclk')))
-    if cards:
-        d = cards[min(index, len(cards) - 1)]
+    d = gpu_sensors.__dict__.setdefault('card', {}).get(index, False)
+    if d is False:
+        d = gpu_sensors.card[index] = _drm_card_of(index)
+    if d:
         try:
             for line in open(os.path.join(d, 'pp_dpm_sclk')):
                 if '*' in line:
@@ -120,7 +136,7 @@ def gpu_sensors(index=0):
                     break
                 if out['power_w'] is not None:
                     break
-            out['source'] = 'sysfs:' + d.split('/')[4]
+            out['source'] = 'sysfs:%s (%s)' % (d.split('/')[4], os.path.basename(os.path.realpath(d)))
         except (OSError, ValueError, IndexError):
             pass
     if out['sclk_mhz'] is None and out['power_w'] is None and not os.environ.get('L2I_NO_ROCM_SMI'):
@@ -471,7 +487,7 @@ def main():
     # ---- the headline: W (+ time-based) warm-up steps, then EXACTLY K timed steps
     warm_run = warm_up(one_step, a.warmup, a.warmup_s)
     mem0 = torch.cuda.memory_stats()
-    sens_before = none if a.no_sensors else gpu_sensors(sens_idx)
+    sens_before = none if a.no_sensors else gpu_sensors(sens_idx)       # (the device idles for the synchronisation in front of it: expect idle clocks)
     if a.no_gc:
         import gc
         gc.collect()

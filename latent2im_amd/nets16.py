@@ -31,7 +31,13 @@ from .specs import RESNET50_LAYERS
 
 SQRT2 = math.sqrt(2.0)
 LRELU_MASK = (SQRT2, 0.2 * SQRT2)
-TRUNK_F32 = os.environ.get('L2I_TRUNK_F32', '1') != '0'        # ResNet-50's residual-trunk gradient in fp32 (_ResNet16Fn.backward); 0: the round-3 bf16 trunk
+# ResNet-50's residual-trunk gradient carried in fp32 through a stage (_ResNet16Fn.backward, l2i_conv_params.slot_f32).  Built on the round-3 review's
+# hypothesis that sixteen successive bf16 roundings of the trunk cost the gradient its direction; MEASURED (tools/bf16_study.py, round 4): no effect —
+# input-gradient cosine against the exact oracle 0.9715 / 0.9526 at 64^2 / 256^2 with the bf16 AND with the fp32 trunk, to four digits.  Rounding a
+# gradient map is unbiased noise of 2^-9 per element (sqrt(50) layers of it: 1.4 %); what moves the gradient is the FORWARD: feature maps stored 2^-9
+# off flip the ReLU masks of units near zero, and the exact oracle with nothing but that storage rounding restated (oracle/nets16.py) lands at the same
+# cosine.  Off by default (it costs 8 bytes per trunk element and block); kept as an option and covered by tests/test_h8_gpu.py.
+TRUNK_F32 = os.environ.get('L2I_TRUNK_F32', '0') != '0'
 
 
 # =====================================================================================================================================
@@ -162,11 +168,10 @@ class _ResNet16Fn(torch.autograd.Function):
             raise RuntimeError('regressor was run without a differentiable input')
         b, g8, h, w, _ = last.shape
         hw = lambda t: (t.shape[2], t.shape[3])
-        # [r4] The residual-trunk gradient G is carried in FP32 (slot order [B][C/8][H][W][8]) through the identity blocks of a stage:
+        # [r4] TRUNK_F32: the residual-trunk gradient G carried in FP32 (slot order [B][C/8][H][W][8]) through the identity blocks of a stage:
         # G <- mask * (c1^T g_y1 + G) is summed in the conv epilogue without rounding (l2i_conv_params.slot_f32), and G is rounded to bf16 only as
-        # the OPERAND of the next block's c3 gradient conv — one rounding of the exact sum per block instead of sixteen successive roundings of the
-        # running value (round 3: the h8 trunk lost the most direction of all four networks, cosine 0.953 at 256^2).  At the three stage
-        # boundaries (projection shortcut: no identity term) the sum is formed in bf16 as before and widened.
+        # the OPERAND of the next block's c3 gradient conv.  At the three stage boundaries (projection shortcut: no identity term) the sum is
+        # formed in bf16 and widened.  Measured to change nothing (see TRUNK_F32 above): off by default.
         trunk32 = TRUNK_F32
         g = (g_feat * (1.0 / (h * w))).reshape(b, g8, 1, 1, 8).expand(b, g8, h, w, 8).contiguous()
         G = K16.mask_mul(g.to(torch.bfloat16), last)                                   # gradient w.r.t. the pre-ReLU sum of the last block

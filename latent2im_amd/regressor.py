@@ -91,13 +91,16 @@ class _ResNetFeatFn(torch.autograd.Function):
         b, c, h, w = ctx.last_shape
         g = (g_feat * (1.0 / (h * w))).reshape(b, c, 1, 1).expand(b, c, h, w).contiguous()
         for blk, (y1, y2, out, in_hw) in zip(reversed(net.blocks), reversed(saved['blocks'])):
-            # out = relu(c3(y2) + idt): the relu mask rides on every consumer of g
-            g_y2 = blk['c3'].conv.dgrad(g, (y2.shape[2], y2.shape[3]), in_mask=out, mask=(1.0, 0.0))
-            g_y1 = blk['c2'].conv.dgrad(g_y2, (y1.shape[2], y1.shape[3]), in_mask=y2, mask=(1.0, 0.0))
+            # out = relu(c3(y2) + idt): the relu mask of `out` rides on every consumer of g.  [r4] The masks of y2 / y1 are applied by the PRODUCING
+            # launch's epilogue (out_mask: a select on values it holds in registers) instead of the consuming launch's prologue (in_mask): the
+            # same numbers, and the 3x3 gradient conv becomes an unmasked launch — the F(4x4,3x3) Winograd kernel (csrc/l2i_wino4.hip) and the
+            # unmasked transposed instantiation take those
+            g_y2 = blk['c3'].conv.dgrad(g, (y2.shape[2], y2.shape[3]), in_mask=out, mask=(1.0, 0.0), out_mask=y2)
+            g_y1 = blk['c2'].conv.dgrad(g_y2, (y1.shape[2], y1.shape[3]), out_mask=y1)
             if blk['down'] is None:
-                g_in = blk['c1'].conv.dgrad(g_y1, in_hw, in_mask=y1, mask=(1.0, 0.0), residual=g, res_mask=out)
+                g_in = blk['c1'].conv.dgrad(g_y1, in_hw, residual=g, res_mask=out)
             else:
-                g_in = blk['c1'].conv.dgrad(g_y1, in_hw, in_mask=y1, mask=(1.0, 0.0))
+                g_in = blk['c1'].conv.dgrad(g_y1, in_hw)
                 blk['down'].conv.dgrad(g, in_hw, out=g_in, in_mask=out, mask=(1.0, 0.0), accumulate=True)
             g = g_in
         a0 = saved['a0']

@@ -159,6 +159,63 @@ def stddev_subgroups(batch, group=4):
     return [list(range(j, batch, n)) for j in range(n)]
 
 
+def _oracle_procs(n_groups, n_px):
+    """Worker PROCESSES for the subgroups of a bounded step: L2I_ORACLE_PROCS, else one per subgroup (at most 4) on a many-core host for
+    >= 512^2 images, else 0 (in-process).  Processes, not threads: torch's large CPU tensors are fresh mmap()s, and the page faults of one
+    address space serialise (python threads over the subgroups measured no gain on the 256-thread GPU box; this is what its suite's wall time is
+    made of: a 1024^2 batch-8 oracle step takes 140 s in one process)."""
+    import os
+    v = os.environ.get('L2I_ORACLE_PROCS')
+    if v is not None:
+        return min(max(0, int(v)), n_groups)
+    if (os.cpu_count() or 1) >= 96 and n_px >= 512 * 512 and n_groups > 1:
+        return min(n_groups, 4)
+    return 0
+
+
+def _bounded_group(args):
+    """One minibatch-stddev subgroup of ``train_step_bounded`` (top-level: it also runs in spawned worker processes)."""
+    nets_state, walk_w, zc, ac, attr_idx, layers, no_content_loss, no_gan_loss, clamp_variant, threads = args
+    if threads:
+        torch.set_num_threads(threads)
+    PG, PR, PV, PD = nets_state['G'], nets_state['R'], nets_state.get('V'), nets_state.get('D')
+    n_latent = walk_w.shape[1]
+    ww = walk_w.detach().clone().requires_grad_(True)
+    with torch.no_grad():
+        ws = get_w(PG, zc, n_latent)
+        x0 = get_logits(PG, ws, None)
+        a0 = get_reg_preds(PR, x0, attr_idx)
+    if clamp_variant:
+        target, eps = get_alphas_clamp(a0, ac)
+    else:
+        target, eps = ac, get_alphas(a0, ac)
+    w1 = walk_linear_multi_w(ws, eps, ww, layers)
+    x1 = get_logits(PG, w1, None)
+    gx = torch.zeros_like(x1)
+    terms, cont_terms = {}, None
+    for name in ('reg', 'cont', 'gan'):
+        if (name == 'cont' and no_content_loss) or (name == 'gan' and no_gan_loss):
+            terms[name] = torch.zeros((), dtype=x1.dtype)
+            continue
+        xl = x1.detach().requires_grad_(True)
+        if name == 'reg':
+            t = reg_loss(PR, xl, target, attr_idx)
+            wgt = 1.0 if (no_content_loss and no_gan_loss) else 10.0
+        elif name == 'cont':
+            t, cts = content_loss(PV, x0, xl)
+            cont_terms = [c.detach() for c in cts]
+            wgt = 0.05
+        else:
+            t = gan_loss(PD, xl)
+            wgt = 0.05
+        g, = torch.autograd.grad(t * wgt, xl)
+        gx += g.to(gx.dtype)
+        terms[name] = t.detach()
+        del t, g, xl
+    grad, = torch.autograd.grad(x1, ww, gx)
+    return dict(x0=x0, x1=x1.detach(), a0=a0, eps=eps.detach(), target=target.detach(), terms=terms, cont_terms=cont_terms, grad=grad.detach())
+
+
 def train_step_bounded(nets_state, walk_w, z, alpha_for_graph, attr_idx, layers=None, no_content_loss=False, no_gan_loss=False,
                        clamp_variant=False):
     """Same function as ``train_step`` evaluated with bounded memory, for the BASELINE-size checks (1024^2, batch 8: the
@@ -166,56 +223,33 @@ def train_step_bounded(nets_state, walk_w, z, alpha_for_graph, attr_idx, layers=
     mean over samples and the subgroups are equal-sized, so the batch value is the mean of the subgroup values), and inside a
     subgroup one loss branch at a time — each branch is back-propagated to the edited image, its graph is freed, and the summed
     image gradient goes through the generator once.  Same arithmetic per sample; only summation order of the final means
-    differs from ``train_step`` (checked against it in tests/test_oracle_golden.py)."""
-    PG, PR, PV, PD = nets_state['G'], nets_state['R'], nets_state.get('V'), nets_state.get('D')
+    differs from ``train_step`` (checked against it in tests/test_oracle_golden.py).
+    On a many-core host the subgroups of a large step run in worker processes (_oracle_procs); the means over subgroups are formed in the
+    serial order, so the result is bit-identical to the in-process evaluation."""
     B = z.shape[0]
-    n_latent = walk_w.shape[1]
     groups = stddev_subgroups(B)
     out = dict(x0=[None] * B, x1=[None] * B, alpha_org=[None] * B, eps=[None] * B, target=[None] * B)
+    n_up = sum(1 for k in nets_state['G'] if k.startswith('to_rgbs.') and k.endswith('.bias') and k.count('.') == 2)
+    n_px = (4 * 2 ** n_up) ** 2                                  # one ToRGB per doubling above 4 x 4 (networks.py:419-452)
+    procs = _oracle_procs(len(groups), n_px)
+    jobs = [(nets_state, walk_w.detach(), z[idx], alpha_for_graph[idx], attr_idx, layers, no_content_loss, no_gan_loss, clamp_variant,
+             torch.get_num_threads() if procs else 0) for idx in groups]
+    if procs:
+        import multiprocessing as mp
+        with mp.get_context('spawn').Pool(procs) as pool:
+            per_group = pool.map(_bounded_group, jobs)
+    else:
+        per_group = [_bounded_group(j) for j in jobs]
     acc = dict(reg=0.0, cont=0.0, gan=0.0, grad=0.0, cont_terms=None)
-    for idx in groups:
-        ww = walk_w.detach().clone().requires_grad_(True)
-        zc, ac = z[idx], alpha_for_graph[idx]
-        with torch.no_grad():
-            ws = get_w(PG, zc, n_latent)
-            x0 = get_logits(PG, ws, None)
-            a0 = get_reg_preds(PR, x0, attr_idx)
-        if clamp_variant:
-            target, eps = get_alphas_clamp(a0, ac)
-        else:
-            target, eps = ac, get_alphas(a0, ac)
-        w1 = walk_linear_multi_w(ws, eps, ww, layers)
-        x1 = get_logits(PG, w1, None)
-        gx = torch.zeros_like(x1)
-        terms = {}
-        for name in ('reg', 'cont', 'gan'):
-            if (name == 'cont' and no_content_loss) or (name == 'gan' and no_gan_loss):
-                terms[name] = torch.zeros((), dtype=x1.dtype)
-                continue
-            xl = x1.detach().requires_grad_(True)
-            if name == 'reg':
-                t = reg_loss(PR, xl, target, attr_idx)
-                wgt = 1.0 if (no_content_loss and no_gan_loss) else 10.0
-            elif name == 'cont':
-                t, cts = content_loss(PV, x0, xl)
-                acc['cont_terms'] = [c.detach() / len(groups) + (a if acc['cont_terms'] else 0.0)
-                                     for c, a in zip(cts, acc['cont_terms'] or [0.0] * len(cts))]
-                wgt = 0.05
-            else:
-                t = gan_loss(PD, xl)
-                wgt = 0.05
-            g, = torch.autograd.grad(t * wgt, xl)
-            gx += g.to(gx.dtype)
-            terms[name] = t.detach()
-            del t, g, xl
-        grad, = torch.autograd.grad(x1, ww, gx)
+    for idx, r in zip(groups, per_group):
         for k, i in enumerate(idx):
-            out['x0'][i], out['x1'][i] = x0[k], x1[k].detach()
-            out['alpha_org'][i], out['eps'][i], out['target'][i] = a0[k], eps[k].detach(), target[k].detach()
+            out['x0'][i], out['x1'][i] = r['x0'][k], r['x1'][k]
+            out['alpha_org'][i], out['eps'][i], out['target'][i] = r['a0'][k], r['eps'][k], r['target'][k]
+        if r['cont_terms'] is not None:
+            acc['cont_terms'] = [c / len(groups) + (a if acc['cont_terms'] else 0.0) for c, a in zip(r['cont_terms'], acc['cont_terms'] or [0.0] * len(r['cont_terms']))]
         for name in ('reg', 'cont', 'gan'):
-            acc[name] = acc[name] + terms[name] / len(groups)
-        acc['grad'] = acc['grad'] + grad.detach() / len(groups)
-        del x1, gx, grad
+            acc[name] = acc[name] + r['terms'][name] / len(groups)
+        acc['grad'] = acc['grad'] + r['grad'] / len(groups)
     res = {k: torch.stack(v) for k, v in out.items()}
     res.update(reg=acc['reg'], cont=acc['cont'], gan=acc['gan'], cont_terms=acc['cont_terms'] or [],
                loss=total_loss(acc['reg'], acc['cont'], acc['gan'], no_content_loss, no_gan_loss), grad=acc['grad'])

@@ -235,13 +235,22 @@ def test_h8_zero_insert_and_modulated_planes():
 
 
 # ---- the networks and the whole step on the 16-bit path against the FLOAT64 oracle ----------------------------------------------------------------
-# Tolerance contract of BASELINE config 5: bf16 storage rounds every feature map to 2^-9 relative, so the fp32 bars of the
-# north star (rtol 1e-3 / atol 1e-4) do not apply to images and gradients; what is held is
-#   images           <= 4e-2 of the largest pixel (measured 0.7 - 1.2e-2), regressor outputs / alpha_org <= 2e-3 absolute,
-#   loss terms       total and regressor terms <= 5e-3 relative (measured 7e-5 - 4e-4), GAN term <= 2e-2 (measured 1e-4 - 8e-3); per-attribute regressor loss <= 1e-3 absolute
-#                    (the north star's "<= 1e-3 per-attr regressor-loss delta": measured 1e-5 - 3e-4),
-#   gradients        cosine similarity with the float64 gradient >= 0.95 (walk), >= 0.99 (generator latent, VGG, discriminator), >= 0.95 (ResNet-50:
-#                    fifty ReLU layers, a flipped mask moves a gradient entry; measured 0.973).
+# Tolerance contract of BASELINE config 5.  bf16 storage rounds every feature map to 2^-9 relative, so the fp32 bars of the
+# north star (rtol 1e-3 / atol 1e-4) do not apply to images and gradients.  Two kinds of bound, kept apart since round 4:
+#   (A) KERNEL CONSISTENCY — against an oracle that restates the path's storage rounding (oracle/nets16.py, ResNet-50: the network whose gradient
+#       is hurt most).  A network with bf16 feature maps is chaotic in its rounding decisions: that oracle against ITSELF with values perturbed by
+#       1e-7 before rounding (an fp32 summation-order difference) agrees only to an output error of 5e-4, a gradient cosine of 0.992 and a relative
+#       L2 of 0.125 (the "floor", measured in the same call).  The kernels are held to 1.35 x that floor — measured AT the floor (0.992 / 0.125 at
+#       64^2, 0.990 / 0.138 at 256^2).  Element-exact checks of every kernel are test_conv_h8_* above (2^-8 relative per element).
+#   (B) PRICE OF THE FORMAT — against the exact float64 oracle (measured by tools/bf16_study.py into profiles/r04_bf16_tolerance.json; bounds =
+#       measured value with a real margin, at 64^2 AND 256^2):
+#         images <= 4e-2 of the largest pixel (measured 0.8 - 1.9e-2); regressor outputs / alpha_org <= 2e-3 absolute (2.4 - 5.9e-4);
+#         total and regressor loss <= 5e-3 relative (1e-5 - 4e-4), GAN term <= 2e-2 (4e-4 - 1.3e-2); per-attribute regressor loss <= 1e-3 absolute
+#         (the north star's "<= 1e-3 per-attr regressor-loss delta": 1.6 - 6.5e-4);
+#         gradient cosines: generator latent >= 0.997 (0.9985), discriminator >= 0.99 (0.995 - 0.997), VGG >= 0.99 (0.995 - 0.996), ResNet-50 >= 0.94
+#         (0.972 at 64^2, 0.953 at 256^2 — and the bf16-storage oracle itself sits at 0.95 - 0.98 against the exact one: fifty ReLU layers whose
+#         masks flip where a rounded feature map crosses zero; the fp32 residual trunk of the round-3 review changes nothing, nets16.TRUNK_F32);
+#         walk gradient of the whole step: cosine >= 0.97, relative L2 <= 0.27 (0.977 - 0.997 / 0.09 - 0.25).
 # The content term is the mean squared DIFFERENCE of two feature maps that are each rounded to bf16: at walk initialisation (|w| ~ 0.02) the true
 # difference is below the rounding step, so its relative error is unbounded by construction and only its absolute size is held.
 def _study():
@@ -253,13 +262,41 @@ def _study():
     return m
 
 
-def test_bf16_networks_vs_float64_oracle():
-    r = _study().networks(64, 2)
+@pytest.mark.parametrize('size', [64, 256])
+def test_bf16_networks_vs_float64_oracle(size):
+    r = _study().networks(size, 2)
     print(r)
-    assert r['G_img_relmax'] < 2.5e-2 and r['G_grad_cos'] > 0.995
-    assert r['R_out_relmax'] < 4e-3 and r['R_grad_cos'] > 0.95
-    assert r['D_out_relmax'] < 1e-2 and r['D_grad_cos'] > 0.99
-    assert max(r['V_loss_rel']) < 1e-3 and r['V_grad_cos'] > 0.99
+    # (A) kernels: ResNet-50 against the oracle with the same storage rounding
+    assert r['R16_out_relmax'] < 2e-3 and r['R16_grad_cos'] > 0.985, {k: v for k, v in r.items() if k.startswith('R16')}
+    assert r['R16_grad_l2'] < 1.35 * r['R16floor_grad_l2'] + 0.01, {k: v for k, v in r.items() if k.startswith('R16')}
+    # (B) the format, against the exact oracle
+    assert r['G_img_relmax'] < 2.5e-2 and r['G_grad_cos'] > 0.997 and r['G_grad_l2'] < 0.08
+    assert r['R_out_relmax'] < 4e-3 and r['R_grad_cos'] > 0.94 and r['R_grad_l2'] < 0.36
+    assert r['R16fmt_grad_cos'] < 0.995                     # the storage rounding alone explains the distance (if this ever fails, tighten R_grad_cos)
+    assert r['D_out_relmax'] < 1e-2 and r['D_grad_cos'] > 0.99 and r['D_grad_l2'] < 0.13
+    assert max(r['V_loss_rel']) < 4e-3 and r['V_grad_cos'] > 0.99 and r['V_grad_l2'] < 0.13      # (content terms: 3e-4 at 64^2, 1.9e-3 at 256^2)
+
+
+def test_bf16_resnet_fp32_trunk_option_matches_the_bf16_trunk():
+    """nets16.TRUNK_F32 (l2i_conv_params.slot_f32: the residual-trunk gradient summed in fp32 through a stage): same network, same input, the input
+    gradient must agree with the default bf16 trunk to rounding (cosine > 0.9995) — the option exists, works, and buys nothing."""
+    from latent2im_amd import nets16, synth
+    R = nets16.ResNet50(synth.resnet50_state(seed=300), device=DEV)
+    rs = np.random.RandomState(5)
+    x = T(rs.randn(2, 3, 128, 128))
+    gy = T(rs.randn(2, 40)).to(DEV)
+    grads = []
+    old = nets16.TRUNK_F32
+    try:
+        for flag in (False, True):
+            nets16.TRUNK_F32 = flag
+            xg = x.to(DEV).requires_grad_(True)
+            R(xg).backward(gy)
+            grads.append(xg.grad.double().cpu().reshape(-1))
+    finally:
+        nets16.TRUNK_F32 = old
+    cos = float(torch.dot(grads[0], grads[1]) / (grads[0].norm() * grads[1].norm()))
+    assert cos > 0.9995 and not torch.equal(grads[0], grads[1]), cos
 
 
 @pytest.mark.parametrize('size,batch', [(64, 4), (256, 2), (1024, 1)])
@@ -276,7 +313,7 @@ def test_bf16_training_step_vs_float64_oracle(size, batch):
     assert r['a0_absmax'] < 2e-3 and r['eps_absmax'] < 2e-3
     assert r["loss_rel"] < 5e-3 and r["reg_rel"] < 5e-3 and r["gan_rel"] < 2e-2          # (the GAN term passes nine bf16 residual blocks at 1024^2: measured 8e-3 there)
     assert max(r['per_attr_reg_loss_delta']) < 1e-3
-    assert r['grad_cos'] > 0.95
+    assert r['grad_cos'] > 0.97 and r['grad_l2'] < 0.27, (r['grad_cos'], r['grad_l2'])
 
 
 def test_bf16_hipgraph_replay_matches_eager_1024_batch8():

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from latent2im_amd import conv, selfcheck, synth
-from oracle import nets as onets, sg2, step as ostep
+from oracle import nets as onets, nets16 as onets16, sg2, step as ostep
 
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 DEV = 'cuda'
@@ -59,6 +59,23 @@ def networks(size, batch):
         yo = fwd(P, xo)
         gxo, = torch.autograd.grad(yo, xo, gyy)
         out.update({name + '_out_relmax': rel(y, yo), name + '_grad_cos': cosine(xg.grad, gxo), name + '_grad_l2': l2rel(xg.grad, gxo)})
+        if name == 'R':
+            # ... and against the float64 oracle WITH the path's bf16 storage rounding restated (oracle/nets16.py): what is left is kernel arithmetic
+            # (order of fp32 sums, bf16 gradient maps); R16fmt_* = that oracle against the exact one = the price of the storage format alone
+            xq = x.clone().requires_grad_(True)
+            yq = onets16.resnet50_forward_bf16(P, xq)
+            gxq, = torch.autograd.grad(yq, xq, gyy)
+            out.update(R16_out_relmax=rel(y, yq), R16_grad_cos=cosine(xg.grad, gxq), R16_grad_l2=l2rel(xg.grad, gxq), R16_grad_relmax=rel(xg.grad, gxq),
+                       R16fmt_out_relmax=rel(yq, yo), R16fmt_grad_cos=cosine(gxq, gxo), R16fmt_grad_l2=l2rel(gxq, gxo))
+            # R16floor_*: the storage-rounding oracle against ITSELF with every value perturbed by 1e-7 relative before it is rounded — the size of an fp32
+            # summation-order difference.  A feature map that lands on the other side of a bf16 rounding boundary moves by 2^-9, fifty layers amplify
+            # it, masks flip: no two fp32-accumulating implementations of this network agree better than this, so the kernels are held to the floor
+            # (x 1.35), not to zero
+            torch.manual_seed(1)
+            xp = x.clone().requires_grad_(True)
+            yp = onets16.resnet50_forward_bf16(P, xp, perturb=1e-7)
+            gxp, = torch.autograd.grad(yp, xp, gyy)
+            out.update(R16floor_out_relmax=rel(yp, yq), R16floor_grad_cos=cosine(gxp, gxq), R16floor_grad_l2=l2rel(gxp, gxq))
     stV = synth.vgg19_prefix_state(seed=400)
     V = nets16.VGG19Prefix(stV, device=DEV)
     other = torch.roll(x, 5, 3)

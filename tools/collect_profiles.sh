@@ -5,14 +5,14 @@
 set -u
 CFG=${1:-c3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r03_$CFG
+OUT=$R/gpurun_out/r04_$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 EXTRA=""
 if [ "$CFG" = "c5" ]; then EXTRA="--config c5 --hip_graph 0"; fi
-COMMON="--serial_streams --cpu_baseline_s 0 --no_alt_precision --sweep none"
-# 1. kernel trace + stats over the full default step counts (2 warm-up + 5 timed + 5 with per-launch events = 12 steps)
+COMMON="--serial_streams --cpu_baseline_s 0 --no_config5 --no_reg_only --sweep none --no_sensors --warmup_s 0 --steps 5 --warmup 2"
+# 1. kernel trace + stats: 2 warm-up + 5 timed + 5 steps with per-launch events = 12 steps in the file
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 bench.py $EXTRA $COMMON > $OUT/bench_serial_streams.json 2> $OUT/bench_serial_streams.err
 # 2. HBM traffic: FETCH_SIZE and WRITE_SIZE do not fit one pass
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_f -o run --output-format csv -- python3 bench.py $EXTRA $COMMON --steps 1 --warmup 1 --no_kernel_events > /dev/null 2>&1
