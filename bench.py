@@ -440,6 +440,7 @@ def main():
     ap.add_argument('--no_config5', action='store_true', help='skip the `config5` block (c5 workload, 16-bit path, hipGraph) of a c3 run')
     ap.add_argument('--config5_steps', type=int, default=10)
     ap.add_argument('--no_reg_only', action='store_true', help='skip the `reg_only` figures')
+    ap.add_argument('--no_allreduce_rehearsal', action='store_true', help='N = 1: do not build the one-rank RCCL group for `allreduce_us` (profiler runs)')
     ap.add_argument('--direct_3x3', action='store_true', help='run 3x3 stride-1 layers on the direct implicit-GEMM kernel instead of Winograd')
     ap.add_argument('--serial_streams', action='store_true', help='run the three loss branches on one stream (profiling aid: with '
                     'concurrent streams the per-kernel durations rocprof reports include time shared with other kernels)')
@@ -574,7 +575,7 @@ def main():
     else:
         wkey3, desc3 = wl.key(a.reg_only), wl.describe(a.reg_only, a.noise_strength, use_graph)
 
-    if world == 1 and allreduce_us is None:
+    if world == 1 and allreduce_us is None and not a.no_allreduce_rehearsal:
         allreduce_us, allreduce_note = one_rank_allreduce_us(wgrad)
     if rk != 0:
         dist.shutdown()

@@ -95,12 +95,19 @@ class _ResNetFeatFn(torch.autograd.Function):
             # launch's epilogue (out_mask: a select on values it holds in registers) instead of the consuming launch's prologue (in_mask): the
             # same numbers, and the 3x3 gradient conv becomes an unmasked launch — the F(4x4,3x3) Winograd kernel (csrc/l2i_wino4.hip) and the
             # unmasked transposed instantiation take those
-            g_y2 = blk['c3'].conv.dgrad(g, (y2.shape[2], y2.shape[3]), in_mask=out, mask=(1.0, 0.0), out_mask=y2)
-            g_y1 = blk['c2'].conv.dgrad(g_y2, (y1.shape[2], y1.shape[3]), out_mask=y1)
-            if blk['down'] is None:
-                g_in = blk['c1'].conv.dgrad(g_y1, in_hw, residual=g, res_mask=out)
+            # (the three stride-2 blocks keep the prologue masks: their c2 gradient is the one-launch transposed kernel, which fuses in_mask only)
+            pre = blk['c2'].conv.stride == 1
+            g_y2 = blk['c3'].conv.dgrad(g, (y2.shape[2], y2.shape[3]), in_mask=out, mask=(1.0, 0.0), **(dict(out_mask=y2) if pre else {}))
+            if pre:
+                g_y1 = blk['c2'].conv.dgrad(g_y2, (y1.shape[2], y1.shape[3]), out_mask=y1)
+                m1 = {}
             else:
-                g_in = blk['c1'].conv.dgrad(g_y1, in_hw)
+                g_y1 = blk['c2'].conv.dgrad(g_y2, (y1.shape[2], y1.shape[3]), in_mask=y2, mask=(1.0, 0.0))
+                m1 = dict(in_mask=y1, mask=(1.0, 0.0))
+            if blk['down'] is None:
+                g_in = blk['c1'].conv.dgrad(g_y1, in_hw, residual=g, res_mask=out, **m1)
+            else:
+                g_in = blk['c1'].conv.dgrad(g_y1, in_hw, **m1)
                 blk['down'].conv.dgrad(g, in_hw, out=g_in, in_mask=out, mask=(1.0, 0.0), accumulate=True)
             g = g_in
         a0 = saved['a0']

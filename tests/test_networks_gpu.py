@@ -332,7 +332,8 @@ def test_config4_whole_step_1024_batch8_five_attrs_vs_oracle():
     """BASELINE config 4 at its per-GPU shape: train_multi_attr.py flow (train_multi_attr.py:71-154: five CelebA attributes, clamped
     targets, transform_base.py:456-490 full loss) at 1024^2, batch 8, against the float32 CPU oracle (bounded-memory evaluation).
     Images, alpha_org, the clamp pair (target, epsilon), every loss term and the per-attribute regressor loss within rtol 1e-3 / atol 1e-4;
-    the walk gradient [5, 18, 512] under the distribution bound of grad_ok and 1e-2 of its largest entry."""
+    the walk gradient [5, 18, 512] under the distribution bound of grad_ok and 1e-2 of its largest entry.  Then the same step at batch 8 on
+    the 16-bit path against the same oracle evaluation, under the bf16 contract."""
     from latent2im_amd import constants
     try:
         size, batch, attrs = 1024, 8, ['Smiling', 'Young', 'Male', 'Eyeglasses', 'Bangs']
@@ -362,6 +363,39 @@ def test_config4_whole_step_1024_batch8_five_attrs_vs_oracle():
         print('config 4 (1024^2, batch 8, 5 attrs, clamp) walk gradient, HIP vs float32 oracle, relative to the largest entry: %.3e' % e)
         grad_ok(r['grad'], o['grad'])
         assert e < 1e-2, e
+        # [r4] The SAME batch-8 step on the 16-bit path against the SAME oracle evaluation (the multi-attribute clamp flow is config 5's; the float32
+        # oracle's own distance from float64 — 3e-3 of the largest gradient entry — is far inside the bf16 contract of tests/test_h8_gpu.py): the
+        # batch-8 bf16 gradient had only ever been compared with itself (replay == eager)
+        import gc
+        from latent2im_amd import conv
+        del gr, r
+        gc.collect()
+        torch.cuda.empty_cache()
+        old = conv.PRECISION
+        try:
+            conv.PRECISION = 'bf16'
+            g16 = selfcheck.build_graph(size, attrs, batch, lr=1e-3)
+            assert type(g16.module.netG).__module__.endswith('nets16')
+            h = selfcheck.run_step(g16, zs, alpha, clamp=True, optimize=False)
+            torch.cuda.synchronize()
+            rel = lambda a, b: float((a.detach().double().cpu() - b.double()).abs().max() / b.double().abs().max())
+            assert rel(h['x0'], o['x0']) < 4e-2 and rel(h['x1'], o['x1']) < 4e-2
+            assert float((h['a0'].double().cpu() - o['alpha_org'].double()).abs().max()) < 2e-3
+            assert float((h['eps'].double().cpu() - o['eps'].double()).abs().max()) < 2e-3
+            assert abs(float(h['loss']) - float(o['loss'])) < 5e-3 * abs(float(o['loss']))
+            assert abs(float(h['terms']['reg']) - float(o['reg'])) < 5e-3 * abs(float(o['reg']))
+            assert abs(float(h['terms']['gan']) - float(o['gan'])) < 2e-2 * abs(float(o['gan']))
+            p16 = g16.regressor(h['x1'])[:, g16.attrIdx].double().cpu()
+            assert float((per_attr(p16) - per_attr(po)).abs().max()) < 1e-3
+            ga, gb = h['grad'].detach().double().cpu().reshape(-1), o['grad'].double().reshape(-1)
+            cos, l2 = float(torch.dot(ga, gb) / (ga.norm() * gb.norm())), float((ga - gb).norm() / gb.norm())
+            print('config 4 shape on the 16-bit path, batch 8: walk-gradient cosine %.4f, relative L2 %.3f vs the float32 oracle' % (cos, l2))
+            assert cos > 0.97 and l2 < 0.27, (cos, l2)
+            del g16, h
+        finally:
+            conv.PRECISION = old
+            gc.collect()
+            torch.cuda.empty_cache()
     finally:
         constants.resolution, constants.BATCH_SIZE = 256, 4
 
@@ -746,9 +780,11 @@ def test_data_parallel_product_graph_matches_single_process(tmp_path, no_gan):
     env = dict(os.environ, L2I_DIST_BACKEND='gloo')
     env.pop('WORLD_SIZE', None)
     single, multi = str(tmp_path / 'single.npz'), str(tmp_path / 'dp2.npz')
-    r = subprocess.run([sys.executable, worker, single] + args, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
+    # (the single-process answer and the two-rank run are independent: started side by side, most of their time is interpreter start-up)
+    p1 = subprocess.Popen([sys.executable, worker, single] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     codes, _ = dist.spawn_local(2, [sys.executable, worker, multi] + args, env=env, timeout=600)
+    _, err1 = p1.communicate(timeout=600)
+    assert p1.returncode == 0, err1[-3000:]
     assert codes == [0, 0], codes
     a, b = np.load(single), np.load(multi)
     assert int(a['world']) == 1 and int(b['world']) == 2
@@ -785,9 +821,11 @@ def test_data_parallel_mlp_walk_broadcast_and_step(tmp_path):
     env = dict(os.environ, L2I_DIST_BACKEND='gloo')
     env.pop('WORLD_SIZE', None)
     single, multi = str(tmp_path / 'single.npz'), str(tmp_path / 'dp2.npz')
-    r = subprocess.run([sys.executable, worker, single] + args, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
+    # (the single-process answer and the two-rank run are independent: started side by side, most of their time is interpreter start-up)
+    p1 = subprocess.Popen([sys.executable, worker, single] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     codes, _ = dist.spawn_local(2, [sys.executable, worker, multi] + args, env=env, timeout=600)
+    _, err1 = p1.communicate(timeout=600)
+    assert p1.returncode == 0, err1[-3000:]
     assert codes == [0, 0], codes
     a, b = np.load(single), np.load(multi)
     assert int(b['world']) == 2 and a['walk'].shape == b['walk'].shape and a['walk'].size > 512 * 1024

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 EXTRA=""
 if [ "$CFG" = "c5" ]; then EXTRA="--config c5 --hip_graph 0"; fi
-COMMON="--serial_streams --cpu_baseline_s 0 --no_config5 --no_reg_only --sweep none --no_sensors --warmup_s 0 --steps 5 --warmup 2"
+COMMON="--serial_streams --cpu_baseline_s 0 --no_config5 --no_reg_only --sweep none --no_sensors --no_allreduce_rehearsal --warmup_s 0 --steps 5 --warmup 2"
 # 1. kernel trace + stats: 2 warm-up + 5 timed + 5 steps with per-launch events = 12 steps in the file
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 bench.py $EXTRA $COMMON > $OUT/bench_serial_streams.json 2> $OUT/bench_serial_streams.err
 # 2. HBM traffic: FETCH_SIZE and WRITE_SIZE do not fit one pass

@@ -1,7 +1,7 @@
 """Summarise two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — they do not fit one pass) of
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <dir_f> -o run --output-format csv -- python3 bench.py --serial_streams \
-        --steps 1 --warmup 1 --cpu_baseline_s 0 --no_alt_precision --no_kernel_events
+        --steps 1 --warmup 1 --cpu_baseline_s 0 --no_config5 --no_reg_only --sweep none --no_kernel_events
     (same with --pmc WRITE_SIZE -d <dir_w>)
 
 into profiles/<name>.json: HBM bytes per kernel family and per conv launch.  Corrections (MI355X_MICROARCH.md, "HBM"):
@@ -21,7 +21,7 @@ import json
 import os
 import sys
 
-CONV = ('conv_wino_kernel', 'conv_mfma_kernel', 'gemm1x1_kernel', 'convt_mfma_kernel', 'conv_direct_small_kernel',
+CONV = ('conv_wino_kernel', 'conv_wino4_kernel', 'conv_mfma_kernel', 'gemm1x1_kernel', 'convt_mfma_kernel', 'conv_direct_small_kernel',
         'conv_bf16x3_pipe_kernel', 'conv_cin3_kernel', 'splitk_epilogue_kernel', 'conv_h8_kernel')
 WORKLOADS = {'c3': [1024, 8, ['Smiling'], 'f32', False],
              'c5': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'bf16', False],
@@ -30,6 +30,8 @@ WORKLOADS = {'c3': [1024, 8, ['Smiling'], 'f32', False],
 
 def family_of(kernel):
     """rocprof kernel name -> the family names of latent2im_amd.conv.FAMILY_INFO."""
+    if kernel.startswith('conv_wino4_kernel'):
+        return 'winograd4_f32'
     if kernel.startswith('conv_wino_kernel'):
         return 'winograd_f32'
     if kernel.startswith('conv_mfma_kernel') or kernel.startswith('splitk_epilogue'):
