@@ -101,6 +101,12 @@ struct Wino4Launch {
 __device__ __forceinline__ f32x2 w4_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 w4_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 w4_mul(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// ReLU-on-load without a packed fp32 max: clamp(x * 2^-60) with the instruction's clamp bit ([0, 1]) is relu(x) * 2^-60 EXACTLY for |x| <= 2^60
+// (a power-of-two scale is exact; values below 2^-66 flush to zero: an absolute error of 1e-20) — one v_pk_mul per pair instead of two v_max_f32.
+// The accumulators then carry y * 2^-60 (products of order 2^-60 .. 2^-75: far above the denormal range) and the epilogue multiplies back.
+#define W4_RELU_SCALE 0x1p-60f
+#define W4_RELU_UNSCALE 0x1p60f
+__device__ __forceinline__ f32x2 w4_relu_scaled(f32x2 a, f32x2 k) { f32x2 r; asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(k)); return r; }
 // a * k + c with the constant pair k in SGPRs
 __device__ __forceinline__ f32x2 w4_fmak(f32x2 a, f32x2 k, f32x2 c) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c)); return r; }
 // horizontal pass (one row; x01, x23, x45 = the row's column pairs):
@@ -228,8 +234,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const l2i_conv_param
     auto colpass = [&](f32x2 (&P)[6], f32x2 sc) {
         if (W4_NOXF) return;
         if constexpr (RELU) {
+            const f32x2 krelu = {W4_RELU_SCALE, W4_RELU_SCALE};
 #pragma unroll
-            for (int r = 0; r < 6; ++r) { asm("v_max_f32 %0, 0, %0" : "+v"(P[r].x)); asm("v_max_f32 %0, 0, %0" : "+v"(P[r].y)); }
+            for (int r = 0; r < 6; ++r) P[r] = w4_relu_scaled(P[r], krelu);
         }
         if constexpr (SCALE) {
 #pragma unroll
@@ -424,6 +431,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const l2i_conv_param
                 const int co = co0 + q;
                 if (!(pok && co < p.Cout)) continue;
                 float4 v = q ? make_float4(y0.y, y1.y, y2.y, y3.y) : make_float4(y0.x, y1.x, y2.x, y3.x);
+                if constexpr (RELU) { v.x *= W4_RELU_UNSCALE; v.y *= W4_RELU_UNSCALE; v.z *= W4_RELU_UNSCALE; v.w *= W4_RELU_UNSCALE; }
                 const size_t oidx = ((size_t)b * p.Cout + co) * plane_o + poff;
                 if (p.out_scale) { v.x *= scv[q]; v.y *= scv[q]; v.z *= scv[q]; v.w *= scv[q]; }
                 if (p.out_mask) {

@@ -104,3 +104,43 @@ def test_winograd_pack_layout_and_transform(cin, cout, h, w, pad):
     Ub = fc.bwd[0].wino_pack()
     if Ub is not None:                                   # needs Cin(of the gradient conv) = cout % 8 == 0
         assert torch.allclose(emu.wino_conv(gy, Ub.double(), cin, 1), gref, rtol=1e-5, atol=1e-5)
+
+
+def test_winograd_f4x4_weight_pack_is_the_kernels_lds_image():
+    """conv.pack_weight_wino4: U = G g G^T per (cout, cin) in the order csrc/l2i_wino4.hip copies it into LDS ([Cin/4][CoutP/16] images of
+    [6 i][4 cin][16 cout][4 j] ++ [6][4][16][2 j]).  Unpacked with that layout and pushed through Y = A^T [U . (B^T d B)] A in float64 it must
+    reproduce the direct 3x3 correlation; padded output channels are zero."""
+    import torch.nn.functional as F
+    from latent2im_amd import conv
+    rs = np.random.RandomState(0)
+    cout, cin = 24, 8
+    w = torch.tensor(rs.randn(cout, cin, 3, 3))
+    pk = conv.pack_weight_wino4(w)
+    assert pk.dtype == torch.float32 and tuple(pk.shape) == (cin // 4, 2, 2304)
+    img = pk.double().numpy()
+    U = np.zeros((32, cin, 6, 6))
+    for c4 in range(cin // 4):
+        for mb in range(2):
+            a = img[c4, mb, :6 * 4 * 16 * 4].reshape(6, 4, 16, 4)
+            b = img[c4, mb, 6 * 4 * 16 * 4:].reshape(6, 4, 16, 2)
+            U[mb * 16:(mb + 1) * 16, c4 * 4:(c4 + 1) * 4, :, :4] = a.transpose(2, 1, 0, 3)
+            U[mb * 16:(mb + 1) * 16, c4 * 4:(c4 + 1) * 4, :, 4:] = b.transpose(2, 1, 0, 3)
+    BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], float)
+    AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], float)
+    x = rs.randn(cin, 6, 6)
+    V = np.einsum('ik,ckl,jl->cij', BT, x, BT)
+    Y = np.einsum('ik,okl,jl->oij', AT, np.einsum('ocij,cij->oij', U, V), AT)
+    ref = F.conv2d(torch.tensor(x)[None], w)[0].numpy()
+    assert np.abs(Y[:cout] - ref).max() < 1e-4 * np.abs(ref).max()          # (the pack is stored in float32)
+    assert np.abs(Y[cout:]).max() == 0.0
+
+
+def test_kernel_source_hash_follows_the_sources_not_the_binary():
+    """bench.py keys roofline.traffic to _lib.source_hash(): stable across calls, sensitive to the kernel sources and the header."""
+    import os
+    from latent2im_amd import _lib
+    h = _lib.source_hash()
+    assert h == _lib.source_hash() and len(h) == 16
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'l2i.h')
+    src = open(hdr).read()
+    assert '#define L2I_ABI_VERSION %d' % _lib.ABI_VERSION in src

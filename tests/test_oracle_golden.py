@@ -220,3 +220,33 @@ def test_bounded_memory_step_is_the_same_function(batch, attrs, clamp, flags):
     for k in ('x0', 'x1', 'alpha_org', 'eps', 'target', 'reg', 'cont', 'gan', 'loss', 'grad'):
         assert a[k].dtype == b[k].dtype, k
         np.testing.assert_allclose(b[k].numpy(), a[k].numpy(), rtol=1e-5, atol=1e-6 * float(a[k].abs().max()), err_msg=k)
+
+
+def test_storage_rounding_oracle_of_the_16bit_resnet():
+    """oracle/nets16.py (the float64 ResNet-50 with the 16-bit path's storage rounding restated): close to the exact network in value
+    (bf16 feature maps: a few 1e-4 of the output), different in gradient (masks flip: the price of the format), and chaotic at the 1e-7
+    level — the floor tests/test_h8_gpu.py holds the kernels to must be a real, non-zero number."""
+    import numpy as np
+    import torch
+    from latent2im_amd import synth
+    from oracle import nets, nets16, step as ostep
+    P = ostep.to_torch(synth.resnet50_state(seed=300), torch.float64)
+    rs = np.random.RandomState(3)
+    x = torch.tensor(rs.randn(1, 3, 64, 64) * 0.5)
+    gy = torch.tensor(rs.randn(1, 40))
+
+    def grad(f):
+        xg = x.clone().requires_grad_(True)
+        y = f(xg)
+        g, = torch.autograd.grad(y, xg, gy)
+        return y.detach(), g
+    y0, g0 = grad(lambda t: nets.resnet50_forward(P, t))
+    y1, g1 = grad(lambda t: nets16.resnet50_forward_bf16(P, t))
+    torch.manual_seed(0)
+    y2, g2 = grad(lambda t: nets16.resnet50_forward_bf16(P, t, perturb=1e-7))
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))
+    assert float((y1 - y0).abs().max() / y0.abs().max()) < 5e-3
+    assert 0.9 < cos(g1, g0) < 0.9995                       # the format moves the gradient ...
+    assert 0.97 < cos(g2, g1) < 0.99999                     # ... and so does an fp32-sized perturbation before the rounding (the chaos floor)
+    assert torch.equal(nets16.q(torch.tensor([1.0, 1.00390625, 3.0e38], dtype=torch.float64)),
+                       torch.tensor([1.0, 1.0, 3.0e38], dtype=torch.float64).float().to(torch.bfloat16).double())
