@@ -447,16 +447,38 @@ extern "C" int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t 
 // NCHW (3-channel images stay fp32: they are the interface to the losses).  Lane = pixel, wmod of the sample through LDS.
 __global__ __launch_bounds__(256) void torgb_fwd_h8_kernel(float* __restrict__ rgb, const u32x4* __restrict__ x, const float* __restrict__ wmod, const float* __restrict__ bias,
                                                            int C, long long HW, int blocks_per_sample) {
-    extern __shared__ float wl[];                          // [3][C]
+    extern __shared__ __attribute__((aligned(16))) float wl[];                          // [3][C]
     const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x - b * blocks_per_sample;
     for (int i = threadIdx.x; i < 3 * C; i += 256) wl[i] = wmod[(size_t)b * 3 * C + i];
     __syncthreads();
     const int G8 = C / 8;
+    // [r4] up to four pixel slots (32 channels) in flight per lane, the weights of a group as 16-byte LDS reads (the first version issued one
+    // 16-byte load and 24 ds_read_b32 per group: 3.2 TB/s); groups in the order 0 .. G8-1 as before (same sums)
+    const float4* wl4 = reinterpret_cast<const float4*>(wl);
+    const int C4 = C / 4;
     for (long long pix = (long long)blk * 256 + threadIdx.x; pix < HW; pix += (long long)blocks_per_sample * 256) {
         float a0 = bias[0], a1 = bias[1], a2 = bias[2];
-        for (int g = 0; g < G8; ++g) {
+        const u32x4* xp = x + (size_t)b * G8 * HW + pix;
+        int g = 0;
+        for (; g + 4 <= G8; g += 4) {
+            u32x4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = xp[(size_t)(g + u) * HW];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[8];
+                unpack8(q[u], v);
+                const float4 w0a = wl4[2 * (g + u)], w0b = wl4[2 * (g + u) + 1], w1a = wl4[C4 + 2 * (g + u)], w1b = wl4[C4 + 2 * (g + u) + 1];
+                const float4 w2a = wl4[2 * C4 + 2 * (g + u)], w2b = wl4[2 * C4 + 2 * (g + u) + 1];
+                const float w0[8] = {w0a.x, w0a.y, w0a.z, w0a.w, w0b.x, w0b.y, w0b.z, w0b.w}, w1[8] = {w1a.x, w1a.y, w1a.z, w1a.w, w1b.x, w1b.y, w1b.z, w1b.w};
+                const float w2[8] = {w2a.x, w2a.y, w2a.z, w2a.w, w2b.x, w2b.y, w2b.z, w2b.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a0 += v[e] * w0[e]; a1 += v[e] * w1[e]; a2 += v[e] * w2[e]; }
+            }
+        }
+        for (; g < G8; ++g) {
             float v[8];
-            unpack8(x[((size_t)b * G8 + g) * HW + pix], v);
+            unpack8(xp[(size_t)g * HW], v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a0 += v[e] * wl[8 * g + e]; a1 += v[e] * wl[C + 8 * g + e]; a2 += v[e] * wl[2 * C + 8 * g + e]; }
         }
