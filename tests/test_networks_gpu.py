@@ -780,11 +780,10 @@ def test_data_parallel_product_graph_matches_single_process(tmp_path, no_gan):
     env = dict(os.environ, L2I_DIST_BACKEND='gloo')
     env.pop('WORLD_SIZE', None)
     single, multi = str(tmp_path / 'single.npz'), str(tmp_path / 'dp2.npz')
-    # (the single-process answer and the two-rank run are independent: started side by side, most of their time is interpreter start-up)
-    p1 = subprocess.Popen([sys.executable, worker, single] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # (one after the other: three processes time-slicing the box's one GPU at once were measured 2x SLOWER than the two runs in sequence)
+    r = subprocess.run([sys.executable, worker, single] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
     codes, _ = dist.spawn_local(2, [sys.executable, worker, multi] + args, env=env, timeout=600)
-    _, err1 = p1.communicate(timeout=600)
-    assert p1.returncode == 0, err1[-3000:]
     assert codes == [0, 0], codes
     a, b = np.load(single), np.load(multi)
     assert int(a['world']) == 1 and int(b['world']) == 2
@@ -821,11 +820,10 @@ def test_data_parallel_mlp_walk_broadcast_and_step(tmp_path):
     env = dict(os.environ, L2I_DIST_BACKEND='gloo')
     env.pop('WORLD_SIZE', None)
     single, multi = str(tmp_path / 'single.npz'), str(tmp_path / 'dp2.npz')
-    # (the single-process answer and the two-rank run are independent: started side by side, most of their time is interpreter start-up)
-    p1 = subprocess.Popen([sys.executable, worker, single] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # (one after the other: three processes time-slicing the box's one GPU at once were measured 2x SLOWER than the two runs in sequence)
+    r = subprocess.run([sys.executable, worker, single] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
     codes, _ = dist.spawn_local(2, [sys.executable, worker, multi] + args, env=env, timeout=600)
-    _, err1 = p1.communicate(timeout=600)
-    assert p1.returncode == 0, err1[-3000:]
     assert codes == [0, 0], codes
     a, b = np.load(single), np.load(multi)
     assert int(b['world']) == 2 and a['walk'].shape == b['walk'].shape and a['walk'].size > 512 * 1024
