@@ -59,9 +59,11 @@ def cpu_baseline(resolution, n_attr, budget_s, full_loss=True, clamp=False):
     (2) >= 3 whole training steps at the REFERENCE's own shape, 256^2 batch 4 (README / constants.py:1 of the reference) — `reference_shape`."""
     from latent2im_amd import synth
     from oracle import step as ostep
-    # torch's CPU convs stop scaling (and collapse when oversubscribed: 256 threads on the 256-core box = 334 s per step,
-    # 32 threads = 18 s), so the port is timed on at most 32 cores and `cores` reports what was actually used
-    threads = min(os.cpu_count() or 1, 32)
+    # `cores` = what the port really ran on: the CPUs the host gives this process (cgroup quota / affinity: the GPU box shows 256 hardware threads
+    # to a pod with a quota of 16 CPUs; more runnable threads than that are only throttled — 16 threads 5.3 s, 32 threads 7.1 s, 256 threads 334 s
+    # for the same step), at most 32
+    import oracle
+    threads = min(oracle.host_cpus(), 32)
     torch.set_num_threads(threads)
 
     def timed(res, batch, min_steps, max_steps, budget):
@@ -82,7 +84,7 @@ def cpu_baseline(resolution, n_attr, budget_s, full_loss=True, clamp=False):
         return done, t_total
 
     done, t_total = timed(resolution, 1, 1, 4, budget_s)
-    out = dict(value=done / t_total, unit='images/s', cores=threads, kind='port', cpu=cpu_model(), host_threads=os.cpu_count(),
+    out = dict(value=done / t_total, unit='images/s', cores=threads, kind='port', cpu=cpu_model(), host_threads=os.cpu_count(), usable_cpus=oracle.host_cpus(),
                sample='%d full training step(s) of batch 1 at %d^2 (same losses), %.1f s of CPU work, torch %s CPU ops'
                       % (done, resolution, t_total, torch.__version__))
     d2, t2 = timed(256, 4, 3, 6, budget_s)

@@ -51,7 +51,8 @@ def smoke():
     from oracle import step as ostep                     # checker only
     assert torch.cuda.is_available(), 'smoke() needs the MI355X'
     import os
-    torch.set_num_threads(min(32, os.cpu_count() or 1))          # the CPU checker: torch's CPU convs collapse at hundreds of threads
+    import oracle
+    torch.set_num_threads(min(32, oracle.host_cpus()))           # the CPU checker: as many threads as the host's quota really gives (oracle.host_cpus)
     torch.cuda.set_device(0)
     g = build_graph(64, ['Smiling'], 4)
     zs = synth.z_sample(4, seed=0)

@@ -24,3 +24,31 @@ Pinning status
   architecture on top of torch's own conv / batch-norm
   primitives, and the product is checked against this restatement.
 """
+
+
+def host_cpus():
+    """CPUs this process may actually use: the smaller of the visible CPUs, the scheduler affinity and the cgroup CPU quota (``cpu.max``: the GPU
+    box shows 256 hardware threads to a pod whose quota is 16 CPUs — more runnable threads than that only get throttled, which is why torch's
+    CPU convolutions "collapse" there at high thread counts and why neither threads nor worker processes speed the oracle up)."""
+    import math
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, math.ceil(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, math.ceil(q / per)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n

@@ -161,14 +161,15 @@ def stddev_subgroups(batch, group=4):
 
 def _oracle_procs(n_groups, n_px):
     """Worker PROCESSES for the subgroups of a bounded step: L2I_ORACLE_PROCS, else one per subgroup (at most 4) on a many-core host for
-    large steps, else 0 (in-process).  Processes, not threads: torch's large CPU tensors are fresh mmap()s, and the page faults of one
-    address space serialise (python threads over the subgroups measured no gain on the 256-thread GPU box; this is what its suite's wall time is
-    made of: a 1024^2 batch-8 oracle step takes 140 s in one process)."""
+    large steps, else 0 (in-process).  "Many-core" counts the CPUs the process may really use (oracle.host_cpus): the GPU box of this project
+    shows 256 hardware threads but gives a pod 16 CPUs of quota, so neither threads nor processes help there (measured: two subgroups in two
+    processes 142 -> 121 s) and the pool stays off."""
     import os
     v = os.environ.get('L2I_ORACLE_PROCS')
     if v is not None:
         return min(max(0, int(v)), n_groups)
-    if (os.cpu_count() or 1) >= 96 and n_px * n_groups >= 512 * 512 and n_groups > 1:          # (1024^2 from batch 8, 256^2 from batch 16)
+    from . import host_cpus
+    if host_cpus() >= 96 and n_px * n_groups >= 512 * 512 and n_groups > 1:          # (1024^2 from batch 8, 256^2 from batch 16)
         return min(n_groups, 4)
     return 0
 

@@ -11,9 +11,11 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
 def pytest_configure(config):
-    # the CPU oracle: torch's CPU convolutions collapse beyond a few dozen threads (256 hardware threads on the GPU box: 5x slower)
+    # the CPU oracle: as many torch threads as the host really gives this process (the GPU box shows 256 hardware threads to a pod with a cgroup
+    # quota of 16 CPUs: 16 threads 5.3 s, 32 threads 7.1 s, 64 threads 10 s for the same oracle step, tools/probes/oracle_threads.py)
     import torch
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    import oracle
+    torch.set_num_threads(min(32, oracle.host_cpus()))
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'slow: takes more than a few seconds on CPU')
 

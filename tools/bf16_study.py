@@ -11,7 +11,8 @@ from oracle import nets as onets, nets16 as onets16, sg2, step as ostep
 
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 DEV = 'cuda'
-torch.set_num_threads(min(32, os.cpu_count() or 1))
+import oracle
+torch.set_num_threads(min(32, oracle.host_cpus()))
 
 
 def rel(a, b):
