@@ -349,20 +349,29 @@ class Workload:
                    self.batch, 'hipGraph-replayed' if graph else 'eager'))
 
 
-def warm_up(one_step, count, seconds):
-    """`count` untimed steps, then more until `seconds` of wall time have passed (clocks, power state, allocator pools, lazily packed
-    weights settle on a time scale, not a step count).  Returns the number of steps run."""
+def warm_up(one_step, count, seconds, dev=None):
+    """`count` untimed steps, then more until about `seconds` of wall time have passed (clocks, power state, allocator pools, lazily packed
+    weights settle on a time scale, not a step count).  Every rank runs the SAME number of steps (a step holds the walk-gradient all-reduce: a
+    per-rank time test would leave ranks in different collectives): the extra steps are computed once from the slowest rank's time for the
+    counted ones.  Returns the number of steps run."""
+    import math
+    from latent2im_amd import capture, dist
     t0 = time.perf_counter()
     n = 0
-    while n < count or (time.perf_counter() - t0) < seconds:
+    for _ in range(max(count, 1)):
         one_step(n)
         n += 1
         if n == 1:
-            from latent2im_amd import capture
             capture.freeze_host_objects()                  # as trainer.train does after its first step
-        if n >= count:
-            torch.cuda.synchronize()                       # bounded: the time test needs finished steps, not launched ones
     torch.cuda.synchronize()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
+    if elapsed < seconds:
+        per_step = max(elapsed / n if n > 1 else elapsed, 1e-3)    # (the very first step carries the lazy weight packing)
+        extra = min(int(math.ceil((seconds - elapsed) / per_step)), 200)
+        for _ in range(extra):
+            one_step(n)
+            n += 1
+        torch.cuda.synchronize()
     return n
 
 
@@ -488,7 +497,7 @@ def main():
     one_step = wl.stepper(reg_only=a.reg_only)
 
     # ---- the headline: W (+ time-based) warm-up steps, then EXACTLY K timed steps
-    warm_run = warm_up(one_step, a.warmup, a.warmup_s)
+    warm_run = warm_up(one_step, a.warmup, a.warmup_s, dev)
     mem0 = torch.cuda.memory_stats()
     sens_before = none if a.no_sensors else gpu_sensors(sens_idx)       # (the device idles for the synchronisation in front of it: expect idle clocks)
     if a.no_gc:
@@ -560,7 +569,7 @@ def main():
         wl.release()
         w5 = Workload('c5', 'bf16', a.resolution, a.batch, None, world, a.config5_steps + 2, True)
         step5 = w5.stepper()
-        warm5 = warm_up(step5, 2, 1.0)
+        warm5 = warm_up(step5, 2, 1.0, dev)
         el5, ms5, r5, _ = timed_steps(step5, 2, a.config5_steps, a.max_ahead)
         el5 = dist.max_over_ranks(el5, dev)
         roof5 = None

@@ -159,26 +159,9 @@ def stddev_subgroups(batch, group=4):
     return [list(range(j, batch, n)) for j in range(n)]
 
 
-def _oracle_procs(n_groups, n_px):
-    """Worker PROCESSES for the subgroups of a bounded step: L2I_ORACLE_PROCS, else one per subgroup (at most 4) on a many-core host for
-    large steps, else 0 (in-process).  "Many-core" counts the CPUs the process may really use (oracle.host_cpus): the GPU box of this project
-    shows 256 hardware threads but gives a pod 16 CPUs of quota, so neither threads nor processes help there (measured: two subgroups in two
-    processes 142 -> 121 s) and the pool stays off."""
-    import os
-    v = os.environ.get('L2I_ORACLE_PROCS')
-    if v is not None:
-        return min(max(0, int(v)), n_groups)
-    from . import host_cpus
-    if host_cpus() >= 96 and n_px * n_groups >= 512 * 512 and n_groups > 1:          # (1024^2 from batch 8, 256^2 from batch 16)
-        return min(n_groups, 4)
-    return 0
-
-
 def _bounded_group(args):
-    """One minibatch-stddev subgroup of ``train_step_bounded`` (top-level: it also runs in spawned worker processes)."""
-    nets_state, walk_w, zc, ac, attr_idx, layers, no_content_loss, no_gan_loss, clamp_variant, threads = args
-    if threads:
-        torch.set_num_threads(threads)
+    """One minibatch-stddev subgroup of ``train_step_bounded``."""
+    nets_state, walk_w, zc, ac, attr_idx, layers, no_content_loss, no_gan_loss, clamp_variant = args
     PG, PR, PV, PD = nets_state['G'], nets_state['R'], nets_state.get('V'), nets_state.get('D')
     n_latent = walk_w.shape[1]
     ww = walk_w.detach().clone().requires_grad_(True)
@@ -225,22 +208,12 @@ def train_step_bounded(nets_state, walk_w, z, alpha_for_graph, attr_idx, layers=
     subgroup one loss branch at a time — each branch is back-propagated to the edited image, its graph is freed, and the summed
     image gradient goes through the generator once.  Same arithmetic per sample; only summation order of the final means
     differs from ``train_step`` (checked against it in tests/test_oracle_golden.py).
-    On a many-core host the subgroups of a large step run in worker processes (_oracle_procs); the means over subgroups are formed in the
-    serial order, so the result is bit-identical to the in-process evaluation."""
+    (Round 4 tried python threads and worker processes over the subgroups: the GPU box gives a pod 16 CPUs of quota, nothing scales there.)"""
     B = z.shape[0]
     groups = stddev_subgroups(B)
     out = dict(x0=[None] * B, x1=[None] * B, alpha_org=[None] * B, eps=[None] * B, target=[None] * B)
-    n_up = sum(1 for k in nets_state['G'] if k.startswith('to_rgbs.') and k.endswith('.bias') and k.count('.') == 2)
-    n_px = (4 * 2 ** n_up) ** 2                                  # one ToRGB per doubling above 4 x 4 (networks.py:419-452)
-    procs = _oracle_procs(len(groups), n_px)
-    jobs = [(nets_state, walk_w.detach(), z[idx], alpha_for_graph[idx], attr_idx, layers, no_content_loss, no_gan_loss, clamp_variant,
-             torch.get_num_threads() if procs else 0) for idx in groups]
-    if procs:
-        import multiprocessing as mp
-        with mp.get_context('spawn').Pool(procs) as pool:
-            per_group = pool.map(_bounded_group, jobs)
-    else:
-        per_group = [_bounded_group(j) for j in jobs]
+    per_group = [_bounded_group((nets_state, walk_w.detach(), z[idx], alpha_for_graph[idx], attr_idx, layers, no_content_loss, no_gan_loss, clamp_variant))
+                 for idx in groups]
     acc = dict(reg=0.0, cont=0.0, gan=0.0, grad=0.0, cont_terms=None)
     for idx, r in zip(groups, per_group):
         for k, i in enumerate(idx):
