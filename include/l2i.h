@@ -93,10 +93,6 @@ typedef struct l2i_conv_params {
     int64_t w_bstride;      /* l2i_conv2d_h8 / l2i_conv_transpose2d_h8: bytes between the weight planes of consecutive samples (the generator's */
                             /* modulated convs: style and demodulation folded into one plane set per sample), 0 = one set for every sample    */
     int32_t out_f32;        /* l2i_conv2d_h8: 1 = the output (and residual / res_mask / out_mask / res_sub) is fp32 NCHW instead of bf16 h8      */
-    int32_t slot_f32;       /* l2i_conv2d_h8 / l2i_conv_transpose2d_h8 with bf16 h8 maps (out_f32 = 0), bit mask: 1 = `residual` is an fp32 tensor in */
-                            /* the h8 slot order [B][C/8][H][W][8] (32 bytes per pixel slot), 2 = so is `y` (and the old y of `accumulate`).  The     */
-                            /* residual-trunk gradient of ResNet-50 is carried this way: summed in fp32 through a stage, rounded to bf16 only as the  */
-                            /* operand of the next block's convs (latent2im_amd/nets16.py).  Masks / res_sub stay bf16 h8; sq_ref is refused with 2. */
 } l2i_conv_params;
 #define L2I_SQ_SLOTS 1024
 
@@ -318,7 +314,7 @@ int l2i_segmented_matvec_f32(float* out, const float* in, const float* in2, cons
 
 const char* l2i_last_error(void);
 /* Bumped whenever a struct of this header grows or an entry point changes meaning (1: round 1-2; 2: round 3, l2i_conv_params gained w_bstride /
- * out_f32; 3: round 4).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
+ * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
 #define L2I_ABI_VERSION 3
 int l2i_abi_version(void);
 int l2i_sizeof_conv_params(void);       /* sizeof(struct l2i_conv_params) of THIS build */

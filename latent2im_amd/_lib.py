@@ -35,7 +35,7 @@ class ConvParams(ctypes.Structure):
         ('w_hi', c_p), ('w_lo', c_p),
         ('ws', c_p), ('ksplit', c_i), ('res_sub', c_p), ('res_coef', c_f), ('res_coef_dev', c_p),
         ('sq_ref', c_p), ('sq_out', c_p),
-        ('w_bstride', c_l), ('out_f32', c_i), ('slot_f32', c_i),
+        ('w_bstride', c_l), ('out_f32', c_i),
     ]
 
 

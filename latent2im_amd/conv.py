@@ -618,8 +618,7 @@ class H8Conv:
         out_f32 = kw.get('out_f32', False)
         if out is None:
             out = (torch.empty(B, self.cin, in_hw[0], in_hw[1], device=gy.device, dtype=torch.float32) if out_f32
-                   else torch.empty(B, (self.cin + 7) // 8, in_hw[0], in_hw[1], 8, device=gy.device,
-                                    dtype=torch.float32 if kw.get('trunk_f32', 0) & 2 else torch.bfloat16))
+                   else torch.empty(B, (self.cin + 7) // 8, in_hw[0], in_hw[1], 8, device=gy.device, dtype=torch.bfloat16))
         pl = planes if planes is not None else self.bwd_planes
         if self.transposed:                                   # dx[ci, i] = sum gy[co, 2i + k - pad] w[co, ci, k]: a stride-2 correlation
             return run_h8(pl, gy, out, self.coutp_in, self.cin, self.k, 2, self.padding, transposed=False, w_bstride=w_bstride, **kw)
@@ -642,10 +641,8 @@ H8Conv.dgrad_compact = _h8_dgrad_compact
 
 def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=0, out_f32=False, out_scale=None, noise=None, noise_w=0.0, bias=None,
            residual=None, res_mask=None, out_mask=None, mask=(1.0, 0.0), act=ACT_NONE, slope=0.2, gain=1.0, out_gain=1.0, accumulate=False, res_sub=None, res_coef=1.0,
-           res_coef_dev=None, sq=None, relu_in=False, trunk_f32=0):
-    """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels.
-    ``trunk_f32`` (l2i_conv_params.slot_f32): bit 1 = ``residual`` is fp32 in the slot order of ``y``, bit 2 = ``y`` itself is (the fp32 residual trunk
-    of a gradient pass: summed without rounding, nets16._ResNet16Fn)."""
+           res_coef_dev=None, sq=None, relu_in=False):
+    """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels."""
     lib = _lib.load()
     B, cg, H, W, _ = x.shape
     assert x.dtype == torch.bfloat16 and cg * 8 == cin and cin % 16 == 0, (x.shape, cin)
@@ -655,7 +652,7 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
         assert y.dtype == torch.float32 and y.shape[1] == cout
         OHf, OWf = y.shape[2], y.shape[3]
     else:
-        assert y.dtype == (torch.float32 if trunk_f32 & 2 else torch.bfloat16) and y.shape[1] * 8 >= cout and cout % 8 == 0, (y.shape, cout, y.dtype)
+        assert y.dtype == torch.bfloat16 and y.shape[1] * 8 >= cout and cout % 8 == 0, (y.shape, cout)
         OHf, OWf = y.shape[2], y.shape[3]
     p = ConvParams()
     p.x, p.w_hi, p.y = _lib.ptr(x), _lib.ptr(planes), _lib.ptr(y)
@@ -670,10 +667,8 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
         p.OH, p.OW = min(OHf, (H + 2 * pad - k) // stride + 1), min(OWf, (W + 2 * pad - k) // stride + 1)
         p.oy_step = p.ox_step = 1
     p.out_scale, p.noise, p.noise_w, p.bias = _lib.fptr(out_scale), _lib.fptr(noise), float(noise_w), _lib.fptr(bias)
-    for t in (res_mask, out_mask, res_sub):
-        assert t is None or (t.shape == y.shape and t.dtype == (torch.float32 if out_f32 else torch.bfloat16))
-    assert residual is None or (residual.shape == y.shape and residual.dtype == (torch.float32 if (out_f32 or trunk_f32 & 1) else torch.bfloat16))
-    p.slot_f32 = int(trunk_f32)
+    for t in (residual, res_mask, out_mask, res_sub):
+        assert t is None or (t.shape == y.shape and t.dtype == y.dtype)
     p.residual, p.res_mask, p.out_mask = _lib.ptr(residual), _lib.ptr(res_mask), _lib.ptr(out_mask)
     p.mask_pos, p.mask_neg = mask                                 # of the OUTPUT mask here: * (out_mask > 0 ? mask[0] : mask[1])
     if relu_in:                                                   # ReLU-on-load (VGG-19 reads pre-ReLU taps): in_mask == x, mask (1, 0)

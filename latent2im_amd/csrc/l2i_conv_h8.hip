@@ -93,19 +93,12 @@ struct H8Out {
         // every operand of the slot is requested before the first one is used: the first version loaded and consumed them one by one, up to five
         // dependent memory round trips per slot and eight slots per wave
         u32x4 q_mask, q_res, q_sub, q_rmask, q_old;
-        float4 s0, s1, b0, b1, r32a, r32b, o32a, o32b;
-        const bool res32 = (p.slot_f32 & 1) != 0, out32 = (p.slot_f32 & 2) != 0;      // fp32 tensors in slot order (kernel arguments: uniform)
+        float4 s0, s1, b0, b1;
         if (p.out_mask) q_mask = reinterpret_cast<const u32x4*>(p.out_mask)[slot];
-        if (p.residual) {
-            if (res32) { r32a = reinterpret_cast<const float4*>(p.residual)[2 * slot]; r32b = reinterpret_cast<const float4*>(p.residual)[2 * slot + 1]; }
-            else q_res = reinterpret_cast<const u32x4*>(p.residual)[slot];
-        }
+        if (p.residual) q_res = reinterpret_cast<const u32x4*>(p.residual)[slot];
         if (p.res_sub) q_sub = reinterpret_cast<const u32x4*>(p.res_sub)[slot];
         if (p.res_mask) q_rmask = reinterpret_cast<const u32x4*>(p.res_mask)[slot];
-        if (p.accumulate) {
-            if (out32) { o32a = reinterpret_cast<const float4*>(p.y)[2 * slot]; o32b = reinterpret_cast<const float4*>(p.y)[2 * slot + 1]; }
-            else q_old = y4[slot];
-        }
+        if (p.accumulate) q_old = y4[slot];
         if (p.out_scale) { s0 = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Cout + co0); s1 = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Cout + co0 + 4); }
         if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + co0); b1 = *reinterpret_cast<const float4*>(p.bias + co0 + 4); }
         if (p.out_scale) { v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w; v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w; }
@@ -122,8 +115,7 @@ struct H8Out {
         }
         if (p.residual) {
             float r[8];
-            if (res32) { r[0] = r32a.x; r[1] = r32a.y; r[2] = r32a.z; r[3] = r32a.w; r[4] = r32b.x; r[5] = r32b.y; r[6] = r32b.z; r[7] = r32b.w; }
-            else h8_unpack(q_res, r);
+            h8_unpack(q_res, r);
             if (p.res_sub) {
                 float s[8];
                 h8_unpack(q_sub, s);
@@ -152,15 +144,9 @@ struct H8Out {
         }
         if (p.accumulate) {
             float o[8];
-            if (out32) { o[0] = o32a.x; o[1] = o32a.y; o[2] = o32a.z; o[3] = o32a.w; o[4] = o32b.x; o[5] = o32b.y; o[6] = o32b.z; o[7] = o32b.w; }
-            else h8_unpack(q_old, o);
+            h8_unpack(q_old, o);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += o[e];
-        }
-        if (out32) {                                               // the fp32 trunk: no rounding on the way out
-            reinterpret_cast<float4*>(p.y)[2 * slot] = make_float4(v[0], v[1], v[2], v[3]);
-            reinterpret_cast<float4*>(p.y)[2 * slot + 1] = make_float4(v[4], v[5], v[6], v[7]);
-            return;
         }
         const u32x4 out = {cvt_pk_bf16_h8(v[0], v[1]), cvt_pk_bf16_h8(v[2], v[3]), cvt_pk_bf16_h8(v[4], v[5]), cvt_pk_bf16_h8(v[6], v[7])};
 #ifdef L2I_H8_ABLATE_STORE                                 // timing ablation: the epilogue's arithmetic without its global store
@@ -561,7 +547,7 @@ static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
     static const int lean_env = getenv("L2I_H8_LEAN") ? atoi(getenv("L2I_H8_LEAN")) : 1;
     // identity / ReLU / leaky ReLU as max(g * gpos, g * gneg) needs 0 <= gneg <= gpos
     const bool gains_ok = p.out_gain > 0.f && (p.act != L2I_ACT_LRELU || (p.act_gain > 0.f && p.act_slope >= 0.f && p.act_slope <= 1.f));
-    L.lean_epi = (!OUT32 && lean_env && !p.slot_f32 && !p.out_mask && !p.residual && !p.accumulate && !p.sq_ref && gains_ok && (size_t)p.OHf * p.OWf < 0xFFFFFFFFull) ? 1 : 0;
+    L.lean_epi = (!OUT32 && lean_env && !p.out_mask && !p.residual && !p.accumulate && !p.sq_ref && gains_ok && (size_t)p.OHf * p.OWf < 0xFFFFFFFFull) ? 1 : 0;
     size_t lds = (size_t)(2 * G::IN_STAGE + 2 * WSLOTS) * 16;
     if (OUT32 && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: tile does not fit the LDS");
@@ -588,9 +574,6 @@ static int h8_common_checks(const l2i_conv_params& p, const char* who) {
     if ((size_t)(p.Cin / 8) * p.H * p.W * 16 >= 0xFFFFFFF0ull || (size_t)(p.Cin / 16) * p.KH * p.KW * 2 * p.CoutP * 16 >= 0xFFFFFFF0ull)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: one sample / the weight planes must stay below 4 GiB (32-bit buffer offsets)");
     if (p.res_sub && !p.residual) return l2i_set_error(L2I_E_ARG, "conv h8: res_sub needs residual");
-    if (p.slot_f32 & ~3) return l2i_set_error(L2I_E_ARG, "conv h8: slot_f32 is a mask of 1 (fp32 residual) and 2 (fp32 y)");
-    if (p.slot_f32 && (p.out_f32 || ((p.slot_f32 & 2) && p.sq_ref) || ((p.slot_f32 & 1) && (!p.residual || p.res_sub))))
-        return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: slot_f32 needs bf16 h8 maps (out_f32 = 0), bit 1 a residual without res_sub, bit 2 no sq_ref");
     if ((p.sq_ref != nullptr) != (p.sq_out != nullptr)) return l2i_set_error(L2I_E_ARG, "conv h8: sq_ref and sq_out go together");
     (void)who;
     return L2I_OK;

@@ -31,13 +31,6 @@ from .specs import RESNET50_LAYERS
 
 SQRT2 = math.sqrt(2.0)
 LRELU_MASK = (SQRT2, 0.2 * SQRT2)
-# ResNet-50's residual-trunk gradient carried in fp32 through a stage (_ResNet16Fn.backward, l2i_conv_params.slot_f32).  Built on the round-3 review's
-# hypothesis that sixteen successive bf16 roundings of the trunk cost the gradient its direction; MEASURED (tools/bf16_study.py, round 4): no effect —
-# input-gradient cosine against the exact oracle 0.9715 / 0.9526 at 64^2 / 256^2 with the bf16 AND with the fp32 trunk, to four digits.  Rounding a
-# gradient map is unbiased noise of 2^-9 per element (sqrt(50) layers of it: 1.4 %); what moves the gradient is the FORWARD: feature maps stored 2^-9
-# off flip the ReLU masks of units near zero, and the exact oracle with nothing but that storage rounding restated (oracle/nets16.py) lands at the same
-# cosine.  Off by default (it costs 8 bytes per trunk element and block); kept as an option and covered by tests/test_h8_gpu.py.
-TRUNK_F32 = os.environ.get('L2I_TRUNK_F32', '0') != '0'
 
 
 # =====================================================================================================================================
@@ -168,38 +161,31 @@ class _ResNet16Fn(torch.autograd.Function):
             raise RuntimeError('regressor was run without a differentiable input')
         b, g8, h, w, _ = last.shape
         hw = lambda t: (t.shape[2], t.shape[3])
-        # [r4] TRUNK_F32: the residual-trunk gradient G carried in FP32 (slot order [B][C/8][H][W][8]) through the identity blocks of a stage:
-        # G <- mask * (c1^T g_y1 + G) is summed in the conv epilogue without rounding (l2i_conv_params.slot_f32), and G is rounded to bf16 only as
-        # the OPERAND of the next block's c3 gradient conv.  At the three stage boundaries (projection shortcut: no identity term) the sum is
-        # formed in bf16 and widened.  Measured to change nothing (see TRUNK_F32 above): off by default.
-        trunk32 = TRUNK_F32
-        g = (g_feat * (1.0 / (h * w))).reshape(b, g8, 1, 1, 8).expand(b, g8, h, w, 8).contiguous()
-        G = K16.mask_mul(g.to(torch.bfloat16), last)                                   # gradient w.r.t. the pre-ReLU sum of the last block
-        if trunk32:
-            G = G.float()
+        # The residual-trunk gradient G stays bf16 (h8) from block to block.  [r4] Carrying it in fp32 through a stage (the round-3 review's
+        # hypothesis: sixteen successive bf16 roundings cost the gradient its direction) was built — fp32 residual / output operands in the conv
+        # epilogue — and MEASURED: input-gradient cosine against the exact oracle 0.9715 / 0.9526 at 64^2 / 256^2 with either trunk, identical to four
+        # digits (profiles/r04_bf16_trunk_f32_vs_bf16.txt; the cause is the forward's storage rounding), while its two extra
+        # epilogue branches cost the 16-bit conv kernel 3 - 17 % on launches with a residual (c5 209.5 -> 213.1 images/s without them): removed.
+        g = (g_feat * (1.0 / (h * w))).reshape(b, g8, 1, 1, 8).expand(b, g8, h, w, 8).contiguous().to(torch.bfloat16)
+        G = K16.mask_mul(g, last)                                                        # gradient w.r.t. the pre-ReLU sum of the last block
         n = len(net.blocks)
         for bi in range(n - 1, -1, -1):
             blk, (cur, y1, y2, out) = net.blocks[bi], saved['blocks'][bi]
             m = cur if bi > 0 else None                    # the block input is the previous block's ReLU output (the pooled stem map is not)
-            Gh = G.to(torch.bfloat16) if trunk32 else G    # the conv operand: ONE rounding of the fp32 sum
-            g_y2 = blk['c3'].conv.dgrad(Gh, hw(y2), out_mask=y2)
+            g_y2 = blk['c3'].conv.dgrad(G, hw(y2), out_mask=y2)
             g_y1 = blk['c2'].conv.dgrad(g_y2, hw(y1), out_mask=y1)
             del g_y2
             if blk['down'] is None:
-                Gp = blk['c1'].conv.dgrad(g_y1, hw(cur), residual=G, out_mask=m, res_mask=m, trunk_f32=3 if trunk32 else 0)
+                Gp = blk['c1'].conv.dgrad(g_y1, hw(cur), residual=G, out_mask=m, res_mask=m)
             elif blk['down'].conv.stride == 1:
                 t = blk['c1'].conv.dgrad(g_y1, hw(cur))
-                Gp = blk['down'].conv.dgrad(Gh, hw(cur), residual=t, out_mask=m, res_mask=m, trunk_f32=2 if trunk32 else 0)
+                Gp = blk['down'].conv.dgrad(G, hw(cur), residual=t, out_mask=m, res_mask=m)
                 del t
             else:
                 Gp = blk['c1'].conv.dgrad(g_y1, hw(cur), out_mask=m)
-                K16.add_zero_insert(Gp, blk['down'].conv.dgrad_compact(Gh), mask=m)      # strided 1x1: compact 1x1 conv + zero insertion
-                if trunk32:
-                    Gp = Gp.float()
-            del g_y1, Gh
+                K16.add_zero_insert(Gp, blk['down'].conv.dgrad_compact(G), mask=m)       # strided 1x1: compact 1x1 conv + zero insertion
+            del g_y1
             G = Gp
-        if trunk32:
-            G = G.to(torch.bfloat16)
         a0 = saved['a0']
         g_a0 = K16.cast_from_h8(K16.maxpool2d_bwd(G, saved['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1), a0.shape[1])
         g_img = net.stem.conv.dgrad(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0))
