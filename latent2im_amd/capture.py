@@ -25,7 +25,9 @@ def freeze_host_objects():
     weight handles — into the collector's permanent generation (``gc.freeze``).  A full collection otherwise walks all of them (measured
     73 ms) whenever the young generations overflow, about once per 20 steps, on the thread that launches the step's ~650 kernels and is barely
     ahead of the GPU: one 160-250 ms step among 120 ms ones (the +4 % between a 5-step and a 20-step timing of round 3).  Afterwards a full
-    pass only sees objects created since (0.01 ms).  The step itself leaves no reference cycles behind (tools/probes/gc_cycles.py)."""
+    pass only sees objects created since (0.01 ms).  The step itself leaves no reference cycles behind (tools/probes/gc_cycles.py).
+    A program that later drops a whole graph and builds another calls ``gc.unfreeze()`` first (frozen objects are still freed by reference
+    counting; only a cycle among them would wait for the unfreeze), as bench.py does between its workloads."""
     import gc
     gc.collect()
     gc.freeze()
