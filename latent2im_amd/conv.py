@@ -415,7 +415,8 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
     elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
           and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise, res_sub)):
         relu_in = in_mask is not None and in_mask.data_ptr() == x.data_ptr() and tuple(mask) == (1.0, 0.0)
-        if (WINO4 == 'all' or (WINO4 == 'nograd' and NOGRAD_PASS)) and OW >= 64 and (in_mask is None or relu_in):
+        if ((WINO4 == 'all' or (WINO4 == 'nograd' and NOGRAD_PASS)) and OW >= 64 and (in_mask is None or relu_in)
+                and cin * H * W * 4 < 0x7FFF0000):             # (one sample below 2 GiB: the kernel's out-of-range sentinel)
             pk = L.wino4_pack()
             p.w, p.CoutP = _lib.fptr(pk), pk.shape[1] * 16
             entry, name = lib.l2i_conv2d_wino4_f32, 'l2i_conv2d_wino4_f32'
