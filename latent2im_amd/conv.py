@@ -19,23 +19,12 @@ import os as _os
 PRECISION = _os.environ.get('L2I_PRECISION', 'f32')      # 'bf16x3': eligible stride-1 layers take the split-precision bf16 MFMA kernel (opt-in)
 USE_WINOGRAD = _os.environ.get('L2I_WINOGRAD', '1') != '0'    # 3x3 stride-1 layers on maps >= 32 wide take the F(2x2,3x3) fp32 kernel
 # [r4] Winograd F(4x4,3x3) (csrc/l2i_wino4.hip: 1.78x fewer MFMAs than F(2x2), error ~1e-6..1e-5 of max|y| instead of 3e-7) for the unmasked 3x3
-# stride-1 launches on maps >= 64 wide: 'all' = every eligible launch, 'nograd' = only launches made under `no_grad_pass()` (the first generator
-# / regressor pass of a step builds no graph: no mask of it ever feeds a backward), 'off'.  Which setting ships is decided by the parity suite.
+# stride-1 launches on maps >= 64 wide: 'all' = every eligible launch on the [r5] position-split kernel, 'r4' = the same launches on the round-4
+# kernel (kept for A/B runs: the two are bit-identical), 'off' = F(2x2) everywhere.  The parity suite runs 'all' and 'off'.
+WINO4_MODES = ('all', 'r4', 'off')
 WINO4 = _os.environ.get('L2I_WINO4', 'all')
-NOGRAD_PASS = False
-
-
-class no_grad_pass:
-    """with conv.no_grad_pass(): launches inside belong to a pass whose activations feed no backward (policy 'nograd' of WINO4)."""
-
-    def __enter__(self):
-        global NOGRAD_PASS
-        self.prev, NOGRAD_PASS = NOGRAD_PASS, True
-
-    def __exit__(self, *a):
-        global NOGRAD_PASS
-        NOGRAD_PASS = self.prev
-
+if WINO4 not in WINO4_MODES:
+    raise ValueError('L2I_WINO4 must be one of %s, got %r' % (WINO4_MODES, WINO4))
 SPLIT_K = _os.environ.get('L2I_SPLIT_K', '1') != '0'    # 4x4 .. 16x16 maps: cut Cin into ranges computed by separate blocks (l2i.h: ksplit / ws)
 _WS = {}            # split-K workspaces, one per (device, stream)
 USE_FUSED_TRANSPOSED = True     # False: issue stride-2 transposed convs as four per-parity launches
@@ -110,12 +99,12 @@ _WINO4_G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1
 def pack_weight_wino4(w):
     """[Cout, Cin, 3, 3] -> Winograd F(4x4,3x3) weights U = G g G^T (6x6, computed in float64, stored fp32) in the LDS image order of
     csrc/l2i_wino4.hip: [Cin/4][CoutP/16][ [6 i][4 cin][16 cout][4 (j = 0..3)] ++ [6 i][4 cin][16 cout][2 (j = 4, 5)] ], CoutP = Cout rounded
-    up to 16 — a block's slice of a 4-channel chunk is one contiguous 9216-byte image that goes global -> LDS by DMA."""
+    up to 32 — a block's slice of a 4-channel chunk (two consecutive 16-channel images: 18432 contiguous bytes) goes global -> LDS by DMA."""
     w = torch.as_tensor(w, dtype=torch.float64)
     cout, cin, kh, kw = w.shape
     assert kh == 3 and kw == 3 and cin % 4 == 0
     G = torch.as_tensor(_WINO4_G, device=w.device)
-    coutp = (cout + 15) // 16 * 16
+    coutp = (cout + 31) // 32 * 32
     U = torch.zeros(coutp, cin, 6, 6, dtype=torch.float64, device=w.device)
     U[:cout] = torch.einsum('ik,ockl,jl->ocij', G, w, G)
     U = U.reshape(coutp // 16, 16, cin // 4, 4, 6, 6).permute(2, 0, 4, 3, 1, 5)          # [c4, mb, i, k, m, j]
@@ -162,6 +151,12 @@ class Launch:
         self.w = self.w.to(device)
         if self.w4 is not None:
             self.w4 = self.w4.to(device)
+        if self.wino is not None:
+            self.wino = self.wino.to(device)
+        if self.wino4 is not None:
+            self.wino4 = self.wino4.to(device)
+        if self.w16 is not None:
+            self.w16 = tuple(t.to(device) for t in self.w16)
         return self
 
 
@@ -415,10 +410,11 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
     elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
           and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise, res_sub)):
         relu_in = in_mask is not None and in_mask.data_ptr() == x.data_ptr() and tuple(mask) == (1.0, 0.0)
-        if ((WINO4 == 'all' or (WINO4 == 'nograd' and NOGRAD_PASS)) and OW >= 64 and (in_mask is None or relu_in)
+        if (WINO4 != 'off' and OW >= 64 and (in_mask is None or relu_in) and L.pad_x == 1 and W % 4 == 0 and cin % 4 == 0
                 and cin * H * W * 4 < 0x7FFF0000):             # (one sample below 2 GiB: the kernel's out-of-range sentinel)
             pk = L.wino4_pack()
             p.w, p.CoutP = _lib.fptr(pk), pk.shape[1] * 16
+            p.tile_hint = 1 if WINO4 == 'r4' else 0            # (A/B: the round-4 kernel on the same pack)
             entry, name = lib.l2i_conv2d_wino4_f32, 'l2i_conv2d_wino4_f32'
         else:
             p.w = _lib.fptr(L.wino_pack())

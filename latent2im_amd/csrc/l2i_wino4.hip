@@ -480,6 +480,428 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const l2i_conv_param
     }
 }
 
+// ====================================================================================================================================
+// [r5] conv_wino4s_kernel — the same F(4x4,3x3) arithmetic, POSITION-SPLIT: the 36 Winograd positions of a (channel block, tile row) are shared by
+// two waves (rows 0..2 / 3..5 of the 6x6 position grid), each of which carries them for TWO 16-channel groups: 18 positions x 2 groups x 4
+// registers = the same 144 accumulators and two blocks per CU, but
+//   * a wave's input transform is only the half of V = B^T d B it multiplies (3 of the 6 rows of B^T d: 6 v_pk per column pair instead of 12, then
+//     the horizontal pass of 3 rows): 36 packed VALU per 36 MFMAs where the first kernel spends 72 — an fp32 MFMA shares its issue with the VALU
+//     (tools/probes/mfma_valu_overlap_probe.hip), every VALU instruction of the stream is matrix time;
+//   * a block owns 32 output channels (was 16): the raw tile is fetched and staged Cout/32 times, not Cout/16 times;
+//   * the raw halo tile goes global -> LDS by 16-BYTE DMA: the LDS window is the 72 columns ox0 - 4 .. ox0 + 67, whose 4-column groups are
+//     aligned with the image (W % 4 == 0), so a group is inside or outside the image as a whole (outside: out-of-range offset = zeros) and a
+//     (4 channel x 10 row) chunk is 3 DMA instructions per wave instead of 11 dword ones.  The raw planes start 4 bytes off 16-byte alignment
+//     (LDS-DMA writes do not care), which puts the patch column pairs (window columns 3 + 4 n + 2 cp) on 8-byte boundaries for ds_read_b64.
+// Block = 4 waves = (position half h = wave & 1) x (tile row t = wave >> 1) = 32 channels x (64 x 8) pixels.  After the K loop the two waves of a
+// tile row swap halves through LDS (the rings are dead by then): wave (h, t) hands over its rows of group 1 - h and finishes group h with the
+// first kernel's lane-local inverse transform and fused epilogue.  Same products, same accumulation order, same inverse: BIT-IDENTICAL to
+// conv_wino4_kernel (tests/test_kernels_gpu.py holds the two against each other).
+namespace w4s {
+constexpr int BMG = 2, BM = 16 * BMG, CK = 4;
+constexpr int TW = 64, TH = 8;
+constexpr int IH = TH + 2;                              // 10 halo rows
+constexpr int IWG = 18, IWP = 4 * IWG;                  // 18 16-byte groups = 72 window columns per row
+constexpr int NGRP = IH * IWG;                          // 180 groups per channel plane
+constexpr int NRS = 3;                                  // 16-byte DMA slots per plane (wave w fetches channel w of the chunk: 192 lanes >= 180)
+constexpr int PLANE = 770;                              // floats: >= 64 NRS 4 (the idle lanes of the last slot write zeros inside their own plane), = 2 (mod 4)
+constexpr int RAWST = CK * PLANE;
+constexpr int UG = CK * 36 * 16;                        // floats of one 16-channel group image of a chunk (9216 B, as w4::UST)
+constexpr int UST = BMG * UG;                           // a block's slice of a chunk: two consecutive group images = 18432 contiguous bytes of the pack
+constexpr int UA = 6 * 64 * 4;
+constexpr int NUSLOT = UST * 4 / 1024;                  // 18 real 1 KiB slots per chunk
+constexpr int NUS = 5;                                  // slots per wave (slot = wave + 4 j; waves 2, 3: the fifth goes to the dump)
+constexpr int RS = 3, US = 2;
+constexpr int RAW0 = US * UST + 1;                      // float index of the raw ring: 4 bytes off 16-byte alignment
+constexpr int DUMP = 256;
+constexpr int LDS_FLOATS = US * UST + 4 + RS * RAWST + DUMP;
+constexpr int XCH = 18 * 64 * 4;                        // floats a wave hands over in the epilogue (18 positions x 64 lanes x float4)
+static_assert(PLANE % 4 == 2 && PLANE >= 64 * NRS * 4, "plane pitch");
+static_assert(4 * XCH <= US * UST + 4 + RS * RAWST, "the exchange area lives in the dead rings");
+static_assert(NUS * 4 >= NUSLOT && (NUS - 1) * 4 < NUSLOT, "U slots");
+}
+
+struct Wino4sLaunch {
+    int tiles_x, tiles_y, mblocks;
+    int total;
+    int nchunks;
+};
+
+template <bool SCALE, bool RELU, int H>
+__device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino4sLaunch& L, float* smem) {
+    using namespace w4s;
+    float* ubuf = smem;                                // US x UST
+    float* rawbuf = smem + RAW0;                       // RS x [CK][PLANE]
+    float* dump = smem + US * UST + 4 + RS * RAWST;
+    float* stab = dump + DUMP;                         // SCALE: [Cin] style scales of this sample
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane >> 4, n = lane & 15;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int trow = wave_u >> 1;                      // tile row of this wave (H = wave & 1: position rows 3 H .. 3 H + 2)
+
+    const int G = gridDim.x;
+    int w = (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
+    if (w >= L.total) return;
+    const int mblk = w % L.mblocks; w /= L.mblocks;
+    const int tx = w % L.tiles_x; w /= L.tiles_x;
+    const int ty = w % L.tiles_y; w /= L.tiles_y;
+    const int b = w, m0 = mblk * BM, oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 - p.pad_y;
+
+    // ---- staging ----
+    const unsigned plane_b = (unsigned)((size_t)p.H * p.W * sizeof(float));
+    const unsigned in_bytes = (unsigned)p.Cin * plane_b;
+    const size_t smp = (size_t)b * p.Cin * ((size_t)p.H * p.W);
+    const unsigned uchunk_b = (unsigned)(p.CoutP / 16) * (unsigned)(UG * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + smp), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)(p.Cin / CK) * uchunk_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0u, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned voff[NRS];                                // group 64 u + lane of the [10][18] plane -> byte offset in the channel plane (minus the immediate)
+#pragma unroll
+    for (int u = 0; u < NRS; ++u) {
+        const int e = u * 64 + lane;
+        const int iy = e / IWG, ig = e - iy * IWG;
+        const int gy = iy0 + iy, gx = ox0 - 4 + 4 * ig;
+        const bool ok = (e < NGRP) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
+        voff[u] = ok ? (unsigned)(gy * p.W + gx) * 4u - (unsigned)u * 1024u : OOB;
+    }
+    const unsigned wvoff = (unsigned)lane * 16u;
+    const unsigned lds_raw = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)rawbuf;
+    const unsigned lds_u = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)ubuf;
+    const unsigned lds_dump = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)dump;
+
+    // DMA of one chunk = 2 statements per wave: U (5 x 16 bytes per lane: slots wave + 4 j of the 18 KiB image; the fifth slot of waves 2, 3 is
+    // past the image: null descriptor into the dump) and the wave's channel plane of the raw tile (3 x 16 bytes per lane).
+    auto issue_u = [&](int cu, int ust, bool on) {
+        const unsigned base = lds_u + (unsigned)(ust * UST * 4) + (unsigned)wave_u * 1024u;
+        const unsigned so = (unsigned)cu * uchunk_b + (unsigned)mblk * (unsigned)(UST * 4) + (unsigned)wave_u * 1024u;
+        const bool w01 = wave_u < 2;
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %8 offen lds\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %9 offen lds\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %10 offen lds\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %11 offen lds\n\t"
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %12 offen lds"
+                     :: "v"(wvoff), "s"((on && !W4_NODMA) ? rs_w : rs_null), "s"((on && w01 && !W4_NODMA) ? rs_w : rs_null),
+                        "s"(base), "s"(base + 4096u), "s"(base + 8192u), "s"(base + 12288u), "s"(w01 ? base + 16384u : lds_dump),
+                        "s"(so), "s"(so + 4096u), "s"(so + 8192u), "s"(so + 12288u), "s"(so + 16384u) : "memory");
+    };
+    auto issue_raw = [&](int cr, int rst, bool on) {
+        const unsigned base = lds_raw + (unsigned)((rst * RAWST + wave_u * PLANE) * 4);
+        const unsigned so = (unsigned)(cr * CK + wave_u) * plane_b;
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %0, %4, %5 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %4, %5 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %2, %4, %5 offen offset:2048 lds"
+                     :: "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(base), "s"((on && !W4_NODMA) ? rs_x : rs_null), "s"(so) : "memory");
+    };
+
+    if constexpr (SCALE) {
+        for (int i = tid; i < p.Cin; i += 256) stab[i] = p.in_scale[(size_t)b * p.Cin + i];
+    }
+
+    const f32x2 km4 = {-4.f, -4.f}, k4 = {4.f, 4.f}, km5 = {-5.f, -5.f}, k2 = {2.f, 2.f}, km2 = {-2.f, -2.f};
+    const f32x2 km4m1 = {-4.f, -1.f}, k2m2 = {2.f, -2.f};
+
+    // ---- input transform, vertical pass of one column pair: raw rows P[0..5] -> rows 3 H .. 3 H + 2 of B^T P (in P[0..2]) ----
+    auto colpass = [&](f32x2 (&P)[6], f32x2 sc) {
+        if (W4_NOXF) return;
+        constexpr int R0 = H ? 1 : 0;                  // rows the half reads: 0..4 (H = 0), 1..5 (H = 1)
+        if constexpr (RELU) {
+            const f32x2 krelu = {W4_RELU_SCALE, W4_RELU_SCALE};
+#pragma unroll
+            for (int r = R0; r < R0 + 5; ++r) P[r] = w4_relu_scaled(P[r], krelu);
+        }
+        if constexpr (SCALE) {
+#pragma unroll
+            for (int r = R0; r < R0 + 5; ++r) P[r] = w4_mul(P[r], sc);
+        }
+        if constexpr (H == 0) {
+            const f32x2 a = w4_fmak(P[2], km4, P[4]), bq = w4_fmak(P[1], km4, P[3]);
+            const f32x2 t0 = w4_fmak(P[0], k4, w4_fmak(P[2], km5, P[4]));
+            P[0] = t0; P[1] = w4_add(a, bq); P[2] = w4_sub(a, bq);
+        } else {
+            const f32x2 c = w4_sub(P[4], P[2]), e = w4_sub(P[3], P[1]);
+            const f32x2 t5 = w4_fmak(P[1], k4, w4_fmak(P[3], km5, P[5]));
+            P[0] = w4_fmak(e, k2, c); P[1] = w4_fmak(e, km2, c); P[2] = t5;
+        }
+    };
+
+    f32x4 acc[BMG][18];
+    f32x2 Ta[3][3], Tb[3][3];                          // [position row][column pair] of this half: the chunk being multiplied / the next chunk
+
+    // patch of (channel kq, tile (trow, n)): its top-left element is window column 3 + 4 n of halo row 4 trow
+    const unsigned pa0 = lds_raw + (unsigned)((kq * PLANE + (4 * trow) * IWP + 3 + 4 * n) * 4);
+    auto load_pair = [&](f32x2 (&P)[6], unsigned pa, int cp) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) P[r] = w4_lds_b64(pa, (r * IWP + 2 * cp) * 4);
+    };
+    auto scale_of = [&](int cch) -> f32x2 {
+        if constexpr (SCALE) { const int ci = min(cch * CK + kq, p.Cin - 1); const float s = stab[ci]; return f32x2{s, s}; }
+        return f32x2{1.f, 1.f};
+    };
+
+    // ---- prologue: U(0); raw(0), raw(1), raw(2) ----
+    issue_u(0, 0, true);
+    issue_raw(0, 0, true);
+    issue_raw(1, 1, 1 < L.nchunks);
+    issue_raw(2, 2, 2 < L.nchunks);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NRS) : "memory");            // U(0), raw(0) landed
+    __syncthreads();                                                          // (also: the style-scale table)
+    {
+        const f32x2 sc = scale_of(0);
+#pragma unroll
+        for (int cp = 0; cp < 3; ++cp) {
+            f32x2 P[6];
+            load_pair(P, pa0, cp);
+            w4_lds_wait6(P[0], P[1], P[2], P[3], P[4], P[5]);
+            colpass(P, sc);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Ta[r][cp] = P[r];
+        }
+    }
+
+    // ---- one chunk: 36 MFMAs (3 position rows x 6 columns x 2 channel groups) on T and U stage `ucur`; builds Tn from raw stage `rnext`
+    //      (= raw(ch + 1)); issues U(ch + 1) into the other U stage and raw(ch + 3) into the raw stage chunk ch - 1 was the last to read ----
+    auto chunk = [&](auto first_tag, int ch, int ucur, int rnext, f32x2 (&T)[3][3], f32x2 (&Tn)[3][3]) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const bool on_u = ch + 1 < L.nchunks, on_r = ch + RS < L.nchunks;
+        const int rstw = rnext == 0 ? RS - 1 : rnext - 1;
+        const int ustw = ucur ^ 1;
+        const float4* ua = reinterpret_cast<const float4*>(ubuf + ucur * UST) + (3 * H) * 64 + lane;          // group 0, rows 3 H ..: positions (i, 0..3)
+        const float2* ub = reinterpret_cast<const float2*>(ubuf + ucur * UST + UA) + (3 * H) * 64 + lane;     //                      positions (i, 4..5)
+        const unsigned pa = pa0 + (unsigned)(rnext * RAWST * 4);
+        const f32x2 scn = scale_of(ch + 1);
+        float4 a4[BMG];
+        float2 a2[BMG];
+#pragma unroll
+        for (int g = 0; g < BMG; ++g) { a4[g] = ua[g * (UG / 4)]; a2[g] = ub[g * (UG / 2)]; }
+        f32x2 P[6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float4 c4[BMG];
+            float2 c2[BMG];
+#pragma unroll
+            for (int g = 0; g < BMG; ++g) { c4[g] = a4[g]; c2[g] = a2[g]; }
+            if (i < 2) {
+#pragma unroll
+                for (int g = 0; g < BMG; ++g) { a4[g] = ua[g * (UG / 4) + (i + 1) * 64]; a2[g] = ub[g * (UG / 2) + (i + 1) * 64]; }
+            }
+            load_pair(P, pa, i);                                               // the next chunk's patch, one column pair per position row
+            if (i == 0) issue_u(ch + 1, ustw, on_u);
+            else if (i == 1) issue_raw(ch + RS, rstw, on_r);
+#if W4_NOXF
+            const f32x2 v05 = T[i][0], v12 = T[i][1], v34 = T[i][2];
+#else
+            const f32x2 ac = w4_fmak_lo(T[i][1], km4m1, T[i][2]);               // (x4 - 4 x2, x4 - x2)
+            const f32x2 be = w4_fmak_hi(T[i][0], km4m1, T[i][1]);               // (x3 - 4 x1, x3 - x1)
+            const f32x2 v05 = w4_fmak_op(T[i][0], k4, w4_fmak(T[i][1], km5, T[i][2]));
+            const f32x2 v12 = w4_lo_pm_lo_op(ac, be);
+            const f32x2 v34 = w4_fmak_hi_op(be, k2m2, ac);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < BMG; ++g) {
+#if W4_NOMFMA
+                if (FIRST) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[g][6 * i + j] = zero;
+                }
+                acc[g][6 * i][0] += c4[g].x * v05.x + c4[g].y * v12.x + c4[g].z * v12.y + c4[g].w * v34.x + c2[g].x * v34.y + c2[g].y * v05.y;
+#else
+                acc[g][6 * i + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c4[g].x, v05.x, FIRST ? zero : acc[g][6 * i + 0], 0, 0, 0);
+                acc[g][6 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c4[g].y, v12.x, FIRST ? zero : acc[g][6 * i + 1], 0, 0, 0);
+                acc[g][6 * i + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c4[g].z, v12.y, FIRST ? zero : acc[g][6 * i + 2], 0, 0, 0);
+                acc[g][6 * i + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(c4[g].w, v34.x, FIRST ? zero : acc[g][6 * i + 3], 0, 0, 0);
+                acc[g][6 * i + 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2[g].x, v34.y, FIRST ? zero : acc[g][6 * i + 4], 0, 0, 0);
+                acc[g][6 * i + 5] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2[g].y, v05.y, FIRST ? zero : acc[g][6 * i + 5], 0, 0, 0);
+#endif
+            }
+            w4_lds_wait6(P[0], P[1], P[2], P[3], P[4], P[5]);
+            colpass(P, scn);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Tn[r][i] = P[r];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto top = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRS) : "memory");            // U(ch) and raw(ch + 1) landed; raw(ch + 2) stays in flight
+        __syncthreads();
+    };
+    auto nxt = [](int v, int m) { return v + 1 == m ? 0 : v + 1; };
+
+    top();
+    chunk(std::true_type(), 0, 0, 1 % RS, Ta, Tb);
+    int ch = 1, rnext = 2 % RS, ucur = 1;
+    for (; ch + 1 < L.nchunks; ch += 2) {
+        top();
+        chunk(std::false_type(), ch, ucur, rnext, Tb, Ta);
+        rnext = nxt(rnext, RS); ucur ^= 1;
+        top();
+        chunk(std::false_type(), ch + 1, ucur, rnext, Ta, Tb);
+        rnext = nxt(rnext, RS); ucur ^= 1;
+    }
+    if (ch < L.nchunks) {
+        top();
+        chunk(std::false_type(), ch, ucur, rnext, Tb, Ta);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // no DMA may outlive the block's LDS
+    __syncthreads();                                                           // every wave is past its last LDS read and its last DMA: the rings are dead
+
+    // ---- the two position halves of a tile row meet: wave (H, t) hands over its rows of group 1 - H and finishes group H ----
+    {
+        float4* xw = reinterpret_cast<float4*>(smem + wave_u * XCH) + lane;
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            const f32x4 v = acc[1 - H][q];
+            xw[q * 64] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    f32x4 oth[18];                                     // the partner's rows (3 (1 - H) ..) of group H
+    {
+        const float4* xr = reinterpret_cast<const float4*>(smem + (wave_u ^ 1) * XCH) + lane;
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            const float4 v = xr[q * 64];
+            oth[q] = f32x4{v.x, v.y, v.z, v.w};
+        }
+    }
+    auto M = [&](int r, int j) -> const f32x4& { return (r / 3 == H) ? acc[H][6 * (r - 3 * H) + j] : oth[6 * (r - 3 * (1 - H)) + j]; };
+
+    // ---- epilogue: lane-local inverse transform Y = A^T M A, then 16-byte row stores (lane (g, n): channels m0 + 16 H + 4 g + 0..3, tile (trow, n)) ----
+    const size_t plane_o = (size_t)p.OHf * p.OWf;
+    const int oyb = oy0 + 4 * trow, ox = ox0 + 4 * n;
+    const bool xok = ox < p.OW;
+    float sq = 0.f;
+    const float rc = p.res_sub ? p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) : 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                      // accumulator rows (2 h, 2 h + 1) = two channels as one register pair
+        const int co0 = m0 + 16 * H + 4 * kq + 2 * h;
+        f32x2 yv[4][6];                                // A^T M: rows 0..3, columns 0..5
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            f32x2 m[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) m[r] = h ? f32x2{M(r, j)[2], M(r, j)[3]} : f32x2{M(r, j)[0], M(r, j)[1]};
+            const f32x2 pp = w4_add(m[1], m[2]), qq = w4_sub(m[1], m[2]), rr = w4_add(m[3], m[4]), ss = w4_sub(m[3], m[4]);
+            yv[0][j] = w4_add(w4_add(m[0], pp), rr);
+            yv[1][j] = w4_fmak(ss, k2, qq);
+            yv[2][j] = w4_fmak(rr, k4, pp);
+            yv[3][j] = w4_add(w4_fmak(ss, f32x2{8.f, 8.f}, qq), m[5]);
+        }
+        float scv[2], bv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int co = co0 + q;
+            scv[q] = (p.out_scale && co < p.Cout) ? p.out_scale[(size_t)b * p.Cout + co] : 1.f;
+            bv[q] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+        }
+#pragma unroll
+        for (int ry = 0; ry < 4; ++ry) {
+            const f32x2* m = yv[ry];
+            const f32x2 pp = w4_add(m[1], m[2]), qq = w4_sub(m[1], m[2]), rr = w4_add(m[3], m[4]), ss = w4_sub(m[3], m[4]);
+            const f32x2 y0 = w4_add(w4_add(m[0], pp), rr), y1 = w4_fmak(ss, k2, qq), y2 = w4_fmak(rr, k4, pp);
+            const f32x2 y3 = w4_add(w4_fmak(ss, f32x2{8.f, 8.f}, qq), m[5]);
+            const int oy = oyb + ry;
+            const bool pok = xok && (oy < p.OH);
+            const size_t poff = (size_t)(oy + p.oy_off) * p.OWf + ox + p.ox_off;
+            float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pok && p.noise) {
+                nz = *reinterpret_cast<const float4*>(p.noise + (size_t)b * plane_o + poff);
+                nz.x *= p.noise_w; nz.y *= p.noise_w; nz.z *= p.noise_w; nz.w *= p.noise_w;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int co = co0 + q;
+                if (!(pok && co < p.Cout)) continue;
+                float4 v = q ? make_float4(y0.y, y1.y, y2.y, y3.y) : make_float4(y0.x, y1.x, y2.x, y3.x);
+                if constexpr (RELU) { v.x *= W4_RELU_UNSCALE; v.y *= W4_RELU_UNSCALE; v.z *= W4_RELU_UNSCALE; v.w *= W4_RELU_UNSCALE; }
+                const size_t oidx = ((size_t)b * p.Cout + co) * plane_o + poff;
+                if (p.out_scale) { v.x *= scv[q]; v.y *= scv[q]; v.z *= scv[q]; v.w *= scv[q]; }
+                if (p.out_mask) {
+                    const float4 mk = *reinterpret_cast<const float4*>(p.out_mask + oidx);
+                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                }
+                v.x += nz.x + bv[q]; v.y += nz.y + bv[q]; v.z += nz.z + bv[q]; v.w += nz.w + bv[q];
+                if (p.residual) {
+                    float4 rv = *reinterpret_cast<const float4*>(p.residual + oidx);
+                    if (p.res_sub) {                               // residual term = res_coef * (residual - res_sub)
+                        const float4 sb = *reinterpret_cast<const float4*>(p.res_sub + oidx);
+                        rv.x = rc * (rv.x - sb.x); rv.y = rc * (rv.y - sb.y); rv.z = rc * (rv.z - sb.z); rv.w = rc * (rv.w - sb.w);
+                    }
+                    if (p.res_mask) {
+                        const float4 mk = *reinterpret_cast<const float4*>(p.res_mask + oidx);
+                        rv.x = mk.x > 0.f ? rv.x : 0.f; rv.y = mk.y > 0.f ? rv.y : 0.f; rv.z = mk.z > 0.f ? rv.z : 0.f; rv.w = mk.w > 0.f ? rv.w : 0.f;
+                    }
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                if (p.act == L2I_ACT_LRELU) {                      // max(v, slope v) == (v > 0 ? v : slope v) for 0 <= slope <= 1
+                    v.x = __builtin_fmaxf(v.x, v.x * p.act_slope) * p.act_gain; v.y = __builtin_fmaxf(v.y, v.y * p.act_slope) * p.act_gain;
+                    v.z = __builtin_fmaxf(v.z, v.z * p.act_slope) * p.act_gain; v.w = __builtin_fmaxf(v.w, v.w * p.act_slope) * p.act_gain;
+                } else if (p.act == L2I_ACT_RELU) {
+                    v.x = __builtin_fmaxf(v.x, 0.f); v.y = __builtin_fmaxf(v.y, 0.f); v.z = __builtin_fmaxf(v.z, 0.f); v.w = __builtin_fmaxf(v.w, 0.f);
+                }
+                if (p.out_gain != 1.f) { v.x *= p.out_gain; v.y *= p.out_gain; v.z *= p.out_gain; v.w *= p.out_gain; }
+                if (p.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(p.y + oidx);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                if (!W4_NOEPI || v.x == 123.456f) *reinterpret_cast<float4*>(p.y + oidx) = v;
+                if (p.sq_ref) {                                    // ContentLoss value of a VGG tap: sum (y - reference)^2 while y is in registers
+                    const float4 rf = *reinterpret_cast<const float4*>(p.sq_ref + oidx);
+                    const float d0 = v.x - rf.x, d1 = v.y - rf.y, d2 = v.z - rf.z, d3 = v.w - rf.w;
+                    sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            }
+        }
+    }
+    if (p.sq_ref) {                                                // (kernel argument: uniform branch) one atomic per block, 1024 slots
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+        __syncthreads();                                           // every wave has read its partner's exchange area: the partial sums may overwrite it
+        if (lane == 0) smem[wave_u] = sq;
+        __syncthreads();
+        if (tid == 0) atomicAdd(p.sq_out + (blockIdx.x & (L2I_SQ_SLOTS - 1)), (smem[0] + smem[1]) + (smem[2] + smem[3]));
+    }
+}
+
+template <bool SCALE, bool RELU>
+__global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const l2i_conv_params p, const Wino4sLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // (a wave-uniform branch: the two halves run the same number of barriers)
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino4s_body<SCALE, RELU, 1>(p, L, smem);
+    else wino4s_body<SCALE, RELU, 0>(p, L, smem);
+}
+
+static int launch_wino4s(const l2i_conv_params& p, hipStream_t st) {
+    Wino4sLaunch L;
+    L.tiles_x = (p.OW + w4s::TW - 1) / w4s::TW;
+    L.tiles_y = (p.OH + w4s::TH - 1) / w4s::TH;
+    L.mblocks = p.CoutP / w4s::BM;
+    const long total = (long)p.B * L.tiles_y * L.tiles_x * L.mblocks;
+    if (total <= 0 || total > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: too many tiles");
+    L.total = (int)total;
+    L.nchunks = p.Cin / w4s::CK;
+    const unsigned grid = (unsigned)((total + 7) & ~7L);
+    const bool relu_in = p.in_mask != nullptr;
+    const bool scale = p.in_scale != nullptr;
+    const size_t lds = (size_t)(w4s::LDS_FLOATS + (scale ? ((p.Cin + 3) & ~3) : 0)) * sizeof(float);
+    if (lds > 80 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: too many input channels for the style-scale table");
+#define L2I_WINO4S(S_, R_)                                                                                                              \
+    do {                                                                                                                                \
+        L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4s_kernel<S_, R_>),                        \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                         \
+        hipLaunchKernelGGL((conv_wino4s_kernel<S_, R_>), dim3(grid), dim3(256), lds, st, p, L);                                          \
+    } while (0)
+    if (relu_in) { if (scale) L2I_WINO4S(true, true); else L2I_WINO4S(false, true); }
+    else { if (scale) L2I_WINO4S(true, false); else L2I_WINO4S(false, false); }
+#undef L2I_WINO4S
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
 static int launch_wino4(const l2i_conv_params& p, hipStream_t st) {
     Wino4Launch L;
     L.tiles_x = (p.OW + w4::TW - 1) / w4::TW;
@@ -522,7 +944,7 @@ extern "C" int l2i_conv2d_wino4_f32(const l2i_conv_params* pp, void* stream) {
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: needs a 3x3 stride-1 dense-output layer with Cin % 4 == 0");
     const bool relu_in = p.in_mask && (const void*)p.in_mask == (const void*)p.x && p.mask_pos == 1.f && p.mask_neg == 0.f;
     if (p.in_mask && !relu_in) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: gradient-masked launches take l2i_conv2d_wino_f32");
-    if (p.CoutP < p.Cout || (p.CoutP % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: CoutP must be Cout rounded up to a multiple of 16");
+    if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: CoutP must be Cout rounded up to a multiple of 32");
     if (p.oy_off < 0 || p.ox_off < 0 || p.OH + p.oy_off > p.OHf || p.OW + p.ox_off > p.OWf)
         return l2i_set_error(L2I_E_ARG, "conv2d_wino4: output window exceeds the output tensor");
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
@@ -531,7 +953,10 @@ extern "C" int l2i_conv2d_wino4_f32(const l2i_conv_params* pp, void* stream) {
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: output rows must be 16-byte aligned multiples of 4 pixels");
     if ((size_t)p.Cin * p.H * p.W * sizeof(float) >= 0x7FFF0000ull || (size_t)p.Cin * 36 * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: one sample must stay below 2 GiB, the weight pack below 4 GiB (32-bit buffer offsets)");
-    if (p.tile_hint != 0) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: tile_hint must be 0 (one configuration)");
+    if (p.tile_hint != 0 && p.tile_hint != 1) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: tile_hint must be 0 (position-split kernel) or 1 (the round-4 kernel)");
     if ((p.sq_ref != nullptr) != (p.sq_out != nullptr) || (((uintptr_t)p.sq_ref) % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: sq_ref (16-byte aligned) and sq_out go together");
-    return launch_wino4(p, (hipStream_t)stream);
+    if (p.tile_hint == 1) return launch_wino4(p, (hipStream_t)stream);
+    if (p.pad_x != 1 || (p.W % 4) != 0)
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: the position-split kernel needs pad_x == 1 and W % 4 == 0 (16-byte groups of the halo window aligned with the image)");
+    return launch_wino4s(p, (hipStream_t)stream);
 }

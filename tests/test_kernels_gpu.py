@@ -294,6 +294,50 @@ def test_winograd_3x3_conv(cin, cout, h, w, b, wino4):
     assert e0 < 5e-6, e0
 
 
+@pytest.mark.parametrize('cin,cout,h,w,b', [(64, 64, 64, 64, 2), (8, 64, 64, 128, 3), (40, 24, 50, 132, 2), (256, 128, 16, 64, 1), (512, 512, 8, 64, 1),
+                                            (32, 32, 40, 96, 1), (128, 96, 7, 64, 2), (16, 40, 9, 72, 1)])
+def test_wino4_position_split_kernel_bit_identical_to_round4_kernel(cin, cout, h, w, b):
+    """[r5] The position-split F(4x4,3x3) kernel (two waves share the 36 Winograd positions of a tile row, 32 output channels per block, 16-byte
+    raw-tile DMA through a 72-column aligned window) does the round-4 kernel's arithmetic in the same order: the two must agree BIT FOR BIT on every
+    instantiation (plain, style-scaled, ReLU-on-load, both) with every epilogue operand, on ragged maps (rows not a multiple of 8, widths not a
+    multiple of 64, channel counts that do not fill a block) and on long K loops (both U stages, all three raw stages many times over)."""
+    rs = np.random.RandomState(cin * 7 + cout + h + w)
+    wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    x, s, d = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cin) + 0.5), T(rs.rand(b, cout) + 0.5)
+    bias, res, rmk, omk, rsb = T(rs.randn(cout)), *(T(rs.randn(b, cout, h, w)) for _ in range(4))
+    nz = T(rs.randn(b, 1, h, w))
+    g = lambda t: t.to(DEV)
+    fc = conv.FrozenConv2d(wt, 1, 1, device=DEV)
+    xg = g(x)
+    coef = torch.full((1,), 2.0, device=DEV)
+    calls = [
+        dict(),
+        dict(in_scale=g(s), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5),
+        dict(in_mask=xg, mask=(1.0, 0.0), bias=g(bias), residual=g(res), res_mask=g(rmk), act=conv.ACT_RELU),
+        dict(in_mask=xg, mask=(1.0, 0.0), in_scale=g(s), residual=g(res), res_sub=g(rsb), res_coef=0.25, res_coef_dev=coef, out_mask=g(omk), out_gain=0.5),
+    ]
+    prev = conv.WINO4
+    try:
+        for kw in calls:
+            out, sums = {}, {}
+            for mode in ('r4', 'all'):
+                conv.WINO4 = mode
+                launched = conv.PROFILE = []
+                try:
+                    sq_acc, fused = torch.zeros(_lib.SQ_SLOTS, device=DEV), [False]
+                    y = g(res).clone()
+                    fc.forward(xg, out=y, accumulate=True, sq=(g(rmk), sq_acc, fused), **kw)
+                finally:
+                    conv.PROFILE = None
+                assert [q[4] for q in launched] == ['l2i_conv2d_wino4_f32'] and fused[0]
+                out[mode], sums[mode] = y, sq_acc.double().sum()
+            assert torch.equal(out['r4'], out['all']), float((out['r4'] - out['all']).abs().max())
+            want_sq = float(((out['all'].double() - g(rmk).double()) ** 2).sum())
+            assert abs(float(sums['all']) - want_sq) <= 1e-5 * want_sq and abs(float(sums['r4']) - want_sq) <= 1e-5 * want_sq
+    finally:
+        conv.WINO4 = prev
+
+
 def test_content_loss_sum_fused_into_the_three_channel_conv():
     """VGG conv_1 (3 -> 64, 3x3) runs on the <= 3-input-channel kernel, which also sums (y - reference)^2 in its epilogue."""
     rs = np.random.RandomState(3)

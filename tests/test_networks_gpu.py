@@ -176,6 +176,37 @@ def test_training_step_golden_and_float64_oracle(golden, precision):
     assert np.mean(np.abs(moved - g['single64.walk']) > 2e-4) < 0.02
 
 
+def test_three_consecutive_training_steps_vs_reference_sequence(golden):
+    """[r5] The reference's own three-step optimizeParametersAll sequence (transform_base.py:456-490 + Adam, fixture 'single.{0,1,2}': its walk carried
+    from step to step, its z batches 0-3 / 4-7 / 8-11, its alpha draws) replayed on the HIP path from the product's OWN state: Adam's moments and
+    bias correction are carried by the product's optimizer, nothing is reset between steps.  Per step: alpha_org, every loss term and the walk
+    gradient against the reference's numbers (bounds of tests/test_oracle_golden.py::test_training_steps_single_attr); the walk after each step
+    (a) against the Adam restatement fed with the product's own gradient sequence (exact: pins m, v, bias correction, lr, betas), (b) against the
+    reference's walk (entries whose gradient sign is settled move identically; Adam's first steps are lr * sign(g), so an entry whose float32
+    gradient is rounding noise may step the other way: at most 2 % more of the entries per step may be further than 0.2 lr per step from it)."""
+    g = golden('step')
+    gr = selfcheck.build_graph(64, ['Smiling'], 4, lr=1e-3)
+    zs = synth.z_sample(12, seed=0)
+    own = ostep.Adam(T(synth.walk_init(1, 10, seed=7)).float(), lr=1e-3)
+    for i in range(3):
+        r = selfcheck.run_step(gr, zs[4 * i:4 * i + 4], g['single.alphas'][i])
+        torch.cuda.synchronize()
+        assert r['loss'].dtype == torch.float64
+        close(r['a0'], g['single.%d.a0' % i], 1e-3, 1e-4)
+        close(r['terms']['reg'], g['single.%d.reg' % i], 1e-3, 1e-5)
+        close(r['terms']['cont'], g['single.%d.cont' % i].mean(), 2e-3, 1e-6)
+        close(r['terms']['gan'], g['single.%d.gan' % i], 1e-3, 1e-5)
+        close(r['loss'], g['single.%d.loss' % i], 1e-3, 1e-4)
+        close(r['x1'].sum(3), g['single.%d.x1_rowsum' % i], 1e-3, 3e-3)
+        gerr = relmax(r['grad'], T(g['single.%d.grad' % i]))
+        assert gerr < 1e-2 * (i + 1), (i, gerr)                       # (steps 1, 2 start from walks that already differ in their noise entries)
+        own.step(r['grad'].detach().cpu().float())
+        moved = gr.walk.w.detach().cpu()
+        assert float((moved - own.p).abs().max()) < 2e-6, (i, float((moved - own.p).abs().max()))      # Adam state carried exactly
+        frac = float(np.mean(np.abs(moved.numpy() - g['single.%d.walk' % i]) > 2e-4 * (i + 1)))
+        assert frac < 0.02 * (i + 1), (i, frac)
+
+
 def test_training_step_multi_attr_clamp_and_regonly(golden, precision):
     g = golden('step')
     zs = synth.z_sample(12, seed=0)

@@ -1,10 +1,13 @@
 """Training-trajectory evidence for the 16-bit path (round-3 review: every bf16 test was one or two steps).  The reference trains 50 000 Adam
 steps (train.py:34-122); here the SAME z / alpha stream and walk initialisation are trained for 100 steps at 64^2 and 30 at 256^2 on the fp32
 path, on the 16-bit path and — as the yardstick — on the fp32-class split path (bf16x3: products accurate to 2^-17), and the walks must land in
-the same place: per-attribute regressor loss on a held-out batch within 1e-3 (the north star's "<= 1e-3 per-attr regressor-loss delta"), final
-walks at a cosine >= 0.99.  The DISPLACEMENT w_final - w_init is compared too: Adam divides every coordinate by its own gradient scale, so
-coordinates whose gradient is rounding noise move by +-lr per step whatever the precision — which is why even the fp32-class yardstick does not
-reach a displacement cosine of 1; the 16-bit path is held to >= 0.9 there and its number is printed beside the yardstick's.
+the same place: per-attribute regressor loss on a held-out batch within 1e-3 (the north star's "<= 1e-3 per-attr regressor-loss delta").  What is
+compared of the walks is the DISPLACEMENT w_final - w_init ([r5]: the cosine of the final walks themselves was vacuous — the walk moves by
+0.2 .. 0.7 |w0|, so two walks from the same w0 are at a cosine of ~1 whatever was trained): its cosine and its relative L2 distance between
+the fp32 and the 16-bit run, each held to the round-4 measurement plus a margin (64^2, one attribute: cosine 0.990 / L2 0.14; 64^2, five scene
+attributes: 0.972 / 0.24; 256^2: 0.944 / 0.33 — profiles/r04_trajectory.txt; bounds below).  Adam divides every coordinate by its own gradient
+scale, so coordinates whose gradient is rounding noise move by +-lr per step whatever the precision — which is why even the fp32-class yardstick
+(printed beside it) does not reach a displacement cosine of 1.
 
 Two more guards live here because they need the 16-bit step as a whole: the packed-fp32 hazard of DESIGN.md section 8 (a co-resident bf16-MFMA
 kernel corrupting `v_pk_*_f32 op_sel:[0,1]` results) is tested by REPEATING work beside conv_h8 launches and counting distinct results —
@@ -60,12 +63,12 @@ def _cos(a, b):
     return float(torch.dot(a, b) / (a.norm() * b.norm()))
 
 
-@pytest.mark.parametrize('size,batch,steps,attrs,clamp,transform', [
-    (64, 4, 100, ['Smiling'], False, 'face'),
-    (64, 4, 100, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], True, 'scene'),
-    (256, 4, 30, ['Smiling', 'Young'], False, 'face'),
+@pytest.mark.parametrize('size,batch,steps,attrs,clamp,transform,cos_min,l2_max', [
+    (64, 4, 100, ['Smiling'], False, 'face', 0.98, 0.19),
+    (64, 4, 100, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], True, 'scene', 0.96, 0.29),
+    (256, 4, 30, ['Smiling', 'Young'], False, 'face', 0.93, 0.38),
 ])
-def test_bf16_training_trajectory_lands_where_fp32_does(size, batch, steps, attrs, clamp, transform):
+def test_bf16_training_trajectory_lands_where_fp32_does(size, batch, steps, attrs, clamp, transform, cos_min, l2_max):
     from latent2im_amd import constants
     try:
         a = _train('f32', size, batch, steps, attrs, clamp, transform)
@@ -75,6 +78,7 @@ def test_bf16_training_trajectory_lands_where_fp32_does(size, batch, steps, attr
         constants.resolution, constants.BATCH_SIZE = 256, 4
     da, db, dy = a['w'] - a['w0'], b['w'] - b['w0'], y['w'] - y['w0']
     cos, cos_y, cos_w = _cos(da, db), _cos(da, dy), _cos(a['w'], b['w'])
+    rel_l2 = float((da - db).norm() / da.norm())
     moved = float(da.norm() / a['w0'].norm())
     delta = (a['per_attr'] - b['per_attr']).abs()
     print('trajectory %d^2 x%d steps %d attrs: walk moved %.2f x |w0|; bf16 vs f32: final-walk cosine %.4f, displacement cosine %.4f (fp32-class yardstick bf16x3 vs f32: '
@@ -84,8 +88,8 @@ def test_bf16_training_trajectory_lands_where_fp32_does(size, batch, steps, attr
     assert torch.equal(a['w0'], b['w0'])
     assert moved > 0.15                                   # the walk really trained (lr 1e-3: Adam moves a coordinate by at most 0.1 in 100 steps; |w0| ~ 0.02 each)
     assert float(delta.max()) < 1e-3, delta
-    assert cos_w > 0.99, cos_w
-    assert cos > 0.9, cos
+    assert cos >= cos_min, cos                            # displacement cosine (the final-walk cosine printed above carries no information)
+    assert rel_l2 <= l2_max, rel_l2
 
 
 def test_streaming_kernels_bit_stable_beside_bf16_mfma_on_another_stream():

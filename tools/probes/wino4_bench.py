@@ -1,5 +1,6 @@
-"""python tools/probes/wino4_bench.py [batch]: the 3x3 stride-1 layer shapes of the 1024^2 step on the F(2x2,3x3) and the F(4x4,3x3) kernels, interleaved
-in one process: ms per launch, TFLOP/s of the dense correlation, and the error of both against a float64 correlation (one sample)."""
+"""python tools/probes/wino4_bench.py [batch]: the 3x3 stride-1 layer shapes of the 1024^2 step on the F(2x2,3x3) kernel ('off'), the round-4 F(4x4,3x3)
+kernel ('r4') and the round-5 position-split F(4x4,3x3) kernel ('all'), interleaved in one process: ms per launch (median of five timed groups),
+TFLOP/s of the dense correlation, and the error against a float64 correlation (one sample)."""
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -22,25 +23,30 @@ for cin, cout, res, tag in SHAPES:
     y = torch.empty(B, cout, res, res, device=DEV)
     flop = 2.0 * B * cout * cin * 9 * res * res
     out = {}
-    for mode in ('off', 'all'):
+    for mode in ('off', 'r4', 'all'):
         conv.WINO4 = mode
-        for kw, nm in ((dict(), 'plain'), (dict(in_scale=s), 'scale')):
+        for kw, nm in ((dict(), 'plain'), (dict(in_scale=s), 'scale'), (dict(in_mask=x, mask=(1.0, 0.0)), 'relu')):
             for _ in range(2):
                 fc.forward(x, out=y, **kw)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n = max(3, int(20e-3 / (flop / 150e12)))
-            e0.record()
-            for _ in range(n):
-                fc.forward(x, out=y, **kw)
-            e1.record()
-            torch.cuda.synchronize()
-            out[(mode, nm)] = e0.elapsed_time(e1) / n
+            n = max(3, int(8e-3 / (flop / 150e12)))
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fc.forward(x, out=y, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / n)
+            out[(mode, nm)] = sorted(ts)[2]
         # error on sample 0 against float64 (CPU)
         ref = F.conv2d(x[:1].double().cpu(), wt.double(), padding=1)
         fc.forward(x, out=y)
         out[(mode, 'err')] = float((y[:1].double().cpu() - ref).abs().max() / ref.abs().max())
     conv.WINO4 = 'all'
-    print('%4d->%4d @%4d  %-26s F2: %.3f ms %6.1f TF (scale %.3f) err %.1e | F4: %.3f ms %6.1f TF (scale %.3f) err %.1e | x%.2f'
-          % (cin, cout, res, tag, out[('off', 'plain')], flop / out[('off', 'plain')] / 1e9, out[('off', 'scale')], out[('off', 'err')],
-             out[('all', 'plain')], flop / out[('all', 'plain')] / 1e9, out[('all', 'scale')], out[('all', 'err')], out[('off', 'plain')] / out[('all', 'plain')]), flush=True)
+    o = lambda m, k: out[(m, k)]
+    print('%4d->%4d @%4d  %-24s F2 %.3f / %.3f / %.3f ms | r4 %.3f / %.3f / %.3f | r5 %.3f / %.3f / %.3f ms (plain / scale / relu) %6.1f TF err %.1e | r5 vs r4 x%.2f x%.2f x%.2f'
+          % (cin, cout, res, tag, o('off', 'plain'), o('off', 'scale'), o('off', 'relu'), o('r4', 'plain'), o('r4', 'scale'), o('r4', 'relu'),
+             o('all', 'plain'), o('all', 'scale'), o('all', 'relu'), flop / o('all', 'plain') / 1e9, o('all', 'err'),
+             o('r4', 'plain') / o('all', 'plain'), o('r4', 'scale') / o('all', 'scale'), o('r4', 'relu') / o('all', 'relu')), flush=True)
