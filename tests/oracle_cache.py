@@ -1,0 +1,100 @@
+"""Compact, committed outputs of the CPU oracle at the BASELINE shapes (tests/golden/oracle_1024.npz).
+
+The two whole-step tests at 1024^2 batch 8 (configs 3 and 4) spent 128 s EACH of the GPU box's suite time evaluating
+``oracle.step.train_step_bounded`` on a 16-CPU pod — for fixed seeds that answer is a constant.  ``tests/golden/make_oracle_cache.py`` (build
+container only) evaluates it once and stores what the tests compare: every scalar / small tensor in full (alpha_org, epsilon, target, the loss
+terms, the per-attribute regressor predictions on the oracle's edited images, the walk gradient) and, of the two image batches (100 MB each),
+row sums, column sums and 4096 probe pixels per image and channel at fixed pseudo-random positions.  ``summarize`` is the ONE function that
+reduces an oracle result: the script uses it to write the cache and tests/test_oracle_cache_cpu.py uses it to re-derive the 256^2 entry from a live
+oracle evaluation, which keeps the cache honest (same code path, same keys)."""
+import numpy as np
+import torch
+
+NPROBE = 4096
+
+# the cached cases: name -> (size, batch, attribute names, transform, z seed, alpha [B, C], clamp flow)
+CASES = {
+    'c3': dict(size=1024, batch=8, attrs=['Smiling'], z_seed=11, alpha=lambda: np.ones((8, 1)) * 0.62, clamp=False),
+    'c4': dict(size=1024, batch=8, attrs=['Smiling', 'Young', 'Male', 'Eyeglasses', 'Bangs'], z_seed=13,
+               alpha=lambda: np.ones((8, 5)) * np.random.RandomState(14).uniform(-1, 1, 5), clamp=True),
+    # the honesty entry: small enough to be re-derived by a CPU test in seconds
+    'c256': dict(size=256, batch=4, attrs=['Smiling', 'Young'], z_seed=12, alpha=lambda: np.ones((4, 2)) * np.array([0.3, -0.4]), clamp=True),
+}
+ATTR_IDX = {'Smiling': 31, 'Young': 39, 'Male': 20, 'Eyeglasses': 15, 'Bangs': 5}
+
+
+def probe_positions(size):
+    """4096 distinct flat pixel positions of a size x size image (the same for every sample and channel)."""
+    return np.sort(np.random.RandomState(size).choice(size * size, NPROBE, replace=False))
+
+
+def image_summary(x):
+    """[B, 3, H, W] (torch, CPU or GPU) -> dict(rows [B,3,H] f64, cols [B,3,W] f64, probes [B,3,NPROBE] f32, absmax)."""
+    x = x.detach()
+    pos = torch.as_tensor(probe_positions(x.shape[-1]), device=x.device)
+    flat = x.reshape(x.shape[0], x.shape[1], -1)
+    return dict(rows=x.double().sum(3).cpu().numpy(), cols=x.double().sum(2).cpu().numpy(), probes=flat[:, :, pos].float().cpu().numpy(),
+                absmax=np.float64(float(x.abs().max())))
+
+
+def evaluate(name):
+    """Run the oracle for one cached case (minutes of CPU at 1024^2).  Returns (oracle result dict, per-attribute predictions on its x1)."""
+    from latent2im_amd import synth
+    from oracle import nets as onets
+    from oracle import step as ostep
+    c = CASES[name]
+    dt = torch.float32
+    size = c['size']
+    nets = dict(G=ostep.to_torch(synth.generator_state(size, seed=100), dt), D=ostep.to_torch(synth.discriminator_state(size, seed=200), dt),
+                R=ostep.to_torch(synth.resnet50_state(seed=300), dt), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400), dt))
+    n_latent = 2 * int(np.log2(size)) - 2
+    idx = [ATTR_IDX[a] for a in c['attrs']]
+    zs = synth.z_sample(c['batch'], seed=c['z_seed'])
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    o = ostep.train_step_bounded(nets, T(synth.walk_init(len(idx), n_latent, seed=7)), T(zs).float(), T(c['alpha']()).float(), idx, clamp_variant=c['clamp'])
+    with torch.no_grad():
+        po = torch.cat([onets.resnet50_forward(nets['R'], o['x1'][i:i + 1])[:, idx] for i in range(c['batch'])])
+    return o, po
+
+
+def summarize(o, po):
+    """Oracle result -> flat dict of numpy arrays (the cache's keys, without the case prefix)."""
+    f = lambda t: t.detach().double().cpu().numpy() if torch.is_tensor(t) else np.float64(t)
+    out = dict(alpha_org=f(o['alpha_org']), eps=f(o['eps']), target=f(o['target']), reg=f(o['reg']), cont=f(o['cont']), gan=f(o['gan']), loss=f(o['loss']),
+               grad=o['grad'].detach().float().cpu().numpy(), po=f(po))
+    if o.get('cont_terms'):
+        out['cont_terms'] = np.array([float(c) for c in o['cont_terms']])
+    for k in ('x0', 'x1'):
+        for kk, v in image_summary(o[k]).items():
+            out['%s.%s' % (k, kk)] = v
+    return out
+
+
+class Cached:
+    """One case of tests/golden/oracle_1024.npz with the accessors the step tests use."""
+
+    def __init__(self, npz, name):
+        self.d = {k[len(name) + 1:]: npz[k] for k in npz.files if k.startswith(name + '.')}
+        assert self.d, 'no cached oracle case %r' % name
+
+    def __getitem__(self, k):
+        return torch.from_numpy(np.asarray(self.d[k]))
+
+    def check_image(self, x, key, rtol=1e-3, atol=1e-4):
+        """Elementwise at the probe pixels (the bound the full-image comparison held), sums along both axes at the matching bound for a sum of W
+        entries whose errors are independent (atol * sqrt(W) * 4; a wrong halo column / row moves one whole line of the sums)."""
+        s = image_summary(x)
+        np.testing.assert_allclose(s['probes'], self.d[key + '.probes'], rtol=rtol, atol=atol)
+        w = x.shape[-1]
+        for ax in ('rows', 'cols'):
+            np.testing.assert_allclose(s[ax], self.d['%s.%s' % (key, ax)], rtol=rtol, atol=4 * atol * np.sqrt(w) + 1e-3 * rtol * w * float(self.d[key + '.absmax']))
+
+    def image_rel_to_max(self, x, key):
+        """max |x - oracle| over the probe pixels, relative to the oracle image's largest magnitude (the 16-bit contract's image bound)."""
+        s = image_summary(x)
+        return float(np.abs(s['probes'].astype(np.float64) - self.d[key + '.probes']).max() / float(self.d[key + '.absmax']))
+
+
+def load(golden_dir, name):
+    import os
+    return Cached(np.load(os.path.join(golden_dir, 'oracle_1024.npz'), allow_pickle=False), name)
