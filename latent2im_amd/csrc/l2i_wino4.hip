@@ -67,6 +67,32 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define W4_NOBAR 0
 #endif
 
+#ifdef L2I_W4_ABLATE_HOTU
+#define W4_HOTU 1
+#else
+#define W4_HOTU 0
+#endif
+#ifdef L2I_W4_ABLATE_HOTR
+#define W4_HOTR 1
+#else
+#define W4_HOTR 0
+#endif
+#ifdef L2I_W4_ABLATE_NOUDMA
+#define W4_NOUDMA 1
+#else
+#define W4_NOUDMA 0
+#endif
+#ifdef L2I_W4_ABLATE_NORDMA
+#define W4_NORDMA 1
+#else
+#define W4_NORDMA 0
+#endif
+#ifdef L2I_W4_UPF
+#define W4_UPF 1
+#else
+#define W4_UPF 0
+#endif
+
 namespace w4 {
 constexpr int BM = 16, CK = 4;
 constexpr int TW = 64, TH = 16;                         // block tile, pixels
@@ -196,7 +222,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const l2i_conv_param
 
     // DMA of one chunk = 5 statements per wave: U (3 x 16 bytes per lane; lanes 0 .. 575 of 768 carry the image, the rest — slot 2 of waves 1-3 —
     // land in the dump) and one per channel of the raw tile (5 x 4 bytes per lane; wave 3's part of the last slot is past the plane: dump).
-    // M0 is written inside the statement that uses it and not restored (hipcc keeps nothing in M0: guide section 5.7).  `on` false (no such
+    // M0 is written inside the statement that uses it and not restored (hipcc keeps nothing in M0: guide section 5.7; M0 is a RESERVED register of
+    // the target — naming it in the clobber list only earns "inline asm clobber list contains reserved registers", the allocator never uses it).  `on` false (no such
     // chunk): null descriptor = zeros, no traffic.
     auto issue_u = [&](int cu, int ust, bool on) {
         const unsigned base = lds_u + (unsigned)(ust * UST * 4) + (unsigned)wave_u * 1024u;
@@ -206,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const l2i_conv_param
                      "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %7 offen lds\n\t"
                      "s_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %8 offen lds"
                      :: "v"(wvoff), "s"((on && !W4_NODMA) ? rs_w : rs_null), "s"((on && w0 && !W4_NODMA) ? rs_w : rs_null),
-                        "s"(base), "s"(base + 4096u), "s"(w0 ? base + 8192u : lds_dump), "s"(so), "s"(so + 4096u), "s"(so + 8192u));
+                        "s"(base), "s"(base + 4096u), "s"(w0 ? base + 8192u : lds_dump), "s"(so), "s"(so + 4096u), "s"(so + 8192u) : "memory");
     };
     auto issue_raw = [&](int c, int cr, int rst, bool on) {
         const unsigned base = lds_raw + (unsigned)((rst * RAWST + c * PLANE) * 4) + (unsigned)wave_u * 256u;
@@ -219,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const l2i_conv_param
                      "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
                      "buffer_load_dword %4, %7, %8 offen lds"
                      :: "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "s"(base), "s"(wave_u < 3 ? base + 4096u : lds_dump),
-                        "s"((on && !W4_NODMA) ? rs_x : rs_null), "s"(so));
+                        "s"((on && !W4_NODMA) ? rs_x : rs_null), "s"(so) : "memory");
     };
 
     if constexpr (SCALE) {
@@ -474,6 +501,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const l2i_conv_param
     if (p.sq_ref) {                                                // (kernel argument: uniform branch) one atomic per block, 1024 slots
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+        __syncthreads();                                           // every wave is past its vmcnt(0): no target-less DMA slot can still land in the dump
         if (lane == 0) dump[wave] = sq;
         __syncthreads();
         if (tid == 0) atomicAdd(p.sq_out + (blockIdx.x & (L2I_SQ_SLOTS - 1)), (dump[0] + dump[1]) + (dump[2] + dump[3]));
@@ -575,8 +603,9 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     // past the image: null descriptor into the dump) and the wave's channel plane of the raw tile (3 x 16 bytes per lane).
     auto issue_u = [&](int cu, int ust, bool on) {
         const unsigned base = lds_u + (unsigned)(ust * UST * 4) + (unsigned)wave_u * 1024u;
-        const unsigned so = (unsigned)cu * uchunk_b + (unsigned)mblk * (unsigned)(UST * 4) + (unsigned)wave_u * 1024u;
+        const unsigned so = (unsigned)(W4_HOTU ? 0 : cu) * uchunk_b + (unsigned)mblk * (unsigned)(UST * 4) + (unsigned)wave_u * 1024u;
         const bool w01 = wave_u < 2;
+        if (W4_NOUDMA) on = false;
         asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %8 offen lds\n\t"
                      "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %9 offen lds\n\t"
                      "s_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %10 offen lds\n\t"
@@ -588,12 +617,25 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     };
     auto issue_raw = [&](int cr, int rst, bool on) {
         const unsigned base = lds_raw + (unsigned)((rst * RAWST + wave_u * PLANE) * 4);
-        const unsigned so = (unsigned)(cr * CK + wave_u) * plane_b;
+        const unsigned so = (unsigned)((W4_HOTR ? 0 : cr) * CK + wave_u) * plane_b;
+        if (W4_NORDMA) on = false;
         asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
                      "buffer_load_dwordx4 %0, %4, %5 offen lds\n\t"
                      "buffer_load_dwordx4 %1, %4, %5 offen offset:1024 lds\n\t"
                      "buffer_load_dwordx4 %2, %4, %5 offen offset:2048 lds"
                      :: "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(base), "s"((on && !W4_NODMA) ? rs_x : rs_null), "s"(so) : "memory");
+    };
+
+    // L2 prefetch of a U chunk: one dword of each of its 144 128-byte lines, DMA'd into the dump (no register target).  The weight pack of a
+    // >= 256-channel layer (9 .. 38 MB) does not live in an XCD's 4 MB L2, and a U stage has ONE chunk (~1 us) of flight: the first block of an
+    // XCD to ask for a slice would wait for HBM / the memory-side cache at every chunk.  Issued right AFTER the U DMA of a chunk, the prefetch
+    // of U(ch + 3) has until the top of chunk ch + 2 (the in-order vmcnt makes it complete before U(ch + 2)) — two chunks — and the DMA of
+    // U(ch + 3), issued at chunk ch + 2, then finds its lines in L2.
+    const unsigned pfoff = tid < NUSLOT * 8 ? (unsigned)tid * 128u : OOB;
+    auto issue_pf = [&](int cu, bool on) {
+        const unsigned so = (unsigned)cu * uchunk_b + (unsigned)mblk * (unsigned)(UST * 4);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %0, %2, %3 offen lds"
+                     :: "v"(pfoff), "s"(lds_dump + (unsigned)wave_u * 256u), "s"((on && !W4_NODMA) ? rs_w : rs_null), "s"(so) : "memory");
     };
 
     if constexpr (SCALE) {
@@ -646,7 +688,8 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     issue_raw(0, 0, true);
     issue_raw(1, 1, 1 < L.nchunks);
     issue_raw(2, 2, 2 < L.nchunks);
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NRS) : "memory");            // U(0), raw(0) landed
+    if (W4_UPF) { issue_pf(1, 1 < L.nchunks); issue_pf(2, 2 < L.nchunks); }
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NRS + 2 * W4_UPF) : "memory");   // U(0), raw(0) landed
     __syncthreads();                                                          // (also: the style-scale table)
     {
         const f32x2 sc = scale_of(0);
@@ -689,7 +732,7 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
                 for (int g = 0; g < BMG; ++g) { a4[g] = ua[g * (UG / 4) + (i + 1) * 64]; a2[g] = ub[g * (UG / 2) + (i + 1) * 64]; }
             }
             load_pair(P, pa, i);                                               // the next chunk's patch, one column pair per position row
-            if (i == 0) issue_u(ch + 1, ustw, on_u);
+            if (i == 0) { issue_u(ch + 1, ustw, on_u); if (W4_UPF) issue_pf(ch + 3, ch + 3 < L.nchunks); }
             else if (i == 1) issue_raw(ch + RS, rstw, on_r);
 #if W4_NOXF
             const f32x2 v05 = T[i][0], v12 = T[i][1], v34 = T[i][2];
@@ -726,7 +769,7 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
         }
     };
     auto top = [&]() {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRS) : "memory");            // U(ch) and raw(ch + 1) landed; raw(ch + 2) stays in flight
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRS + W4_UPF) : "memory");   // U(ch) and raw(ch + 1) landed; raw(ch + 2) (and the prefetch) stay in flight
         __syncthreads();
     };
     auto nxt = [](int v, int m) { return v + 1 == m ? 0 : v + 1; };

@@ -7,7 +7,7 @@ for shape in "512 512 64 8" "64 64 1024 8" "128 128 256 8"; do
   echo "== $shape"
   for kind in plain relu_in; do
     python $R/tools/probes/one_wino4.py $shape $MODE $kind 30
-    for lib in $R/tools/ab/libl2i_w4_no_*.so; do
+    for lib in $R/tools/ab/libl2i_w4_*.so; do
       L2I_LIB=$lib python $R/tools/probes/one_wino4.py $shape $MODE $kind 30
     done
   done
