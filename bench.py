@@ -104,6 +104,17 @@ def source_hash():
     return _lib.source_hash()
 
 
+def committed_build():
+    """latent2im_amd/csrc/BUILD_HASHES.json (tools/update_build_hash.py): the library sha256 the committed sources build to (reproducible build),
+    and whether the library this run loaded is that build."""
+    from latent2im_amd import _lib
+    rec = _lib.committed_build()
+    if rec is None:
+        return None
+    return dict(library_sha256_16=rec['library_sha256'][:16], kernel_sources_sha256_16=rec['kernel_sources_sha256_16'],
+                sources_match=rec['sources_match'], library_match=rec['library_match'])
+
+
 def _drm_card_of(index):
     """/sys/class/drm/cardN/device of HIP device `index`, matched by PCI address (a box can expose dozens of cards: card0 is NOT device 0)."""
     import glob
@@ -276,7 +287,7 @@ def roofline_block(prof, steps, tag, workload_key, t_events):
                               algorithmic_tflops=round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
                               executed_tflops=round(exe_flop / (tot_ms * 1e-3) / 1e12, 2),
                               executed_frac_of_fastest_instruction_peak=round(exe_flop / (tot_ms * 1e-3) / 1e12 / peak_all, 4)),
-                ms_per_step_with_events=round(t_events, 2), library_sha256_16=lib_hash(), kernel_sources_sha256_16=src,
+                ms_per_step_with_events=round(t_events, 2), library_sha256_16=lib_hash(), kernel_sources_sha256_16=src, committed_build=committed_build(),
                 note='dominant kernel family = most GPU time per step; bound = the roof it is closer to (hbm: algorithmic bytes of its launches '
                      '/ their HIP-event time against 8 TB/s).  mfma: achieved / frac = FLOPs the matrix cores EXECUTE in that family '
                      '(Winograd F(2x2,3x3): 16/36, F(4x4,3x3): 36/144 of the dense correlation; 3-term bf16 split: 3 products per fp32 product) '

@@ -112,6 +112,29 @@ EXPORTS = tuple(_SIGNATURES)
 _lib = None
 
 
+BUILD_HASHES = os.path.join(_HERE, 'csrc', 'BUILD_HASHES.json')      # tools/update_build_hash.py: library sha256 of the committed sources
+
+
+def committed_build():
+    """What tools/update_build_hash.py recorded for the committed kernel sources, and whether the library that would be loaded IS that build:
+    dict(kernel_sources_sha256_16, library_sha256, hipcc, sources_match, library_match).  The build is reproducible (csrc/Makefile), so
+    library_match = False with sources_match = True means a different compiler or a hand-built library."""
+    import hashlib
+    import json
+    try:
+        with open(BUILD_HASHES) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    rec['sources_match'] = rec.get('kernel_sources_sha256_16') == source_hash()
+    try:
+        with open(LIB_PATH, 'rb') as f:
+            rec['library_match'] = hashlib.sha256(f.read()).hexdigest() == rec.get('library_sha256')
+    except OSError:
+        rec['library_match'] = False
+    return rec
+
+
 def source_hash():
     """sha256[:16] over the kernel SOURCES (csrc/*.hip, *.h, Makefile, include/l2i.h; names + contents, sorted).  The PMC traffic summaries
     under profiles/ are keyed to this and not to the .so file: a rebuild of the same sources in another directory hashes the binary
@@ -119,7 +142,7 @@ def source_hash():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, 'csrc')
-    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.h')) or f == 'Makefile')
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.h')) or f == 'Makefile')      # (not BUILD_HASHES.json)
     files.append(os.path.join(os.path.dirname(_HERE), 'include', 'l2i.h'))
     for f in files:
         h.update(os.path.basename(f).encode())
