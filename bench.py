@@ -241,7 +241,7 @@ def family_table(prof, steps):
     return rows
 
 
-def roofline_block(prof, steps, tag, workload_key, t_events):
+def roofline_block(prof, steps, tag, workload_key, t_events, ev_steps=None):
     """`roofline` object from the per-launch event pass (`prof`): dominant conv family, the roof it is nearer to, every family, the PMC
     traffic figure of profiles/ when it was taken on these kernel sources and this workload."""
     from latent2im_amd import conv
@@ -253,7 +253,7 @@ def roofline_block(prof, steps, tag, workload_key, t_events):
     peak_all = max(f['peak_tflops'] for f in fams)
     traffic, traffic_note = None, 'no PMC summary under profiles/ for these kernel sources and this workload'
     src = source_hash()
-    for rnd in ('r04', 'r03'):
+    for rnd in ('r05', 'r04', 'r03'):
         tp = os.path.join(ROOT, 'profiles', '%s_%s_hbm_traffic.json' % (rnd, tag))
         if not os.path.isfile(tp):
             continue
@@ -287,7 +287,7 @@ def roofline_block(prof, steps, tag, workload_key, t_events):
                               algorithmic_tflops=round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
                               executed_tflops=round(exe_flop / (tot_ms * 1e-3) / 1e12, 2),
                               executed_frac_of_fastest_instruction_peak=round(exe_flop / (tot_ms * 1e-3) / 1e12 / peak_all, 4)),
-                ms_per_step_with_events=round(t_events, 2), library_sha256_16=lib_hash(), kernel_sources_sha256_16=src, committed_build=committed_build(),
+                ms_per_step_with_events=round(t_events, 2), event_pass_step_ms=ev_steps, library_sha256_16=lib_hash(), kernel_sources_sha256_16=src, committed_build=committed_build(),
                 note='dominant kernel family = most GPU time per step; bound = the roof it is closer to (hbm: algorithmic bytes of its launches '
                      '/ their HIP-event time against 8 TB/s).  mfma: achieved / frac = FLOPs the matrix cores EXECUTE in that family '
                      '(Winograd F(2x2,3x3): 16/36, F(4x4,3x3): 36/144 of the dense correlation; 3-term bf16 split: 3 products per fp32 product) '
@@ -388,19 +388,27 @@ def warm_up(one_step, count, seconds, dev=None):
 
 def event_pass(wl, one_step, first, steps):
     """The same steps again, eager on ONE stream, with a HIP event pair around every conv launch on the launch stream (kept out of the timed
-    region: ~280 pairs per step cost ~7 % wall on their own, and concurrent streams make per-kernel durations overlap)."""
+    region: ~280 pairs per step cost ~7 % wall on their own, and concurrent streams make per-kernel durations overlap).
+    [r5] One UNTIMED step goes first and its entries are dropped: the pass creates ~550 events per step, and the first step pays for their
+    creation (hipEventCreate through torch's event pool, empty until then) — round 4's driver record showed `ms_per_step_with_events` at 205-216 ms
+    in some runs and 116 in others with identical per-kernel times; the per-step wall times (`event_pass_step_ms`, one synchronisation per step)
+    now say where such a stall sits.  Returns (per-launch entries of the `steps` counted steps, mean wall ms per counted step, [wall ms per step
+    INCLUDING the dropped first one])."""
     from latent2im_amd import constants, conv
     concurrent, constants.CONCURRENT_LOSS_BRANCHES = constants.CONCURRENT_LOSS_BRANCHES, False
-    conv.PROFILE = []
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(steps):
-        one_step(first + i)
-    torch.cuda.synchronize()
-    t_events = (time.perf_counter() - t1) / steps * 1e3
-    prof, conv.PROFILE = conv.PROFILE, None
+    per_step, prof = [], []
+    for i in range(steps + 1):
+        conv.PROFILE = []
+        t1 = time.perf_counter()
+        one_step(first + (i - 1 if i else 0))
+        torch.cuda.synchronize()
+        per_step.append(round((time.perf_counter() - t1) * 1e3, 2))
+        if i:
+            prof += conv.PROFILE
+    conv.PROFILE = None
     constants.CONCURRENT_LOSS_BRANCHES = concurrent
-    return prof, t_events
+    return prof, sum(per_step[1:]) / steps, per_step
 
 
 def quick_rate(one_step, steps, global_b, dev, max_ahead):
@@ -533,9 +541,10 @@ def main():
                  alloc_retries=int(mem1['num_alloc_retries'] - mem0['num_alloc_retries']))
 
     # ---- roofline of the conv kernels (every rank repeats the steps: the walk-gradient all-reduce is inside a step; rank 0 reports)
-    prof, t_events = None, None
+    prof, t_events, ev_steps = None, None, None
+    n_ev = min(a.event_steps, a.steps)
     if not a.no_kernel_events:
-        prof, t_events = event_pass(wl, wl.stepper(reg_only=a.reg_only, graph=False), a.warmup, min(a.event_steps, a.steps))
+        prof, t_events, ev_steps = event_pass(wl, wl.stepper(reg_only=a.reg_only, graph=False), a.warmup, n_ev)
     dist.barrier()
 
     # ---- reg-only loss (train.py:174-176 --no_content_loss --no_gan_loss) on the same graph
@@ -543,6 +552,9 @@ def main():
     if not a.no_reg_only and not a.reg_only:
         reg = {precision: dict(quick_rate(wl.stepper(reg_only=True), 5, global_b, dev, a.max_ahead),
                                workload=wl.describe(True, a.noise_strength, use_graph))}
+        if not a.no_kernel_events:                           # [r5] the reg-only loss is the configuration SURVEY 8(d) calls jointly reachable: its own roofline
+            prof_r, t_ev_r, ev_r = event_pass(wl, wl.stepper(reg_only=True, graph=False), 0, n_ev)
+            reg[precision]['roofline'] = roofline_block(prof_r, n_ev, 'c3_reg', wl.key(True), t_ev_r, ev_r) if rk == 0 else None
 
     # ---- batch sweep (the BASELINE metric is quoted over a batch sweep): the same eager step at other per-GPU batches, every rank
     sweep = None
@@ -585,13 +597,16 @@ def main():
         el5 = dist.max_over_ranks(el5, dev)
         roof5 = None
         if not a.no_kernel_events:
-            prof5, t_ev5 = event_pass(w5, w5.stepper(graph=False), 2, min(a.event_steps, a.config5_steps))
-            roof5 = roofline_block(prof5, min(a.event_steps, a.config5_steps), 'c5', w5.key(), t_ev5) if rk == 0 else None
+            prof5, t_ev5, ev5 = event_pass(w5, w5.stepper(graph=False), 2, min(a.event_steps, a.config5_steps))
+            roof5 = roofline_block(prof5, min(a.event_steps, a.config5_steps), 'c5', w5.key(), t_ev5, ev5) if rk == 0 else None
         cfg5 = dict(value=round(global_b * a.config5_steps / el5, 3), unit='images/s', ms_per_step=round(el5 / a.config5_steps * 1e3, 2),
                     steps=a.config5_steps, warmup_steps_run=warm5, dtype='bf16', baseline_config='configs[4] per-GPU shape',
                     workload=w5.describe(False, a.noise_strength, True), loss=float(r5['loss']), roofline=roof5, **step_stats(ms5))
         if reg is not None:
             reg['bf16'] = dict(quick_rate(w5.stepper(reg_only=True), 5, global_b, dev, a.max_ahead), workload=w5.describe(True, a.noise_strength, True))
+            if not a.no_kernel_events:
+                prof_r, t_ev_r, ev_r = event_pass(w5, w5.stepper(reg_only=True, graph=False), 0, n_ev)
+                reg['bf16']['roofline'] = roofline_block(prof_r, n_ev, 'c5_reg', w5.key(True), t_ev_r, ev_r) if rk == 0 else None
         w5.release()
         conv.PRECISION = precision
     else:
@@ -611,13 +626,12 @@ def main():
             e = agg.setdefault((q[5],) + tuple(q[3]), [0, 0.0, q[2], call_bytes(q)])
             e[0] += 1
             e[1] += q[0].elapsed_time(q[1])
-        n_ev = min(a.event_steps, a.steps)
         rows = [dict(family=k[0], shape=list(k[1:]), launches_per_step=v[0] / n_ev, ms_per_launch=round(v[1] / v[0], 4), ms_per_step=round(v[1] / n_ev, 3),
                      tflops=round(v[2] / (v[1] / v[0] * 1e-3) / 1e12, 1), GBs=round(v[3] / (v[1] / v[0] * 1e-3) / 1e9, 1)) for k, v in agg.items()]
         rows.sort(key=lambda r: -r['ms_per_step'])
         json.dump(rows, open(a.dump_launches, 'w'), indent=0)
     if prof:
-        roof = roofline_block(prof, min(a.event_steps, a.steps), 'c5' if c5 else 'c3', wkey3, t_events)
+        roof = roofline_block(prof, n_ev, 'c5' if c5 else 'c3', wkey3, t_events, ev_steps)
     out = dict(metric='edited images/sec', value=round(value, 3), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(ms_per_step, 2), higher_is_better=True, scaling='weak', vs_baseline=None, dtype=precision,
                data='synthetic',

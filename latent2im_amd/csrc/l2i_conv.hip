@@ -884,6 +884,7 @@ extern "C" int l2i_conv2d_f32(const l2i_conv_params* pp, void* stream) {
     if (family == L2I_FAMILY_DIRECT_SMALL) return launch_direct_small(p, (hipStream_t)stream);
     if (family == L2I_FAMILY_GEMM1X1) return l2i_launch_gemm1x1(p, (hipStream_t)stream);
     if (family == L2I_FAMILY_CIN3) return l2i_launch_cin3(p, (hipStream_t)stream);
+    if (p.tile_hint == 0 && l2i_conv3x3s2_eligible(p)) return l2i_launch_conv3x3s2(p, (hipStream_t)stream);      // [r5] same family, DMA-staged operands
 
     // ---- tile selection: minimise a simple time model  waves(grid / resident blocks) x cycles per block  ----
     //      cycles per block = MFMA issue (64 cycles each) + per-chunk barrier/commit cost + epilogue stores (hidden by co-resident blocks);

@@ -14,6 +14,8 @@ bool l2i_cin3_eligible(const l2i_conv_params& p);                 // l2i_cin3.hi
 int l2i_launch_cin3(const l2i_conv_params& p, hipStream_t st);
 bool l2i_convt_small_eligible(const l2i_conv_params& p);          // l2i_convt_small.hip: 7x7 / pad 3 stride-2 transposed conv onto <= 3 channels
 int l2i_launch_convt_small(const l2i_conv_params& p, hipStream_t st);
+bool l2i_conv3x3s2_eligible(const l2i_conv_params& p);            // l2i_conv_s2.hip: unmasked 3x3 stride-2 layers on maps >= 32 wide, both operands by LDS-DMA
+int l2i_launch_conv3x3s2(const l2i_conv_params& p, hipStream_t st);
 int l2i_launch_splitk_epilogue(const l2i_conv_params& q, hipStream_t st);     // l2i_conv.hip: y = epilogue(sum of q.ksplit partials in q.ws)
 
 #define L2I_CHECK_LAUNCH()                                                      \

@@ -24,11 +24,10 @@ if __name__ == '__main__':
     data = dict(np.load(path, allow_pickle=False)) if os.path.isfile(path) else {}
     for name in (sys.argv[1:] or list(oracle_cache.CASES)):
         t0 = time.time()
-        o, po = oracle_cache.evaluate(name)
+        summ = oracle_cache.evaluate_and_summarize(name)
         data = {k: v for k, v in data.items() if not k.startswith(name + '.')}
-        for k, v in oracle_cache.summarize(o, po).items():
+        for k, v in summ.items():
             data['%s.%s' % (name, k)] = v
-        del o, po
         print('%s: %.0f s' % (name, time.time() - t0), flush=True)
         np.savez_compressed(path, **data)
     print('%s: %d arrays, %.2f MB' % (path, len(data), os.path.getsize(path) / 1e6))

@@ -12,13 +12,24 @@ import torch
 
 NPROBE = 4096
 
-# the cached cases: name -> (size, batch, attribute names, transform, z seed, alpha [B, C], clamp flow)
+# the cached cases: name -> size, batch, attribute names (CelebA table) or indices (scene table), z seed, alpha [B, C], clamp flow;
+# `bounded`: oracle.step.train_step_bounded (the 1024^2 evaluations) or the plain train_step; `f64`: the case stores the FLOAT64 evaluation and,
+# beside it, the float32 evaluation's walk gradient (`grad32`: "how far the oracle's own float32 run is from the exact value" is the yardstick of
+# the walk-gradient tests)
+SCENE5 = ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk']
 CASES = {
-    'c3': dict(size=1024, batch=8, attrs=['Smiling'], z_seed=11, alpha=lambda: np.ones((8, 1)) * 0.62, clamp=False),
+    'c3': dict(size=1024, batch=8, attrs=['Smiling'], z_seed=11, alpha=lambda: np.ones((8, 1)) * 0.62, clamp=False, bounded=True, f64=False),
     'c4': dict(size=1024, batch=8, attrs=['Smiling', 'Young', 'Male', 'Eyeglasses', 'Bangs'], z_seed=13,
-               alpha=lambda: np.ones((8, 5)) * np.random.RandomState(14).uniform(-1, 1, 5), clamp=True),
+               alpha=lambda: np.ones((8, 5)) * np.random.RandomState(14).uniform(-1, 1, 5), clamp=True, bounded=True, f64=False),
     # the honesty entry: small enough to be re-derived by a CPU test in seconds
-    'c256': dict(size=256, batch=4, attrs=['Smiling', 'Young'], z_seed=12, alpha=lambda: np.ones((4, 2)) * np.array([0.3, -0.4]), clamp=True),
+    'c256': dict(size=256, batch=4, attrs=['Smiling', 'Young'], z_seed=12, alpha=lambda: np.ones((4, 2)) * np.array([0.3, -0.4]), clamp=True, bounded=True, f64=False),
+    # [r5, second batch] the other oracle evaluations the GPU suite used to repeat on every run
+    'c2': dict(size=256, batch=16, attrs=['Smiling'], z_seed=5, alpha=lambda: np.ones((16, 1)) * np.random.RandomState(8).uniform(0, 1, 1), clamp=False,
+               bounded=False, f64=False),
+    'g256': dict(size=256, batch=4, attrs=['Smiling'], z_seed=6, alpha=lambda: np.ones((4, 1)) * 0.37, clamp=False, bounded=False, f64=True),
+    'g1024': dict(size=1024, batch=1, attrs=['Smiling'], z_seed=12, alpha=lambda: np.ones((1, 1)) * 0.41, clamp=False, bounded=True, f64=True),
+    'c5': dict(size=1024, batch=1, attrs=SCENE5, scene=True, z_seed=15, alpha=lambda: np.ones((1, 5)) * np.random.RandomState(16).uniform(-1, 1, 5), clamp=True,
+               bounded=True, f64=True),
 }
 ATTR_IDX = {'Smiling': 31, 'Young': 39, 'Male': 20, 'Eyeglasses': 15, 'Bangs': 5}
 
@@ -37,31 +48,43 @@ def image_summary(x):
                 absmax=np.float64(float(x.abs().max())))
 
 
-def evaluate(name):
-    """Run the oracle for one cached case (minutes of CPU at 1024^2).  Returns (oracle result dict, per-attribute predictions on its x1)."""
+def evaluate(name, dt=None):
+    """Run the oracle for one cached case (minutes of CPU at 1024^2) in float32, or in `dt`.  Returns (oracle result dict, per-attribute
+    predictions of the oracle's regressor on its x1)."""
     from latent2im_amd import synth
     from oracle import nets as onets
     from oracle import step as ostep
     c = CASES[name]
-    dt = torch.float32
+    dt = dt or torch.float32
     size = c['size']
     nets = dict(G=ostep.to_torch(synth.generator_state(size, seed=100), dt), D=ostep.to_torch(synth.discriminator_state(size, seed=200), dt),
                 R=ostep.to_torch(synth.resnet50_state(seed=300), dt), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400), dt))
     n_latent = 2 * int(np.log2(size)) - 2
-    idx = [ATTR_IDX[a] for a in c['attrs']]
+    idx = list(range(len(c['attrs']))) if c.get('scene') else [ATTR_IDX[a] for a in c['attrs']]      # (dataset/attributes_scene.txt: the first five rows)
     zs = synth.z_sample(c['batch'], seed=c['z_seed'])
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-    o = ostep.train_step_bounded(nets, T(synth.walk_init(len(idx), n_latent, seed=7)), T(zs).float(), T(c['alpha']()).float(), idx, clamp_variant=c['clamp'])
+    fn = ostep.train_step_bounded if c['bounded'] else ostep.train_step
+    o = fn(nets, T(synth.walk_init(len(idx), n_latent, seed=7)).to(dt), T(zs).to(dt), T(c['alpha']()).to(dt), idx, clamp_variant=c['clamp'])
     with torch.no_grad():
-        po = torch.cat([onets.resnet50_forward(nets['R'], o['x1'][i:i + 1])[:, idx] for i in range(c['batch'])])
+        po = torch.cat([onets.resnet50_forward(nets['R'], o['x1'][i:i + 1].detach())[:, idx] for i in range(c['batch'])])
     return o, po
+
+
+def evaluate_and_summarize(name):
+    """What tests/golden/make_oracle_cache.py stores for a case: the float32 summary, or (f64 cases) the float64 summary plus `grad32`."""
+    if not CASES[name]['f64']:
+        return summarize(*evaluate(name))
+    out = summarize(*evaluate(name, torch.float64))
+    o32, _ = evaluate(name, torch.float32)
+    out['grad32'] = o32['grad'].detach().float().cpu().numpy()
+    return out
 
 
 def summarize(o, po):
     """Oracle result -> flat dict of numpy arrays (the cache's keys, without the case prefix)."""
     f = lambda t: t.detach().double().cpu().numpy() if torch.is_tensor(t) else np.float64(t)
     out = dict(alpha_org=f(o['alpha_org']), eps=f(o['eps']), target=f(o['target']), reg=f(o['reg']), cont=f(o['cont']), gan=f(o['gan']), loss=f(o['loss']),
-               grad=o['grad'].detach().float().cpu().numpy(), po=f(po))
+               grad=o['grad'].detach().cpu().numpy(), po=f(po))
     if o.get('cont_terms'):
         out['cont_terms'] = np.array([float(c) for c in o['cont_terms']])
     for k in ('x0', 'x1'):

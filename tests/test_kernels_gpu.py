@@ -84,6 +84,43 @@ def test_conv_forward_dgrad_vs_torch(case, hint, wino4_off):
     close(gx, gref, 1e-4, 2e-5)
 
 
+@pytest.mark.parametrize('cin,cout,pad,h,w,b', [(16, 24, 1, 64, 64, 2), (32, 64, 0, 132, 132, 1), (8, 40, 0, 69, 133, 2), (64, 96, 1, 72, 200, 1),
+                                               (256, 128, 1, 16, 64, 2), (32, 64, 0, 67, 1028, 1), (12, 70, 0, 19, 65, 3)])
+def test_conv3x3_stride2_dma_kernel(cin, cout, pad, h, w, b):
+    """[r5] conv3x3s2_dma_kernel (l2i_conv_s2.hip: 3x3 stride-2 layers with both operands staged by LDS-DMA, odd plane pitch, three-stage ring) against
+    a float64 correlation with every fusion it serves on the path — style scale in / demodulation out / noise / bias / leaky ReLU (the gradient of a
+    generator up layer and the discriminator's strided convs), residual + masks + accumulate — on pad 0 and pad 1, odd input pitches (pad 0 only),
+    widths that leave partial tiles and windows that run past the right image edge, channel counts that leave half-filled channel blocks, long K
+    loops; and against the generic kernel on the same launch (forced through tile_hint), which must agree to fp32 rounding."""
+    rs = np.random.RandomState(cin + cout + h + w)
+    wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    x, s, d = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cin) + 0.5), T(rs.rand(b, cout) + 0.5)
+    oh, ow = (h + 2 * pad - 3) // 2 + 1, (w + 2 * pad - 3) // 2 + 1
+    assert ow >= 32
+    bias, res, rmk, omk, prev = T(rs.randn(cout)), *(T(rs.randn(b, cout, oh, ow)) for _ in range(4))
+    nz = T(rs.randn(b, 1, oh, ow))
+    g = lambda t: t.to(DEV)
+    D = lambda t: t.double()
+    fc = conv.FrozenConv2d(wt, 2, pad, device=DEV)
+    c64 = lambda xx: F.conv2d(xx, D(wt), stride=2, padding=pad)
+    ref1 = F.leaky_relu(c64(D(x) * D(s)[:, :, None, None]) * D(d)[:, :, None, None] + D(nz) * 0.3 + D(bias)[None, :, None, None], 0.2) * 2 ** 0.5
+    ref2 = torch.relu(c64(D(x)) + D(bias)[None, :, None, None] + torch.where(rmk > 0, D(res), torch.zeros_like(D(res))))
+    ref3 = torch.where(omk > 0, c64(D(x)), torch.zeros_like(D(res))) * 0.5 + D(prev)
+    for hint in (0, 2):                                   # 0: the dispatch (DMA kernel); 2: the generic kernel's (2, 2) tile
+        launched = conv.PROFILE = []
+        try:
+            y1 = fc.forward(g(x), in_scale=g(s), out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5, tile_hint=hint)
+            y2 = fc.forward(g(x), bias=g(bias), residual=g(res), res_mask=g(rmk), act=conv.ACT_RELU, tile_hint=hint)
+            y3 = g(prev).clone()
+            fc.forward(g(x), out=y3, out_mask=g(omk), out_gain=0.5, accumulate=True, tile_hint=hint)
+        finally:
+            conv.PROFILE = None
+        assert all(q[5] == 'implicit_gemm_f32' for q in launched)
+        for got, want in ((y1, ref1), (y2, ref2), (y3, ref3)):
+            err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+            assert err < 5e-6, (hint, err)
+
+
 def test_conv_prologue_epilogue_fusions():
     rs = np.random.RandomState(5)
     wt = T(rs.randn(48, 40, 3, 3) / 19.0)

@@ -279,8 +279,11 @@ def test_full_size_training_step_vs_oracle(size, batch, attrs, clamp):
     clamp flow; one sample, which is what the CPU oracle finishes in under a minute): a whole training step — both generator
     passes, regressor, VGG content, discriminator, backward into the walk — against the float32 CPU oracle on the same z/seed.
     Images, alpha_org and every loss term within rtol 1e-3 / atol 1e-4 (the per-attribute regressor loss included); the walk
-    gradient like tests/test_oracle_golden.py: relative to its largest entry."""
+    gradient like tests/test_oracle_golden.py: relative to its largest entry.  [r5] The batch-16 oracle evaluation (56 s on the GPU box) is read
+    from tests/golden/oracle_1024.npz (case 'c2'; tests/oracle_cache.py); the one-sample 1024^2 case stays a live evaluation."""
     from latent2im_amd import constants
+    from tests import oracle_cache
+    from tests.conftest import GOLDEN
     try:
         gr = selfcheck.build_graph(size, attrs, batch, lr=1e-3)
         zs = synth.z_sample(batch, seed=5)
@@ -288,22 +291,30 @@ def test_full_size_training_step_vs_oracle(size, batch, attrs, clamp):
         alpha = np.ones((batch, len(attrs))) * (rs.uniform(-1, 1, len(attrs)) if clamp else rs.uniform(0, 1, len(attrs)))
         r = selfcheck.run_step(gr, zs, alpha, clamp=clamp, optimize=False)
         torch.cuda.synchronize()
-        nets = dict(G=ostep.to_torch(synth.generator_state(size, seed=100)), D=ostep.to_torch(synth.discriminator_state(size, seed=200)),
-                    R=ostep.to_torch(synth.resnet50_state(seed=300)), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400)))
         idx = gr.attrIdx
-        o = ostep.train_step(nets, T(synth.walk_init(len(attrs), gr.module.netG.n_latent, seed=7)), T(zs).float(), T(alpha).float(), idx,
-                             clamp_variant=clamp)
-        close(r['x0'], o['x0'])
+        if size == 256:
+            case = oracle_cache.CASES['c2']
+            assert (case['batch'], case['attrs'], case['z_seed'], case['clamp']) == (batch, attrs, 5, clamp) and np.array_equal(case['alpha'](), alpha)
+            o = oracle_cache.load(GOLDEN, 'c2')
+            o.check_image(r['x0'], 'x0')
+            o.check_image(r['x1'], 'x1')
+            po = o['po'].double()
+        else:
+            nets = dict(G=ostep.to_torch(synth.generator_state(size, seed=100)), D=ostep.to_torch(synth.discriminator_state(size, seed=200)),
+                        R=ostep.to_torch(synth.resnet50_state(seed=300)), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400)))
+            o = ostep.train_step(nets, T(synth.walk_init(len(attrs), gr.module.netG.n_latent, seed=7)), T(zs).float(), T(alpha).float(), idx,
+                                 clamp_variant=clamp)
+            close(r['x0'], o['x0'])
+            close(r['x1'], o['x1'])
+            po = onets.resnet50_forward(nets['R'], o['x1'])[:, idx].double()
         close(r['a0'], o['alpha_org'])
         close(r['eps'], o['eps'])
-        close(r['x1'], o['x1'])
         close(r['terms']['reg'], o['reg'], 1e-3, 1e-5)
         close(r['terms']['cont'], o['cont'], 1e-3, 1e-6)
         close(r['terms']['gan'], o['gan'], 1e-3, 1e-5)
         close(r['loss'], o['loss'], 1e-3, 1e-4)
         # per-attribute regressor loss (the "<= 1e-3 per-attr regressor-loss delta" of the north star)
         pg = gr.regressor(r['x1'])[:, idx].double().cpu()
-        po = onets.resnet50_forward(nets['R'], o['x1'])[:, idx].double()
         tgt = o['target'].double()
         per_attr = lambda p: -(tgt * p.clamp(min=1e-12).log() + (1 - tgt) * (1 - p).clamp(min=1e-12).log()).mean(0)
         close(per_attr(pg), per_attr(po), 1e-3, 1e-5)
@@ -442,7 +453,7 @@ def test_config5_step_1024_bf16x3_hipgraph_vs_oracle():
     """BASELINE config 5 at its own shape: SceneGraph on the transient-scene table, five attributes, train_multi_attr.py clamp flow
     (train_multi_attr.py:71-154), every eligible contraction on the split-precision bf16 matrix path (conv.PRECISION = 'bf16x3'), forward +
     backward REPLAYED from one hipGraph (capture.CapturedStep) at 1024^2 — one sample against the oracle in FLOAT64 (bounded-memory
-    evaluation): images, epsilon and every loss term within rtol 1e-3 / atol 1e-4, the walk gradient no further from the exact value than
+    evaluation, cached): images, epsilon and every loss term within rtol 1e-3 / atol 1e-4, the walk gradient no further from the exact value than
     twice the oracle's own float32 run (or 5e-3 of the largest entry) — the bar of test_walk_gradient_1024_vs_float64_oracle.  Then the
     per-GPU batch of the config: one replay at batch 8 equals the same step launched eagerly."""
     from latent2im_amd import capture, constants, conv
@@ -458,23 +469,21 @@ def test_config5_step_1024_bf16x3_hipgraph_vs_oracle():
         step = capture.CapturedStep(gr, 1, 5, clamp=True)
         r = step(zs, alpha, optimize=False)
         torch.cuda.synchronize()
-        errs, o64 = {}, None
-        for dt in (torch.float64, torch.float32):
-            o = ostep.train_step_bounded(_oracle_nets(size, dt), T(synth.walk_init(5, gr.module.netG.n_latent, seed=7)).to(dt), T(zs).to(dt),
-                                         T(alpha).to(dt), [0, 1, 2, 3, 4], clamp_variant=True)
-            if dt == torch.float64:
-                o64 = o
-                errs['hip'] = relmax(r['grad'], o64['grad'])
-                close(r['x0'], o64['x0'])
-                close(r['x1'], o64['x1'])
-                close(r['a0'], o64['alpha_org'])
-                close(r['eps'], o64['eps'])
-                close(r['loss'], o64['loss'], 1e-3, 1e-4)
-                close(r['terms']['reg'], o64['reg'], 1e-3, 1e-5)
-                close(r['terms']['cont'], o64['cont'], 1e-3, 1e-6)
-                close(r['terms']['gan'], o64['gan'], 1e-3, 1e-5)
-            else:
-                errs['oracle32'] = relmax(o['grad'], o64['grad'])
+        # [r5] the float64 oracle evaluation of this sample and the float32 run's gradient: tests/golden/oracle_1024.npz, case 'c5'
+        from tests import oracle_cache
+        from tests.conftest import GOLDEN
+        case = oracle_cache.CASES['c5']
+        assert case['z_seed'] == 15 and np.array_equal(case['alpha'](), alpha) and case['attrs'] == attrs
+        o64 = oracle_cache.load(GOLDEN, 'c5')
+        errs = dict(hip=relmax(r['grad'], o64['grad']), oracle32=relmax(o64['grad32'], o64['grad']))
+        o64.check_image(r['x0'], 'x0')
+        o64.check_image(r['x1'], 'x1')
+        close(r['a0'], o64['alpha_org'])
+        close(r['eps'], o64['eps'])
+        close(r['loss'], o64['loss'], 1e-3, 1e-4)
+        close(r['terms']['reg'], o64['reg'], 1e-3, 1e-5)
+        close(r['terms']['cont'], o64['cont'], 1e-3, 1e-6)
+        close(r['terms']['gan'], o64['gan'], 1e-3, 1e-5)
         print('config 5 (1024^2, bf16x3, hipGraph replay) walk gradient vs float64 oracle, relative to the largest entry:', errs)
         assert errs['hip'] < max(2 * errs['oracle32'], 5e-3), errs
         del step, gr
@@ -508,30 +517,24 @@ def test_config5_step_1024_bf16x3_hipgraph_vs_oracle():
 def test_walk_gradient_1024_vs_float64_oracle():
     """The walk gradient of a full-loss step at 1024^2 (one sample) against the oracle evaluated in FLOAT64 — the same bar as
     test_walk_gradient_256_vs_float64_oracle at the bench resolution: no further from the exact value than twice the oracle's own
-    float32 run, or 5e-3 of the largest entry."""
+    float32 run, or 5e-3 of the largest entry.  [r5] Oracle values from tests/golden/oracle_1024.npz (case 'g1024')."""
     from latent2im_amd import constants
+    from tests import oracle_cache
+    from tests.conftest import GOLDEN
     try:
-        size, batch = 1024, 1
-        gr = selfcheck.build_graph(size, ['Smiling'], batch, lr=1e-3)
-        zs = synth.z_sample(batch, seed=12)
-        alpha = np.ones((batch, 1)) * 0.41
-        r = selfcheck.run_step(gr, zs, alpha, optimize=False)
+        case = oracle_cache.CASES['g1024']
+        size, batch = case['size'], case['batch']
+        gr = selfcheck.build_graph(size, case['attrs'], batch, lr=1e-3)
+        zs = synth.z_sample(batch, seed=case['z_seed'])
+        r = selfcheck.run_step(gr, zs, case['alpha'](), optimize=False)
         torch.cuda.synchronize()
-        errs = {}
-        o64 = None
-        for dt in (torch.float64, torch.float32):
-            o = ostep.train_step_bounded(_oracle_nets(size, dt), T(synth.walk_init(1, gr.module.netG.n_latent, seed=7)).to(dt), T(zs).to(dt),
-                                         T(alpha).to(dt), gr.attrIdx)
-            if dt == torch.float64:
-                o64 = o
-                errs['hip'] = relmax(r['grad'], o64['grad'])
-                close(r['x1'], o64['x1'])
-                close(r['loss'], o64['loss'], 1e-3, 1e-4)
-                close(r['terms']['reg'], o64['reg'], 1e-3, 1e-5)
-                close(r['terms']['cont'], o64['cont'], 1e-3, 1e-6)
-                close(r['terms']['gan'], o64['gan'], 1e-3, 1e-5)
-            else:
-                errs['oracle32'] = relmax(o['grad'], o64['grad'])
+        o64 = oracle_cache.load(GOLDEN, 'g1024')
+        errs = dict(hip=relmax(r['grad'], o64['grad']), oracle32=relmax(o64['grad32'], o64['grad']))
+        o64.check_image(r['x1'], 'x1')
+        close(r['loss'], o64['loss'], 1e-3, 1e-4)
+        close(r['terms']['reg'], o64['reg'], 1e-3, 1e-5)
+        close(r['terms']['cont'], o64['cont'], 1e-3, 1e-6)
+        close(r['terms']['gan'], o64['gan'], 1e-3, 1e-5)
         print('1024^2 walk gradient vs float64 oracle, relative to the largest entry:', errs)
         assert errs['hip'] < max(2 * errs['oracle32'], 5e-3), errs
     finally:
@@ -541,27 +544,22 @@ def test_walk_gradient_1024_vs_float64_oracle():
 def test_walk_gradient_256_vs_float64_oracle():
     """Walk gradient of a full-loss step at 256^2 (batch 4) against the oracle evaluated in float64 — the value the arithmetic
     has without rounding.  The HIP path must be no further from it than twice the oracle's own float32 run (or 5e-3 of the
-    largest entry, whichever is larger): the same bar as the 64^2 fixture test, at a BASELINE resolution."""
+    largest entry, whichever is larger): the same bar as the 64^2 fixture test, at a BASELINE resolution.  [r5] Both oracle evaluations are
+    constants of the seeds: read from tests/golden/oracle_1024.npz (case 'g256': the float64 result and the float32 run's gradient)."""
     from latent2im_amd import constants
+    from tests import oracle_cache
+    from tests.conftest import GOLDEN
     try:
-        size, batch, attrs = 256, 4, ['Smiling']
+        case = oracle_cache.CASES['g256']
+        size, batch, attrs = case['size'], case['batch'], case['attrs']
         gr = selfcheck.build_graph(size, attrs, batch, lr=1e-3)
-        zs = synth.z_sample(batch, seed=6)
-        alpha = np.ones((batch, 1)) * 0.37
-        r = selfcheck.run_step(gr, zs, alpha, optimize=False)
+        zs = synth.z_sample(batch, seed=case['z_seed'])
+        r = selfcheck.run_step(gr, zs, case['alpha'](), optimize=False)
         torch.cuda.synchronize()
-        errs = {}
-        for dt in (torch.float64, torch.float32):
-            nets = dict(G=ostep.to_torch(synth.generator_state(size, seed=100), dt), D=ostep.to_torch(synth.discriminator_state(size, seed=200), dt),
-                        R=ostep.to_torch(synth.resnet50_state(seed=300), dt), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400), dt))
-            o = ostep.train_step(nets, T(synth.walk_init(1, gr.module.netG.n_latent, seed=7)).to(dt), T(zs).to(dt), T(alpha).to(dt), gr.attrIdx)
-            if dt == torch.float64:
-                o64 = o
-                errs['hip'] = relmax(r['grad'], o64['grad'])
-                close(r['loss'], o64['loss'], 1e-3, 1e-4)
-                close(r['terms']['reg'], o64['reg'], 1e-3, 1e-5)
-            else:
-                errs['oracle32'] = relmax(o['grad'], o64['grad'])
+        o64 = oracle_cache.load(GOLDEN, 'g256')
+        errs = dict(hip=relmax(r['grad'], o64['grad']), oracle32=relmax(o64['grad32'], o64['grad']))
+        close(r['loss'], o64['loss'], 1e-3, 1e-4)
+        close(r['terms']['reg'], o64['reg'], 1e-3, 1e-5)
         print('walk gradient vs float64 oracle, relative to the largest entry:', errs)
         assert errs['hip'] < max(2 * errs['oracle32'], 5e-3), errs
     finally:
