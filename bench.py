@@ -463,7 +463,7 @@ def main():
     ap.add_argument('--cpu_baseline_s', type=float, default=12.0, help='CPU-oracle time budget (0 = skip)')
     ap.add_argument('--no_kernel_events', action='store_true', help='do not bracket conv launches with events')
     ap.add_argument('--event_steps', type=int, default=5, help='steps of the per-launch event pass (roofline)')
-    ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
+    ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16', 'f16'],
                     help="f32: exact fp32 MFMA, fp32 storage (c3 default); bf16: the 16-bit path — bf16 h8 storage, one bf16 MFMA per MAC, fp32 accumulation (c5 "
                          "default); bf16x3: fp32 storage, 3-term bf16 split on the matrix cores (fp32-class results)")
     ap.add_argument('--hip_graph', type=int, default=None, help='1: replay forward+backward from one hipGraph (c5 default), 0: eager launches')

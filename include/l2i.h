@@ -189,6 +189,29 @@ int l2i_add_zero_insert_h8(void* y, const void* c, const void* mask, int64_t pla
 int l2i_mask_mul_h8(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream);                     /* y = g * (ref > 0 ? pos : neg) */
 int l2i_modulate_planes_h8(void* planes, const float* w32, const float* s, int B, int Cs, int CinP, int KK, int CoutP, void* stream);
 
+/* [r5] The same sixteen entry points with IEEE fp16 (binary16) elements instead of bf16 — BASELINE configs[4] names "fp16 MFMA"; what the reference
+ * would run under autocast on networks.py:231-272.  Identical signatures, layouts and fusions; the contraction is v_mfma_f32_32x32x16_f16 (same rate
+ * as the bf16 instruction), conversions round to nearest even.  fp16 has 3 more mantissa bits than bf16 and 3 fewer exponent bits: the caller keeps
+ * gradients inside its range with power-of-two loss scales (latent2im_amd/nets16.py: one per loss branch, undone on the fp32 side: exact). */
+int l2i_conv2d_h8_f16(const l2i_conv_params* p, void* stream);
+int l2i_conv_transpose2d_h8_f16(const l2i_conv_params* p, void* stream);
+int l2i_cast_f32_to_h8_f16(void* y, const float* x, int B, int C, int Cpad, int64_t HW, void* stream);
+int l2i_cast_h8_to_f32_f16(float* y, const void* x, int B, int C, int Cpad, int64_t HW, void* stream);
+int l2i_upfirdn2d_h8_f16(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
+                         int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
+                         float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, void* stream);
+int l2i_torgb_fwd_h8_f16(float* rgb, const void* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream);
+int l2i_sg2_act_bwd_h8_f16(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
+                           const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream);
+int l2i_dot_reduce_h8_f16(float* out, const void* a, const void* b, int B, int C, int64_t HW, void* stream);
+int l2i_maxpool2d_fwd_h8_f16(void* y, void* idx, const void* x, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, int relu, void* stream);
+int l2i_maxpool2d_bwd_h8_f16(void* gx, const void* gy, const void* idx, const void* a, const void* b, float coef, const float* coef_dev, int64_t planes, int H, int W,
+                             int k, int s, int pad, int OH, int OW, void* stream);
+int l2i_sqdiff_h8_f16(float* sum_out, void* grad, const void* a, const void* b, int64_t slots, float coef, const float* coef_dev, void* stream);
+int l2i_add_zero_insert_h8_f16(void* y, const void* c, const void* mask, int64_t planes, int H, int W, int OH, int OW, void* stream);
+int l2i_mask_mul_h8_f16(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream);
+int l2i_modulate_planes_h8_f16(void* planes, const float* w32, const float* s, int B, int Cs, int CinP, int KK, int CoutP, void* stream);
+
 /* out[i] = act_grad_table(x[i] + b[(i / step_b) % size_b], ref[i]) * scale   — the reference op, all six
  * act*10+grad cases (fused_bias_act_kernel.cu:36-47).  b / ref may be NULL (= the reference's empty tensors). */
 int l2i_fused_bias_act_f32(float* y, const float* x, const float* b, const float* ref, int64_t n,
@@ -316,8 +339,8 @@ int l2i_segmented_matvec_f32(float* out, const float* in, const float* in2, cons
 
 const char* l2i_last_error(void);
 /* Bumped whenever a struct of this header grows or an entry point changes meaning (1: round 1-2; 2: round 3, l2i_conv_params gained w_bstride /
- * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
-#define L2I_ABI_VERSION 3
+ * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
+#define L2I_ABI_VERSION 4
 int l2i_abi_version(void);
 int l2i_sizeof_conv_params(void);       /* sizeof(struct l2i_conv_params) of THIS build */
 

@@ -105,7 +105,11 @@ _SIGNATURES = {
     'l2i_sizeof_conv_params': (c_i, []),
 }
 
-ABI_VERSION = 3          # L2I_ABI_VERSION of include/l2i.h this binding mirrors
+# [r5] every h8 entry point exists twice: bf16 elements (the name as is) and IEEE fp16 elements (suffix _f16), same signatures
+for _n in [k for k in _SIGNATURES if k.endswith('_h8') or k in ('l2i_cast_f32_to_h8', 'l2i_cast_h8_to_f32')]:
+    _SIGNATURES[_n + '_f16'] = _SIGNATURES[_n]
+
+ABI_VERSION = 4          # L2I_ABI_VERSION of include/l2i.h this binding mirrors
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -16,7 +16,15 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvParams  # noqa: F401
 
 import os as _os
 
-PRECISION = _os.environ.get('L2I_PRECISION', 'f32')      # 'bf16x3': eligible stride-1 layers take the split-precision bf16 MFMA kernel (opt-in)
+PRECISION = _os.environ.get('L2I_PRECISION', 'f32')      # 'bf16x3': eligible stride-1 layers take the split-precision bf16 MFMA kernel (opt-in);
+                                                          # 'bf16' / 'f16': the 16-bit path (nets16.py) with bf16 / IEEE fp16 h8 feature maps
+H8_PRECISIONS = ('bf16', 'f16')
+
+
+def h8_dtype():
+    """Element type of the 16-bit path's h8 tensors under the current PRECISION ([r5]: 'f16' = IEEE fp16, everything else bf16)."""
+    return torch.float16 if PRECISION == 'f16' else torch.bfloat16
+
 USE_WINOGRAD = _os.environ.get('L2I_WINOGRAD', '1') != '0'    # 3x3 stride-1 layers on maps >= 32 wide take the F(2x2,3x3) fp32 kernel
 # [r4] Winograd F(4x4,3x3) (csrc/l2i_wino4.hip: 1.78x fewer MFMAs than F(2x2), error ~1e-6..1e-5 of max|y| instead of 3e-7) for the unmasked 3x3
 # stride-1 launches on maps >= 64 wide: 'all' = every eligible launch on the [r5] position-split kernel, 'r4' = the same launches on the round-4
@@ -536,14 +544,15 @@ class FrozenConv2d:
 # ------------------------------------------------------------------------------------------------------------------------------------
 # The 16-bit path (BASELINE config 5): bf16 tensors in the channel-blocked "h8" layout [B, C/8, H, W, 8] (include/l2i.h: l2i_conv2d_h8)
 # ------------------------------------------------------------------------------------------------------------------------------------
-def to_h8(x, pad_to=8):
-    """fp32 / bf16 NCHW -> bf16 h8 [B, C/8, H, W, 8] (channels zero-padded to a multiple of ``pad_to``).  A torch reshuffle: used at the few
-    fp32 boundaries of the 16-bit path and by the tests, not inside the conv stack (the kernels read and write h8 directly)."""
+def to_h8(x, pad_to=8, dtype=None):
+    """fp32 / 16-bit NCHW -> 16-bit h8 [B, C/8, H, W, 8] (channels zero-padded to a multiple of ``pad_to``) in the path's element type (or ``dtype``).
+    A torch reshuffle: used at the few fp32 boundaries of the 16-bit path and by the tests, not inside the conv stack (the kernels read and write
+    h8 directly)."""
     B, C, H, W = x.shape
     cp = (C + pad_to - 1) // pad_to * pad_to
     if cp != C:
         x = torch.cat([x, x.new_zeros(B, cp - C, H, W)], 1)
-    return x.reshape(B, cp // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().to(torch.bfloat16)
+    return x.reshape(B, cp // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().to(dtype or h8_dtype())
 
 
 def from_h8(t, channels=None):
@@ -564,15 +573,20 @@ def pack_weight_h8_f32(w):
     return full.reshape(coutp, cinp // 16, 2, 8, kh * kw).permute(1, 4, 2, 0, 3).contiguous()
 
 
-def pack_weight_h8(w, cin_pad=32):
-    """[Cout, Cin, KH, KW] fp32 -> bf16 plane [Cin/16][KH*KW][2][CoutP][8] (int16 view): the LDS image order of csrc/l2i_conv_h8.hip.
-    Cin is zero-padded to a multiple of ``cin_pad`` (32: the kernel's K chunk; 16 is enough for 3x3 stride-1 layers)."""
+def pack_weight_h8(w, cin_pad=32, dtype=None):
+    """[Cout, Cin, KH, KW] fp32 -> 16-bit plane [Cin/16][KH*KW][2][CoutP][8] (int16 view) in the path's element type (or ``dtype``): the LDS image
+    order of csrc/l2i_conv_h8.hip.  Cin is zero-padded to a multiple of ``cin_pad`` (32: the kernel's K chunk; 16 is enough for 3x3 stride-1 layers)."""
     w = torch.as_tensor(w, dtype=torch.float32)
     cout, cin, kh, kw = w.shape
     cinp = (cin + cin_pad - 1) // cin_pad * cin_pad
     if cinp != cin:
         w = torch.cat([w, w.new_zeros(cout, cinp - cin, kh, kw)], 1)
-    return pack_weight_bf16x3(w)[0]
+    if (dtype or h8_dtype()) == torch.bfloat16:
+        return pack_weight_bf16x3(w)[0]
+    coutp = (cout + 31) // 32 * 32
+    full = torch.zeros(coutp, cinp, kh, kw, dtype=torch.float32, device=w.device)
+    full[:cout] = w
+    return full.to(torch.float16).reshape(coutp, cinp // 16, 2, 8, kh * kw).permute(1, 4, 2, 0, 3).contiguous().view(torch.int16)
 
 
 class H8Conv:
@@ -586,6 +600,7 @@ class H8Conv:
         self.stride, self.padding, self.transposed, self.device = stride, padding, transposed, device
         assert cin_pad == 32 or (cin_pad == 16 and self.k == 3 and stride == 1 and not transposed), 'a 16-channel chunk exists for 3x3 stride-1 layers only'
         self.cinp, self.coutp_in = (self.cin + cin_pad - 1) // cin_pad * cin_pad, (self.cout + 31) // 32 * 32
+        self.dtype = h8_dtype()                                       # element type of the weight planes: the maps it is called with must have it
         wt = w.transpose(0, 1).contiguous()
         self.fwd_planes = pack_weight_h8(w, cin_pad).to(device)
         if transposed or stride == 2:
@@ -605,7 +620,7 @@ class H8Conv:
         out_f32 = kw.get('out_f32', False)
         if out is None:
             out = (torch.empty(B, self.cout, oh, ow, device=x.device, dtype=torch.float32) if out_f32
-                   else torch.empty(B, (self.cout + 7) // 8, oh, ow, 8, device=x.device, dtype=torch.bfloat16))
+                   else torch.empty(B, (self.cout + 7) // 8, oh, ow, 8, device=x.device, dtype=x.dtype))
         return run_h8(planes if planes is not None else self.fwd_planes, x, out, self.cinp, self.cout, self.k, 2 if self.transposed else self.stride, self.padding,
                       transposed=self.transposed, w_bstride=w_bstride, **kw)
 
@@ -615,7 +630,7 @@ class H8Conv:
         out_f32 = kw.get('out_f32', False)
         if out is None:
             out = (torch.empty(B, self.cin, in_hw[0], in_hw[1], device=gy.device, dtype=torch.float32) if out_f32
-                   else torch.empty(B, (self.cin + 7) // 8, in_hw[0], in_hw[1], 8, device=gy.device, dtype=torch.bfloat16))
+                   else torch.empty(B, (self.cin + 7) // 8, in_hw[0], in_hw[1], 8, device=gy.device, dtype=gy.dtype))
         pl = planes if planes is not None else self.bwd_planes
         if self.transposed:                                   # dx[ci, i] = sum gy[co, 2i + k - pad] w[co, ci, k]: a stride-2 correlation
             return run_h8(pl, gy, out, self.coutp_in, self.cin, self.k, 2, self.padding, transposed=False, w_bstride=w_bstride, **kw)
@@ -629,7 +644,7 @@ def _h8_dgrad_compact(self, gy, planes=None, **kw):
     compact (output-resolution) map; the caller scatters it into every second pixel (kernels16.add_zero_insert)."""
     assert self.k == 1 and self.stride == 2 and not self.transposed
     B, _, oh, ow, _ = gy.shape
-    out = torch.empty(B, (self.cin + 7) // 8, oh, ow, 8, device=gy.device, dtype=torch.bfloat16)
+    out = torch.empty(B, (self.cin + 7) // 8, oh, ow, 8, device=gy.device, dtype=gy.dtype)
     return run_h8(planes if planes is not None else self.bwd_planes, gy, out, self.coutp_in, self.cin, 1, 1, 0, **kw)
 
 
@@ -642,14 +657,15 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
     """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels."""
     lib = _lib.load()
     B, cg, H, W, _ = x.shape
-    assert x.dtype == torch.bfloat16 and cg * 8 == cin and cin % 16 == 0, (x.shape, cin)
+    assert x.dtype in (torch.bfloat16, torch.float16) and cg * 8 == cin and cin % 16 == 0, (x.dtype, x.shape, cin)
+    f16 = x.dtype == torch.float16
     coutp = planes.shape[-2]
     assert planes.shape[-5] == cin // 16 and planes.shape[-4] == k * k and coutp >= cout, (planes.shape, cin, k, cout)
     if out_f32:
         assert y.dtype == torch.float32 and y.shape[1] == cout
         OHf, OWf = y.shape[2], y.shape[3]
     else:
-        assert y.dtype == torch.bfloat16 and y.shape[1] * 8 >= cout and cout % 8 == 0, (y.shape, cout)
+        assert y.dtype == x.dtype and y.shape[1] * 8 >= cout and cout % 8 == 0, (y.dtype, y.shape, cout)
         OHf, OWf = y.shape[2], y.shape[3]
     p = ConvParams()
     p.x, p.w_hi, p.y = _lib.ptr(x), _lib.ptr(planes), _lib.ptr(y)
@@ -680,7 +696,8 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
         assert sq[0].shape == y.shape and sq[0].dtype == y.dtype and sq[1].numel() == _lib.SQ_SLOTS
         p.sq_ref, p.sq_out = _lib.ptr(sq[0]), _lib.fptr(sq[1])
         sq[2][0] = True
-    entry, name = (lib.l2i_conv_transpose2d_h8, 'l2i_conv_transpose2d_h8') if transposed else (lib.l2i_conv2d_h8, 'l2i_conv2d_h8')
+    name = ('l2i_conv_transpose2d_h8' if transposed else 'l2i_conv2d_h8') + ('_f16' if f16 else '')
+    entry = getattr(lib, name)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -29,9 +29,28 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
+
+// [r5] The file is compiled twice (csrc/Makefile): as is = bf16 elements (l2i_conv2d_h8, l2i_conv_transpose2d_h8), and with -DL2I_H8_F16 = IEEE
+// fp16 elements (the same entry points with the suffix _f16: BASELINE configs[4] says "fp16 MFMA").  The h8 layout, the DMA pipeline and the
+// epilogues are element-type agnostic; what differs is the MFMA instruction (v_mfma_f32_32x32x16_{bf16,f16}: same rate), the two unpack
+// converts and the packing convert (v_cvt_pk_{bf16,f16}_f32: one instruction per pair, round to nearest even, both).  ReLU-on-load stays the
+// packed integer max: a negative fp16 is a negative int16 as well.  Everything lives in a per-type namespace: two objects with the same
+// template kernels would otherwise be merged by the linker.
+#ifdef L2I_H8_F16
+#define H8_NS l2i_h8_f16
+#define H8_NAME(n) n##_f16
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));          // (the fragment type keeps its name: "bf16x8" = eight 16-bit elements)
+#define H8_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
+#define H8_NS l2i_h8_bf16
+#define H8_NAME(n) n
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define H8_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
+
+namespace H8_NS {
 
 namespace g8 {
 template <int WN, int K, int S, int TR, int KS_ = 2> struct Geo {
@@ -60,6 +79,15 @@ struct H8Launch {
     int lean_epi;                      // h8 output without per-pixel operand maps (no out_mask / residual / accumulate / sq_ref): the lean epilogue
 };
 
+#ifdef L2I_H8_F16
+__device__ __forceinline__ unsigned cvt_pk_bf16_h8(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { float r; asm("v_cvt_f32_f16 %0, %1" : "=v"(r) : "v"(u)); return r; }
+__device__ __forceinline__ float bf16_hi(unsigned u) { float r; asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(u)); return r; }
+#else
 __device__ __forceinline__ unsigned cvt_pk_bf16_h8(float lo, float hi) {
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
@@ -67,6 +95,7 @@ __device__ __forceinline__ unsigned cvt_pk_bf16_h8(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+#endif
 
 // ---- epilogue, h8 output ----------------------------------------------------------------------------------------------------------
 // acc[m][n][r]: channel m0 + 32 m + (r & 3) + 8 (r >> 2) + 4 half, pixel (oy0 + wave WN + n, ox0 + j).  Register quad q = r >> 2 of a lane
@@ -352,7 +381,7 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
 #ifdef L2I_H8_ABLATE_MFMA                                  // timing ablation (tools/probes/h8_ablate.sh): fragments are read, no matrix work
                         acc[TR ? py * 2 + ((kx + PADT) & 1) : 0][m][n][0] += __builtin_bit_cast(f32x4_, af[m])[0] * __builtin_bit_cast(f32x4_, bf[n])[0];
 #else
-                        acc[TR ? py * 2 + ((kx + PADT) & 1) : 0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bf[n], acc[TR ? py * 2 + ((kx + PADT) & 1) : 0][m][n], 0, 0, 0);
+                        acc[TR ? py * 2 + ((kx + PADT) & 1) : 0][m][n] = H8_MFMA(af[m], bf[n], acc[TR ? py * 2 + ((kx + PADT) & 1) : 0][m][n], 0, 0, 0);
 #endif
             }
         }
@@ -579,7 +608,7 @@ static int h8_common_checks(const l2i_conv_params& p, const char* who) {
     return L2I_OK;
 }
 
-extern "C" int l2i_conv2d_h8(const l2i_conv_params* pp, void* stream) {
+extern "C" int H8_NAME(l2i_conv2d_h8)(const l2i_conv_params* pp, void* stream) {
     if (!pp) return l2i_set_error(L2I_E_ARG, "conv2d_h8: null params");
     const l2i_conv_params& p = *pp;
     if (int rc = h8_common_checks(p, "conv2d_h8")) return rc;
@@ -623,7 +652,7 @@ extern "C" int l2i_conv2d_h8(const l2i_conv_params* pp, void* stream) {
     return wide ? launch_h8<2, 2, 1, 2, 0, false>(p, st) : launch_h8<1, 2, 1, 2, 0, false>(p, st);
 }
 
-extern "C" int l2i_conv_transpose2d_h8(const l2i_conv_params* pp, void* stream) {
+extern "C" int H8_NAME(l2i_conv_transpose2d_h8)(const l2i_conv_params* pp, void* stream) {
     if (!pp) return l2i_set_error(L2I_E_ARG, "conv_transpose2d_h8: null params");
     const l2i_conv_params& p = *pp;
     if (int rc = h8_common_checks(p, "conv_transpose2d_h8")) return rc;
@@ -637,3 +666,4 @@ extern "C" int l2i_conv_transpose2d_h8(const l2i_conv_params* pp, void* stream) 
     if (p.pad_x == 0) return wide ? launch_h8<2, 1, 3, 1, 1, false>(p, st) : launch_h8<1, 2, 3, 1, 1, false>(p, st);
     return wide ? launch_h8<2, 1, 3, 1, 2, false>(p, st) : launch_h8<1, 2, 3, 1, 2, false>(p, st);
 }
+}  // namespace H8_NS

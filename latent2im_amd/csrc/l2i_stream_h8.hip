@@ -13,15 +13,35 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// [r5] Compiled twice like l2i_conv_h8.hip: bf16 elements as is, IEEE fp16 elements with -DL2I_H8_F16 (entry points with the suffix _f16).
+// Only the three converts below know the element type.
+#ifdef L2I_H8_F16
+#define H8_NS l2i_h8s_f16
+#define H8_NAME(n) n##_f16
+#else
+#define H8_NS l2i_h8s_bf16
+#define H8_NAME(n) n
+#endif
+
+namespace H8_NS {
 namespace {
+#ifdef L2I_H8_F16
+__device__ __forceinline__ float blo(unsigned u) { float r; asm("v_cvt_f32_f16 %0, %1" : "=v"(r) : "v"(u)); return r; }
+__device__ __forceinline__ float bhi(unsigned u) { float r; asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(u)); return r; }
+#else
 __device__ __forceinline__ float blo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+#endif
 __device__ __forceinline__ void unpack8(const u32x4& u, float (&v)[8]) {
     v[0] = blo(u.x); v[1] = bhi(u.x); v[2] = blo(u.y); v[3] = bhi(u.y); v[4] = blo(u.z); v[5] = bhi(u.z); v[6] = blo(u.w); v[7] = bhi(u.w);
 }
 __device__ __forceinline__ unsigned pk(float lo, float hi) {
     unsigned r;
+#ifdef L2I_H8_F16
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+#else
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+#endif
     return r;
 }
 __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) { return u32x4{pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7])}; }
@@ -58,14 +78,14 @@ __global__ __launch_bounds__(256) void cast_h8_to_f32_kernel(float* __restrict__
             if (8 * g + e < C) y[(b * C + 8 * g + e) * HW + pix] = v[e];
     }
 }
-extern "C" int l2i_cast_f32_to_h8(void* y, const float* x, int B, int C, int Cpad, int64_t HW, void* stream) {
+extern "C" int H8_NAME(l2i_cast_f32_to_h8)(void* y, const float* x, int B, int C, int Cpad, int64_t HW, void* stream) {
     if (!y || !x || B <= 0 || C <= 0 || Cpad < C || (Cpad % 8) != 0 || HW <= 0) return l2i_set_error(L2I_E_ARG, "cast_f32_to_h8: bad arguments");
     const long long total = (long long)B * (Cpad / 8) * HW;
     hipLaunchKernelGGL(cast_f32_to_h8_kernel, dim3(l2i_grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, x, C, Cpad / 8, (long long)HW, total);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }
-extern "C" int l2i_cast_h8_to_f32(float* y, const void* x, int B, int C, int Cpad, int64_t HW, void* stream) {
+extern "C" int H8_NAME(l2i_cast_h8_to_f32)(float* y, const void* x, int B, int C, int Cpad, int64_t HW, void* stream) {
     if (!y || !x || B <= 0 || C <= 0 || Cpad < C || (Cpad % 8) != 0 || HW <= 0) return l2i_set_error(L2I_E_ARG, "cast_h8_to_f32: bad arguments");
     const long long total = (long long)B * (Cpad / 8) * HW;
     hipLaunchKernelGGL(cast_h8_to_f32_kernel, dim3(l2i_grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, y, (const u32x4*)x, C, Cpad / 8, (long long)HW, total);
@@ -395,7 +415,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_h8_sep4_up2_kernel(u32x4* __res
     }
 }
 
-extern "C" int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
+extern "C" int H8_NAME(l2i_upfirdn2d_h8)(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
                                 int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
                                 float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, void* stream) {
     if (!y || !x || !k) return l2i_set_error(L2I_E_ARG, "upfirdn2d_h8: null tensor");
@@ -485,7 +505,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_h8_kernel(float* __restrict__ r
         rgb[((size_t)b * 3 + 0) * HW + pix] = a0; rgb[((size_t)b * 3 + 1) * HW + pix] = a1; rgb[((size_t)b * 3 + 2) * HW + pix] = a2;
     }
 }
-extern "C" int l2i_torgb_fwd_h8(float* rgb, const void* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream) {
+extern "C" int H8_NAME(l2i_torgb_fwd_h8)(float* rgb, const void* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream) {
     if (!rgb || !x || !wmod || !bias || B <= 0 || C <= 0 || (C % 8) != 0 || C > 4096 || HW <= 0) return l2i_set_error(L2I_E_ARG, "torgb_fwd_h8: bad arguments");
     int bps = (int)((HW + 255) / 256);
     if (bps > 512) bps = 512;
@@ -595,7 +615,7 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_h8_kernel(u32x4* __restrict__
         atomicAdd(red_x_grgb + ((size_t)b * C + 8 * g) * 3 + (i - 8), part[0][i] + part[1][i] + part[2][i] + part[3][i]);
     }
 }
-extern "C" int l2i_sg2_act_bwd_h8(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
+extern "C" int H8_NAME(l2i_sg2_act_bwd_h8)(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
                                   const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream) {
     if (!dz || !y || !red_dz_z || B <= 0 || C <= 0 || (C % 8) != 0 || HW <= 0) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd_h8: bad arguments");
     if ((grgb != nullptr) != (wmod_rgb != nullptr)) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd_h8: grgb and wmod_rgb go together");
@@ -647,7 +667,7 @@ __global__ __launch_bounds__(256) void dot_reduce_h8_kernel(float* __restrict__ 
     __syncthreads();
     if (threadIdx.x < 8) atomicAdd(out + (size_t)b * C + 8 * g + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
-extern "C" int l2i_dot_reduce_h8(float* out, const void* a, const void* b, int B, int C, int64_t HW, void* stream) {
+extern "C" int H8_NAME(l2i_dot_reduce_h8)(float* out, const void* a, const void* b, int B, int C, int64_t HW, void* stream) {
     if (!out || !a || B <= 0 || C <= 0 || (C % 8) != 0 || HW <= 0) return l2i_set_error(L2I_E_ARG, "dot_reduce_h8: bad arguments");
     const int strips = h8_strips(B * (C / 8), HW);
     hipLaunchKernelGGL(dot_reduce_h8_kernel, dim3((unsigned)(B * (C / 8) * strips)), dim3(256), 0, (hipStream_t)stream, out, (const u32x4*)a, (const u32x4*)b, C, (long long)HW, strips);
@@ -736,14 +756,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_h8_kernel(u32x4* __restrict__
         gx[i] = pack8(acc);
     }
 }
-extern "C" int l2i_maxpool2d_fwd_h8(void* y, void* idx, const void* x, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, int relu, void* stream) {
+extern "C" int H8_NAME(l2i_maxpool2d_fwd_h8)(void* y, void* idx, const void* x, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, int relu, void* stream) {
     if (!y || !idx || !x || planes <= 0 || H <= 0 || W <= 0 || k <= 0 || k > 15 || s <= 0 || OH <= 0 || OW <= 0) return l2i_set_error(L2I_E_ARG, "maxpool_fwd_h8: bad arguments");
     hipLaunchKernelGGL(maxpool_fwd_h8_kernel, dim3(l2i_grid_for((long long)planes * OH * OW, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (uint2*)idx, (const u32x4*)x,
                        (long long)planes, H, W, k, s, pad, OH, OW, relu);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }
-extern "C" int l2i_maxpool2d_bwd_h8(void* gx, const void* gy, const void* idx, const void* a, const void* b, float coef, const float* coef_dev, int64_t planes, int H, int W,
+extern "C" int H8_NAME(l2i_maxpool2d_bwd_h8)(void* gx, const void* gy, const void* idx, const void* a, const void* b, float coef, const float* coef_dev, int64_t planes, int H, int W,
                                     int k, int s, int pad, int OH, int OW, void* stream) {
     if (!gx || !gy || !idx || planes <= 0 || H <= 0 || W <= 0 || k <= 0 || k > 15 || s <= 0 || OH <= 0 || OW <= 0) return l2i_set_error(L2I_E_ARG, "maxpool_bwd_h8: bad arguments");
     if ((a != nullptr) != (b != nullptr)) return l2i_set_error(L2I_E_ARG, "maxpool_bwd_h8: a and b go together");
@@ -774,7 +794,7 @@ __global__ __launch_bounds__(256) void sqdiff_h8_kernel(float* __restrict__ sum_
         if (threadIdx.x == 0) atomicAdd(sum_out, (red[0] + red[1]) + (red[2] + red[3]));
     }
 }
-extern "C" int l2i_sqdiff_h8(float* sum_out, void* grad, const void* a, const void* b, int64_t slots, float coef, const float* coef_dev, void* stream) {
+extern "C" int H8_NAME(l2i_sqdiff_h8)(float* sum_out, void* grad, const void* a, const void* b, int64_t slots, float coef, const float* coef_dev, void* stream) {
     if (!a || !b || slots <= 0) return l2i_set_error(L2I_E_ARG, "sqdiff_h8: bad arguments");
     hipLaunchKernelGGL(sqdiff_h8_kernel, dim3(l2i_grid_for(slots, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, sum_out, (u32x4*)grad, (const u32x4*)a, (const u32x4*)b,
                        (long long)slots, coef, coef_dev);
@@ -806,7 +826,7 @@ __global__ __launch_bounds__(256) void add_zero_insert_h8_kernel(u32x4* __restri
         y[o] = pack8(a);
     }
 }
-extern "C" int l2i_add_zero_insert_h8(void* y, const void* c, const void* mask, int64_t planes, int H, int W, int OH, int OW, void* stream) {
+extern "C" int H8_NAME(l2i_add_zero_insert_h8)(void* y, const void* c, const void* mask, int64_t planes, int H, int W, int OH, int OW, void* stream) {
     if (!y || !c || planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return l2i_set_error(L2I_E_ARG, "add_zero_insert_h8: bad arguments");
     hipLaunchKernelGGL(add_zero_insert_h8_kernel, dim3(l2i_grid_for((long long)planes * OH * OW, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)c,
                        (const u32x4*)mask, (long long)planes, H, W, OH, OW);
@@ -830,7 +850,7 @@ __global__ __launch_bounds__(256) void modulate_planes_kernel(u32x4* __restrict_
         planes[i] = pack8(v);
     }
 }
-extern "C" int l2i_modulate_planes_h8(void* planes, const float* w32, const float* s, int B, int Cs, int CinP, int KK, int CoutP, void* stream) {
+extern "C" int H8_NAME(l2i_modulate_planes_h8)(void* planes, const float* w32, const float* s, int B, int Cs, int CinP, int KK, int CoutP, void* stream) {
     if (!planes || !w32 || !s || B <= 0 || CinP <= 0 || (CinP % 16) != 0 || Cs > CinP || KK <= 0 || CoutP <= 0) return l2i_set_error(L2I_E_ARG, "modulate_planes_h8: bad arguments");
     if (Cs != CinP) return l2i_set_error(L2I_E_ARG, "modulate_planes_h8: the scale vector must cover the padded channel count");
     const long long sps = (long long)(CinP / 16) * KK * 2 * CoutP, total = sps * B;
@@ -851,9 +871,10 @@ __global__ __launch_bounds__(256) void mask_mul_h8_kernel(u32x4* __restrict__ y,
         y[i] = pack8(a);
     }
 }
-extern "C" int l2i_mask_mul_h8(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream) {
+extern "C" int H8_NAME(l2i_mask_mul_h8)(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream) {
     if (!y || !g || !ref || slots <= 0) return l2i_set_error(L2I_E_ARG, "mask_mul_h8: bad arguments");
     hipLaunchKernelGGL(mask_mul_h8_kernel, dim3(l2i_grid_for(slots, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)g, (const u32x4*)ref, pos, neg, (long long)slots);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }
+}  // namespace H8_NS

@@ -173,9 +173,12 @@ def load_networks(resolution, device, need_vgg=True, need_d=True):
         r_state = synth.resnet50_state(seed=constants.SYNTH_SEED_R)
         src['R'] = 'synthetic(seed=%d)' % constants.SYNTH_SEED_R
     from . import conv
-    if conv.PRECISION == 'bf16':                           # the 16-bit path (BASELINE config 5): bf16 h8 feature maps, one bf16 MFMA per MAC (nets16.py)
+    if conv.PRECISION in conv.H8_PRECISIONS:                           # the 16-bit path (BASELINE config 5): bf16 h8 feature maps, one bf16 MFMA per MAC (nets16.py)
         from . import nets16
         GenCls, RegCls, VggCls, DCls = nets16.Generator, nets16.ResNet50, nets16.VGG19Prefix, nets16.Discriminator
+        if conv.PRECISION == 'f16':                                    # static power-of-two gradient scales of the fp16 path for this resolution / batch
+            from . import constants as _c
+            nets16.LOSS_SCALE_LOG2.update(nets16.loss_scale_for(resolution, _c.BATCH_SIZE))
     else:
         GenCls, RegCls, VggCls, DCls = Generator, ResNet50, VGG19Prefix, Discriminator
     src['precision'] = conv.PRECISION

@@ -9,6 +9,18 @@ from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU  # noqa: F401
 
 BF = torch.bfloat16
+H8_DTYPES = (torch.bfloat16, torch.float16)
+
+
+def h8_dtype():
+    """Element type of the 16-bit path's h8 maps: bf16 (conv.PRECISION 'bf16') or IEEE fp16 ('f16', [r5])."""
+    from . import conv
+    return conv.h8_dtype()
+
+
+def _fn(lib, name, dtype):
+    """The entry point of `name` for h8 maps of `dtype` (csrc/l2i_*_h8.hip are compiled once per element type)."""
+    return getattr(lib, name + '_f16' if dtype == torch.float16 else name)
 
 
 def separable(kernel):
@@ -29,17 +41,18 @@ def separable(kernel):
 
 
 def _h8(t):
-    assert t.dtype == BF and t.dim() == 5 and t.shape[4] == 8 and t.is_contiguous(), (t.dtype, t.shape)
+    assert t.dtype in H8_DTYPES and t.dim() == 5 and t.shape[4] == 8 and t.is_contiguous(), (t.dtype, t.shape)
     return _lib.ptr(t)
 
 
-def cast_to_h8(x, cpad=None):
-    """fp32 NCHW -> bf16 h8 with ``cpad`` channels (zero filled above C)."""
+def cast_to_h8(x, cpad=None, dtype=None):
+    """fp32 NCHW -> 16-bit h8 with ``cpad`` channels (zero filled above C)."""
     lib = _lib.load()
     B, C, H, W = x.shape
     cpad = (C + 7) // 8 * 8 if cpad is None else cpad
-    y = torch.empty(B, cpad // 8, H, W, 8, device=x.device, dtype=BF)
-    _lib.check(lib.l2i_cast_f32_to_h8(_lib.ptr(y), _lib.fptr(x.contiguous()), B, C, cpad, H * W, _lib.stream_ptr()), 'l2i_cast_f32_to_h8')
+    dtype = dtype or h8_dtype()
+    y = torch.empty(B, cpad // 8, H, W, 8, device=x.device, dtype=dtype)
+    _lib.check(_fn(lib, 'l2i_cast_f32_to_h8', dtype)(_lib.ptr(y), _lib.fptr(x.contiguous()), B, C, cpad, H * W, _lib.stream_ptr()), 'l2i_cast_f32_to_h8')
     return y
 
 
@@ -48,7 +61,7 @@ def cast_from_h8(t, channels=None):
     B, G8, H, W, _ = t.shape
     C = G8 * 8 if channels is None else channels
     y = torch.empty(B, C, H, W, device=t.device, dtype=torch.float32)
-    _lib.check(lib.l2i_cast_h8_to_f32(_lib.fptr(y), _h8(t), B, C, G8 * 8, H * W, _lib.stream_ptr()), 'l2i_cast_h8_to_f32')
+    _lib.check(_fn(lib, 'l2i_cast_h8_to_f32', t.dtype)(_lib.fptr(y), _h8(t), B, C, G8 * 8, H * W, _lib.stream_ptr()), 'l2i_cast_h8_to_f32')
     return y
 
 
@@ -62,11 +75,11 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0, 0, 0), noise=None, noise_w=0.0
     kh, kw = kernel.shape
     oh = (H * up + pad[2] + pad[3] - kh) // down + 1
     ow = (W * up + pad[0] + pad[1] - kw) // down + 1
-    y = torch.empty(B, G8, oh, ow, 8, device=x.device, dtype=BF)
+    y = torch.empty(B, G8, oh, ow, 8, device=x.device, dtype=x.dtype)
     use_sep = sep is not None and kh == 4 and kw == 4 and not os.environ.get('L2I_H8_NOSEP')            # the library picks its separable register-streaming kernels (no resampling, down 2, up 2) where they apply
     k1y = (ctypes.c_float * 4)(*sep[0]) if use_sep else None
     k1x = (ctypes.c_float * 4)(*sep[1]) if use_sep else None
-    _lib.check(lib.l2i_upfirdn2d_h8(_lib.ptr(y), _h8(x), _lib.fptr(kernel.contiguous()), B * G8, G8 * 8, H, W, kh, kw, up, down, pad[0], pad[1], pad[2], pad[3],
+    _lib.check(_fn(lib, 'l2i_upfirdn2d_h8', x.dtype)(_lib.ptr(y), _h8(x), _lib.fptr(kernel.contiguous()), B * G8, G8 * 8, H, W, kh, kw, up, down, pad[0], pad[1], pad[2], pad[3],
                                     _lib.fptr(noise), float(noise_w), _lib.fptr(bias), int(act), float(slope), float(gain), None if mask is None else _h8(mask),
                                     float(mask_vals[0]), float(mask_vals[1]), None if addend is None else _h8(addend), k1y, k1x, _lib.stream_ptr()), 'l2i_upfirdn2d_h8')
     assert (mask is None or mask.shape == y.shape) and (addend is None or addend.shape == y.shape)
@@ -78,7 +91,7 @@ def torgb_fwd(x, wmod, bias):
     lib = _lib.load()
     B, G8, H, W, _ = x.shape
     rgb = torch.empty(B, 3, H, W, device=x.device, dtype=torch.float32)
-    _lib.check(lib.l2i_torgb_fwd_h8(_lib.fptr(rgb), _h8(x), _lib.fptr(wmod.contiguous()), _lib.fptr(bias), B, G8 * 8, H * W, _lib.stream_ptr()), 'l2i_torgb_fwd_h8')
+    _lib.check(_fn(lib, 'l2i_torgb_fwd_h8', x.dtype)(_lib.fptr(rgb), _h8(x), _lib.fptr(wmod.contiguous()), _lib.fptr(bias), B, G8 * 8, H * W, _lib.stream_ptr()), 'l2i_torgb_fwd_h8')
     return rgb
 
 
@@ -87,7 +100,7 @@ def sg2_act_bwd(y, gin, gin_scale, grgb, wmod_rgb, bias, noise, noise_w, slope, 
     lib = _lib.load()
     B, G8, H, W, _ = y.shape
     dz = torch.empty_like(y)
-    _lib.check(lib.l2i_sg2_act_bwd_h8(_lib.ptr(dz), None if gin is None else _h8(gin), _lib.fptr(gin_scale), _lib.fptr(grgb), _lib.fptr(wmod_rgb), _h8(y), _lib.fptr(bias),
+    _lib.check(_fn(lib, 'l2i_sg2_act_bwd_h8', y.dtype)(_lib.ptr(dz), None if gin is None else _h8(gin), _lib.fptr(gin_scale), _lib.fptr(grgb), _lib.fptr(wmod_rgb), _h8(y), _lib.fptr(bias),
                                       _lib.fptr(noise), float(noise_w), float(slope), float(gain), _lib.fptr(red), _lib.fptr(red_rgb), B, G8 * 8, H * W,
                                       _lib.stream_ptr()), 'l2i_sg2_act_bwd_h8')
     return dz
@@ -99,7 +112,7 @@ def dot_reduce(a, b=None, out=None):
     B, G8, H, W, _ = a.shape
     if out is None:
         out = torch.zeros(B * G8 * 8, device=a.device, dtype=torch.float32)
-    _lib.check(lib.l2i_dot_reduce_h8(_lib.fptr(out), _h8(a), None if b is None else _h8(b), B, G8 * 8, H * W, _lib.stream_ptr()), 'l2i_dot_reduce_h8')
+    _lib.check(_fn(lib, 'l2i_dot_reduce_h8', a.dtype)(_lib.fptr(out), _h8(a), None if b is None else _h8(b), B, G8 * 8, H * W, _lib.stream_ptr()), 'l2i_dot_reduce_h8')
     return out.view(B, G8 * 8)
 
 
@@ -107,9 +120,9 @@ def maxpool2d_fwd(x, k, s, pad, relu=False):
     lib = _lib.load()
     B, G8, H, W, _ = x.shape
     oh, ow = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
-    y = torch.empty(B, G8, oh, ow, 8, device=x.device, dtype=BF)
+    y = torch.empty(B, G8, oh, ow, 8, device=x.device, dtype=x.dtype)
     idx = torch.empty(B, G8, oh, ow, 8, device=x.device, dtype=torch.uint8)
-    _lib.check(lib.l2i_maxpool2d_fwd_h8(_lib.ptr(y), _lib.ptr(idx), _h8(x), B * G8, H, W, k, s, pad, oh, ow, int(relu), _lib.stream_ptr()), 'l2i_maxpool2d_fwd_h8')
+    _lib.check(_fn(lib, 'l2i_maxpool2d_fwd_h8', x.dtype)(_lib.ptr(y), _lib.ptr(idx), _h8(x), B * G8, H, W, k, s, pad, oh, ow, int(relu), _lib.stream_ptr()), 'l2i_maxpool2d_fwd_h8')
     return y, idx
 
 
@@ -117,8 +130,8 @@ def maxpool2d_bwd(gy, idx, in_hw, k, s, pad, a=None, b=None, coef=0.0, coef_dev=
     """Pool backward on h8 maps; a / b (h8, input-sized): + coef * coef_dev[0] * (b - a) in the same pass."""
     lib = _lib.load()
     B, G8, oh, ow, _ = gy.shape
-    gx = torch.empty(B, G8, in_hw[0], in_hw[1], 8, device=gy.device, dtype=BF)
-    _lib.check(lib.l2i_maxpool2d_bwd_h8(_lib.ptr(gx), _h8(gy), _lib.ptr(idx), None if a is None else _h8(a), None if b is None else _h8(b), float(coef), _lib.fptr(coef_dev),
+    gx = torch.empty(B, G8, in_hw[0], in_hw[1], 8, device=gy.device, dtype=gy.dtype)
+    _lib.check(_fn(lib, 'l2i_maxpool2d_bwd_h8', gy.dtype)(_lib.ptr(gx), _h8(gy), _lib.ptr(idx), None if a is None else _h8(a), None if b is None else _h8(b), float(coef), _lib.fptr(coef_dev),
                                         B * G8, in_hw[0], in_hw[1], k, s, pad, oh, ow, _lib.stream_ptr()), 'l2i_maxpool2d_bwd_h8')
     return gx
 
@@ -127,7 +140,7 @@ def sqdiff(a, b, coef=0.0, want_grad=False, coef_dev=None, want_sum=True):
     lib = _lib.load()
     s = torch.zeros(1, device=a.device, dtype=torch.float32) if want_sum else None
     g = torch.empty_like(b) if want_grad else None
-    _lib.check(lib.l2i_sqdiff_h8(_lib.fptr(s), None if g is None else _lib.ptr(g), _h8(a), _h8(b), a.numel() // 8, float(coef), _lib.fptr(coef_dev), _lib.stream_ptr()), 'l2i_sqdiff_h8')
+    _lib.check(_fn(lib, 'l2i_sqdiff_h8', a.dtype)(_lib.fptr(s), None if g is None else _lib.ptr(g), _h8(a), _h8(b), a.numel() // 8, float(coef), _lib.fptr(coef_dev), _lib.stream_ptr()), 'l2i_sqdiff_h8')
     return s, g
 
 
@@ -135,7 +148,7 @@ def add_zero_insert(y, c, mask=None):
     """y[.., 2oy, 2ox, :] += c[.., oy, ox, :] * (mask[.., 2oy, 2ox, :] > 0 if a mask is given) in place (h8)."""
     lib = _lib.load()
     B, G8, H, W, _ = y.shape
-    _lib.check(lib.l2i_add_zero_insert_h8(_h8(y), _h8(c), None if mask is None else _h8(mask), B * G8, H, W, c.shape[2], c.shape[3], _lib.stream_ptr()), 'l2i_add_zero_insert_h8')
+    _lib.check(_fn(lib, 'l2i_add_zero_insert_h8', y.dtype)(_h8(y), _h8(c), None if mask is None else _h8(mask), B * G8, H, W, c.shape[2], c.shape[3], _lib.stream_ptr()), 'l2i_add_zero_insert_h8')
     return y
 
 
@@ -143,16 +156,18 @@ def mask_mul(g, ref, pos=1.0, neg=0.0):
     """g * (ref > 0 ? pos : neg) on h8 maps."""
     lib = _lib.load()
     y = torch.empty_like(g)
-    _lib.check(lib.l2i_mask_mul_h8(_lib.ptr(y), _h8(g), _h8(ref), float(pos), float(neg), g.numel() // 8, _lib.stream_ptr()), 'l2i_mask_mul_h8')
+    _lib.check(_fn(lib, 'l2i_mask_mul_h8', g.dtype)(_lib.ptr(y), _h8(g), _h8(ref), float(pos), float(neg), g.numel() // 8, _lib.stream_ptr()), 'l2i_mask_mul_h8')
     return y
 
 
-def modulate_planes(w32, s):
-    """w32: fp32 weights in plane order [Cin/16, KK, 2, CoutP, 8] (conv.pack_weight_h8_f32); s [B, Cin] fp32 -> bf16 planes [B, Cin/16, KK, 2, CoutP, 8] (int16 view)."""
+def modulate_planes(w32, s, dtype=None):
+    """w32: fp32 weights in plane order [Cin/16, KK, 2, CoutP, 8] (conv.pack_weight_h8_f32); s [B, Cin] fp32 -> 16-bit planes [B, Cin/16, KK, 2, CoutP, 8]
+    (int16 view) in the element type of the path (or ``dtype``)."""
     lib = _lib.load()
+    dtype = dtype or h8_dtype()
     B = s.shape[0]
     c16, kk, _, coutp, _ = w32.shape
     assert s.shape[1] == c16 * 16 and s.is_contiguous()
     planes = torch.empty((B,) + tuple(w32.shape), device=w32.device, dtype=torch.int16)
-    _lib.check(lib.l2i_modulate_planes_h8(_lib.ptr(planes), _lib.fptr(w32), _lib.fptr(s), B, c16 * 16, c16 * 16, kk, coutp, _lib.stream_ptr()), 'l2i_modulate_planes_h8')
+    _lib.check(_fn(lib, 'l2i_modulate_planes_h8', dtype)(_lib.ptr(planes), _lib.fptr(w32), _lib.fptr(s), B, c16 * 16, c16 * 16, kk, coutp, _lib.stream_ptr()), 'l2i_modulate_planes_h8')
     return planes

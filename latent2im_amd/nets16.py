@@ -32,6 +32,51 @@ from .specs import RESNET50_LAYERS
 SQRT2 = math.sqrt(2.0)
 LRELU_MASK = (SQRT2, 0.2 * SQRT2)
 
+# [r5] IEEE fp16 elements (conv.PRECISION = 'f16'; BASELINE configs[4]: "fp16 MFMA") have 3 more mantissa bits than bf16 and a range of 6e-8 .. 65504:
+# the forward maps of the four networks fit it as they are (demodulated generator activations, folded-BatchNorm ResNet, VGG taps of [-1,1] images),
+# the GRADIENT maps do not (a ContentLoss gradient at 1024^2 is ~1e-11 per element).  Each loss branch therefore multiplies the gradient it receives by
+# a power of two on the way in and its fp32 result (the 3-channel image gradient; the latent gradient of the generator) by the inverse on the way
+# out: exact in every fp32 quantity, and inside a branch all maps are linear in the incoming gradient.  The exponents are STATIC per (branch,
+# resolution, batch): `loss_scale` below — measured with tools/bf16_study.py --probe (max / median magnitude of every gradient map), chosen to put the
+# largest map of a branch near 2^8 .. 2^11; nothing is checked at run time.  bf16 elements: every scale is 1 (not applied).
+PROBE = None            # tools/bf16_study.py --probe: a list that receives (tag, shape, max |g|, median |g| of the non-zero entries) per gradient map
+
+
+def _probe(tag, t):
+    if PROBE is not None:
+        a = t.detach().float().abs().reshape(-1)
+        nz = a[a > 0]
+        PROBE.append((tag, tuple(t.shape), float(a.max()), float(nz.median()) if nz.numel() else 0.0, float((a == 0).float().mean())))
+
+
+LOSS_SCALE_LOG2 = dict(R=0, V=0, D=0, G=0)      # set by loss_scale_for(); an override for experiments: L2I_F16_SCALES="R,V,D,G" (log2 values)
+
+
+def loss_scale_for(resolution, batch):
+    """log2 of the per-branch gradient scales of the fp16 path at `resolution`^2, per-GPU `batch` (see above).  The magnitudes follow the loss
+    normalisations: the ContentLoss is a mean over B * C * H * W elements (gradient ~ 1 / (B H W)), the regressor's BCE a mean over B * attrs through
+    an average pool (1 / B), the discriminator's BCE a mean over B through learned-scale convs, and the generator receives their sum."""
+    env = os.environ.get('L2I_F16_SCALES')
+    if env:
+        r, v, d, g = (int(x) for x in env.split(','))
+        return dict(R=r, V=v, D=d, G=g)
+    lb = int(round(math.log2(max(batch, 1))))
+    lr = int(round(math.log2(resolution)))
+    return dict(R=F16_SCALE_BASE['R'] + lb + F16_SCALE_RES['R'] * (lr - 8), V=F16_SCALE_BASE['V'] + lb + F16_SCALE_RES['V'] * (lr - 8),
+                D=F16_SCALE_BASE['D'] + lb + F16_SCALE_RES['D'] * (lr - 8), G=F16_SCALE_BASE['G'] + lb + F16_SCALE_RES['G'] * (lr - 8))
+
+
+# exponents at 256^2, batch 1, and their growth per doubling of the resolution (tools/bf16_study.py --probe, profiles/r05_fp16_gradient_ranges.txt)
+F16_SCALE_BASE = dict(R=0, V=0, D=0, G=0)
+F16_SCALE_RES = dict(R=0, V=0, D=0, G=0)
+
+
+def _gs(net, key):
+    """The branch's gradient scale (a float power of two; 1.0 on the bf16 path)."""
+    if net.dtype != torch.float16:
+        return 1.0
+    return float(2.0 ** LOSS_SCALE_LOG2[key])
+
 
 # =====================================================================================================================================
 # VGG-19 prefix content loss (perceptual.py)
@@ -40,6 +85,7 @@ class VGG19Prefix:
     def __init__(self, state, device='cuda'):
         P = state
         self.device = device
+        self.dtype = K16.h8_dtype()
         w0 = torch.as_tensor(np.asarray(P['0.weight']), dtype=torch.float32)
         w0 = w0 / torch.tensor(VGG_STD, dtype=torch.float32).reshape(1, 3, 1, 1)
         ws = [w0] + [torch.as_tensor(np.asarray(P['%d.weight' % i]), dtype=torch.float32) for i in (2, 5, 7)]
@@ -51,7 +97,7 @@ class VGG19Prefix:
         """[B,3,H,W] fp32 -> (c1, c2, p, c3, c4, pool_idx) h8: pre-ReLU conv outputs conv_1..conv_4, p = relu(maxpool(c2)).  ``org`` = the four
         taps of the original image: a seventh element, the four sums of (c_k - org_k)^2, formed in the conv epilogues."""
         xc = K.fused_bias_act(img.contiguous(), self.neg_mean, None, 1, 0, 0.0, 1.0)        # x - mean (fp32: the padding stays exactly zero)
-        xh = K16.cast_to_h8(xc, 16)                                # three real channels of a 16-channel chunk
+        xh = K16.cast_to_h8(xc, 16, dtype=self.dtype)              # three real channels of a 16-channel chunk
         sq = [None] * 4
         if org is not None:
             acc = torch.zeros(4, C._lib.SQ_SLOTS, device=img.device, dtype=torch.float32)
@@ -61,6 +107,9 @@ class VGG19Prefix:
         p, idx = K16.maxpool2d_fwd(c2, 2, 2, 0, relu=True)          # relu(maxpool(.)) == maxpool(relu(.)); the stored map is already rectified
         c3 = self.convs[2].forward(p, bias=self.biases[2], sq=sq[2])
         c4 = self.convs[3].forward(c3, relu_in=True, bias=self.biases[3], sq=sq[3])
+        if PROBE is not None:
+            for tag, t in (('V.fwd.c1', c1), ('V.fwd.c2', c2), ('V.fwd.c3', c3), ('V.fwd.c4', c4)):
+                _probe(tag, t)
         if org is None:
             return c1, c2, p, c3, c4, idx
         return c1, c2, p, c3, c4, idx, [acc[k].sum().reshape(1) for k in range(4)]
@@ -85,18 +134,24 @@ class _Content16Fn(torch.autograd.Function):
     def backward(ctx, g_losses):
         net, (o1, o2, o3, o4) = ctx.net, ctx.org
         c1, c2, p, c3, c4, idx = ctx.acts
-        gl = [g_losses[k:k + 1].contiguous() for k in range(4)]
+        S = _gs(net, 'V')
+        gl = [(g_losses[k:k + 1] * S).contiguous() if S != 1.0 else g_losses[k:k + 1].contiguous() for k in range(4)]
         hw = lambda t: (t.shape[2], t.shape[3])
         d4 = K16.sqdiff(o4, c4, coef=2.0 / c4.numel(), coef_dev=gl[3], want_grad=True, want_sum=False)[1]
+        d4_probe = d4 if PROBE is not None else None
         g3 = net.convs[3].dgrad(d4, hw(c3), out_mask=c3, residual=c3, res_sub=o3, res_coef=2.0 / c3.numel(), res_coef_dev=gl[2])
         del d4
+        _probe('V.g3', g3)
         gp = net.convs[2].dgrad(g3, hw(p), out_mask=p)
         del g3
         g2 = K16.maxpool2d_bwd(gp, idx, hw(c2), 2, 2, 0, a=o2, b=c2, coef=2.0 / c2.numel(), coef_dev=gl[1])
         del gp
+        _probe('V.g2', g2)
         g1 = net.convs[1].dgrad(g2, hw(c1), out_mask=c1, residual=c1, res_sub=o1, res_coef=2.0 / c1.numel(), res_coef_dev=gl[0])
         del g2
-        g_img = net.convs[0].dgrad(g1, ctx.in_hw, out_f32=True)
+        for tag, t in (('V.d4', d4_probe), ('V.g1', g1)) if PROBE is not None else ():
+            _probe(tag, t)
+        g_img = net.convs[0].dgrad(g1, ctx.in_hw, out_f32=True, out_gain=1.0 / S)
         ctx.acts = ctx.org = None
         return g_img, None, None
 
@@ -115,6 +170,7 @@ class ResNet50:
     def __init__(self, state, device='cuda'):
         P = state
         self.device = device
+        self.dtype = K16.h8_dtype()
         self.stem = _CB(P, 'conv1', 'bn1', 2, 3, device)            # 7x7 stride 2 on the 3-channel fp32 image: the fp32 kernels (0.3 % of the net's MACs)
         self.blocks = []
         for li, (planes, blocks, stride) in enumerate(RESNET50_LAYERS):
@@ -138,7 +194,7 @@ class _ResNet16Fn(torch.autograd.Function):
         keep = img.requires_grad
         x = img.detach().contiguous()
         a0 = net.stem.conv.forward(x, bias=net.stem.bias, act=C.ACT_RELU)              # fp32 [B,64,H/2,W/2]
-        p0, idx0 = K16.maxpool2d_fwd(K16.cast_to_h8(a0), 3, 2, 1)
+        p0, idx0 = K16.maxpool2d_fwd(K16.cast_to_h8(a0, dtype=net.dtype), 3, 2, 1)
         saved = dict(in_hw=(x.shape[2], x.shape[3]), a0=a0 if keep else None, idx0=idx0 if keep else None, blocks=[])
         cur = p0
         for blk in net.blocks:
@@ -149,6 +205,8 @@ class _ResNet16Fn(torch.autograd.Function):
             if keep:
                 saved['blocks'].append((cur, y1, y2, out))
             cur = out
+            if PROBE is not None and blk['down'] is not None:
+                _probe('R.fwd.out', out)
         b, g8, h, w, _ = cur.shape
         feat = K16.dot_reduce(cur) * (1.0 / (h * w))                                   # adaptive avg-pool (1,1), fp32 sums
         ctx.net, ctx.saved, ctx.last = net, saved if keep else None, cur if keep else None
@@ -166,7 +224,8 @@ class _ResNet16Fn(torch.autograd.Function):
         # epilogue — and MEASURED: input-gradient cosine against the exact oracle 0.9715 / 0.9526 at 64^2 / 256^2 with either trunk, identical to four
         # digits (profiles/r04_bf16_trunk_f32_vs_bf16.txt; the cause is the forward's storage rounding), while its two extra
         # epilogue branches cost the 16-bit conv kernel 3 - 17 % on launches with a residual (c5 209.5 -> 213.1 images/s without them): removed.
-        g = (g_feat * (1.0 / (h * w))).reshape(b, g8, 1, 1, 8).expand(b, g8, h, w, 8).contiguous().to(torch.bfloat16)
+        S = _gs(net, 'R')
+        g = (g_feat * (S / (h * w))).reshape(b, g8, 1, 1, 8).expand(b, g8, h, w, 8).contiguous().to(net.dtype)
         G = K16.mask_mul(g, last)                                                        # gradient w.r.t. the pre-ReLU sum of the last block
         n = len(net.blocks)
         for bi in range(n - 1, -1, -1):
@@ -186,9 +245,11 @@ class _ResNet16Fn(torch.autograd.Function):
                 K16.add_zero_insert(Gp, blk['down'].conv.dgrad_compact(G), mask=m)       # strided 1x1: compact 1x1 conv + zero insertion
             del g_y1
             G = Gp
+            if PROBE is not None and (bi in (0, n - 1) or net.blocks[bi]['down'] is not None):
+                _probe('R.G%d' % bi, G)
         a0 = saved['a0']
         g_a0 = K16.cast_from_h8(K16.maxpool2d_bwd(G, saved['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1), a0.shape[1])
-        g_img = net.stem.conv.dgrad(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0))
+        g_img = net.stem.conv.dgrad(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0), out_gain=1.0 / S)
         ctx.saved = ctx.last = None
         return g_img, None
 
@@ -208,6 +269,7 @@ class Discriminator(_Discriminator32):
     def __init__(self, state, size, device='cuda'):
         P = state
         self.size, self.device = size, device
+        self.dtype = K16.h8_dtype()
         log_size = int(math.log2(size))
         self.conv0 = _eq16(P, 'convs.0.0.weight', 1, 0, device)
         self.bias0 = _vec(P, 'convs.0.1.bias', device)
@@ -239,7 +301,7 @@ class _DBody16Fn(torch.autograd.Function):
         keep = img.requires_grad
         x = img.detach().contiguous()
         lr = dict(act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
-        y0 = net.conv0.forward(K16.cast_to_h8(x, 32), bias=net.bias0, **lr)
+        y0 = net.conv0.forward(K16.cast_to_h8(x, 32, dtype=net.dtype), bias=net.bias0, **lr)
         saved = [y0]
         cur = y0
         for blk in net.blocks:
@@ -254,6 +316,7 @@ class _DBody16Fn(torch.autograd.Function):
             if keep:
                 saved.append((y1, y2, (h, cur.shape[3])))
             cur = out
+            _probe('D.fwd.out@%d' % h, out)
         ctx.net, ctx.saved, ctx.in_hw = net, saved if keep else None, (x.shape[2], x.shape[3])
         return K16.cast_from_h8(cur)                                               # [B,512,4,4] fp32 for the tail
 
@@ -262,8 +325,10 @@ class _DBody16Fn(torch.autograd.Function):
         net, saved = ctx.net, ctx.saved
         if saved is None:
             raise RuntimeError('discriminator was run without a differentiable input')
-        g = K16.cast_to_h8(g32.contiguous())
+        S = _gs(net, 'D')
+        g = K16.cast_to_h8(g32.contiguous() * S if S != 1.0 else g32.contiguous(), dtype=net.dtype)
         for blk, (y1, y2, in_hw) in zip(reversed(net.blocks), reversed(saved[1:])):
+            _probe('D.g@%d' % in_hw[0], g)
             h = in_hw[0]
             gm = K16.mask_mul(g, y2, 1.0, 0.2)                                    # 1/sqrt2 * lrelu' * sqrt2 on the conv2 branch (g also feeds the skip branch)
             g_t = blk['c2'].dgrad(gm, (h + 1, h + 1))
@@ -275,7 +340,8 @@ class _DBody16Fn(torch.autograd.Function):
             g_ts = blk['sk1'].dgrad(g, (h // 2, h // 2), out_gain=1.0 / SQRT2)
             g = K16.upfirdn2d(g_ts, blk['kf'], up=2, pad=(2, 1, 2, 1), addend=g_a, sep=blk['kfsep'])      # adjoint of (blur, every second pixel): zero-insertion FIR
             del g_ts, g_a
-        g_img = net.conv0.dgrad(K16.mask_mul(g, saved[0], *LRELU_MASK), ctx.in_hw, out_f32=True)
+        _probe('D.g_last', g)
+        g_img = net.conv0.dgrad(K16.mask_mul(g, saved[0], *LRELU_MASK), ctx.in_hw, out_f32=True, out_gain=1.0 / S)
         ctx.saved = None
         return g_img, None
 
@@ -307,6 +373,7 @@ class _StyledLayer16:
 class Generator(_Generator32):
     def __init__(self, state, size, device='cuda', style_dim=512, n_mlp=8, lr_mlp=0.01):
         self.size, self.device, self.style_dim = size, device, style_dim
+        self.dtype = K16.h8_dtype()
         self.log_size = int(math.log2(size))
         self.n_latent = self.log_size * 2 - 2
         self.num_layers = (self.log_size - 2) * 2 + 1
@@ -316,7 +383,7 @@ class Generator(_Generator32):
             w = _t(P['style.%d.weight' % i], device)
             self.mlp.append(((w * ((1.0 / math.sqrt(w.shape[1])) * lr_mlp)).t().contiguous(), _t(P['style.%d.bias' % i], device) * lr_mlp))
         self.const = _t(P['input.input'], device)
-        self.const16 = C.to_h8(self.const)                                     # [1, 64, 4, 4, 8]
+        self.const16 = C.to_h8(self.const, dtype=self.dtype)                    # [1, 64, 4, 4, 8]
         geo, _ = specs.generator_geometry(size)
         self.layers = [_StyledLayer16(P, name, cin, cout, up, device) for name, cin, cout, res, up in geo]
         self.rgbs = [_ToRGB(P, 'to_rgb1', geo[0][2], False, device)]
@@ -348,7 +415,7 @@ class _Synthesis16Fn(torch.autograd.Function):
             h = x.shape[2]
             res = h * 2 if L.up else h
             nz = _noise_for(gen, noise, li, B, res, dev, drawn)
-            planes = K16.modulate_planes(L.w32_fwd, s)                         # weight * style, one plane set per sample (networks.py:234-235)
+            planes = K16.modulate_planes(L.w32_fwd, s, dtype=gen.dtype)        # weight * style, one plane set per sample (networks.py:234-235)
             bstride = planes[0].numel() * 2
             if L.up:
                 t = L.conv.forward(x, planes=planes, w_bstride=bstride, out_scale=demod)          # (2H+1)^2
@@ -357,6 +424,8 @@ class _Synthesis16Fn(torch.autograd.Function):
             else:
                 y = L.conv.forward(x, planes=planes, w_bstride=bstride, out_scale=demod, noise=nz, noise_w=L.noise_w, bias=L.bias, **lr)
             del planes
+            if PROBE is not None and li % 2 == 0:
+                _probe('G.fwd.y%d@%d' % (li, res), y)
             rec = dict(x=x if keep else None, y=y if keep else None, s=s, demod=demod, nz=nz)
             if li == 0 or (li % 2 == 0):
                 R = gen.rgbs[li // 2]
@@ -381,7 +450,8 @@ class _Synthesis16Fn(torch.autograd.Function):
         red_dz, q_all, red_rgb = plan.reductions(B, dev)
         n_rgb = len(gen.rgbs)
         g_rgb = [None] * n_rgb
-        g = g_img.contiguous()
+        S = _gs(gen, 'G')
+        g = g_img.contiguous() * S if S != 1.0 else g_img.contiguous()
         for j in range(n_rgb - 1, -1, -1):
             g_rgb[j] = g
             if j > 0:
@@ -396,7 +466,7 @@ class _Synthesis16Fn(torch.autograd.Function):
             demod, s = rec['demod'], rec['s']
             x = rec['x']
             hw = (x.shape[2], x.shape[3])
-            planes = K16.modulate_planes(L.w32_bwd, demod)                     # the gradient conv's weights carry the demodulation factor
+            planes = K16.modulate_planes(L.w32_bwd, demod, dtype=gen.dtype)    # the gradient conv's weights carry the demodulation factor
             bstride = planes[0].numel() * 2
             if L.up:
                 dt = K16.upfirdn2d(dz, L.blur_k_flip, pad=(2, 2, 2, 2), sep=L.blur_flip_sep)        # gradient of the (2H+1)^2 map under the blur
@@ -408,7 +478,11 @@ class _Synthesis16Fn(torch.autograd.Function):
                 del dz
             del planes
             K16.dot_reduce(dxmod, x, out=plan.s(q_all, B, li).view(-1))          # d s via x * s
+            if PROBE is not None and (li % 2 == 0 or li == len(gen.layers) - 1):
+                _probe('G.dx%d@%d' % (li, hw[0]), dxmod)
             gin, gin_scale = dxmod, s
             rec['y'] = rec['x'] = None
         g_lat = plan.backward(B, s_all, d_all, red_dz, q_all, red_rgb)
+        if S != 1.0:
+            g_lat = g_lat * (1.0 / S)
         return g_lat, None, None

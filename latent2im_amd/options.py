@@ -47,7 +47,7 @@ class TrainOptions:
         p.add_argument('--no_log_sync', action='store_true', help='do not read the loss back every step (train.py:110)')
         p.add_argument('--hip_graph', action='store_true',
                        help='record forward+backward of the step once and replay it from one hipGraph per iteration (static batch size)')
-        p.add_argument('--precision', type=str, default=None, choices=['f32', 'bf16x3', 'bf16'],
+        p.add_argument('--precision', type=str, default=None, choices=['f32', 'bf16x3', 'bf16', 'f16'],
                        help='matrix path of the frozen networks: exact fp32 MFMA (default), the 3-term bf16 split on fp32 tensors (fp32 accuracy), '
                             'or the 16-bit path (bf16 feature maps in HBM, one bf16 MFMA per MAC, fp32 accumulation; BASELINE config 5)')
         p.add_argument('--synthetic_weights', action='store_true',

@@ -1,6 +1,10 @@
-"""Tolerance study of the 16-bit path (conv.PRECISION = 'bf16': bf16 h8 feature maps, one bf16 MFMA per MAC) against the float64 CPU oracle on
-the same z / weights: per network (forward and input gradient) and for whole training steps at 64^2 (batch 4), 256^2 (batch 2), 1024^2 (batch 1).
-Prints one JSON line per case; profiles/r03_bf16_tolerance.json is this script's output on the MI355X.  usage: python tools/bf16_study.py [sizes]"""
+"""Tolerance study of the 16-bit path (conv.PRECISION = 'bf16': bf16 h8 feature maps, one bf16 MFMA per MAC; [r5] 'f16': IEEE fp16 elements with
+static power-of-two gradient scales) against the float64 CPU oracle on the same z / weights: per network (forward and input gradient) and for
+whole training steps at 64^2 (batch 4), 256^2 (batch 2), 1024^2 (batch 1).  Prints one JSON line per case; profiles/r0N_{bf16,fp16}_tolerance.json
+are this script's outputs on the MI355X.
+usage: python tools/bf16_study.py [sizes] [--precision bf16|f16] [--noise_strength S]
+       python tools/bf16_study.py [sizes] --probe [--precision ...] [--batch B]: no oracle; one training step with latent2im_amd.nets16.PROBE set:
+       max / median magnitude (and zero fraction) of the forward and gradient maps of every branch — what the fp16 gradient scales are read from."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -32,7 +36,10 @@ def l2rel(a, b):
 
 def networks(size, batch):
     from latent2im_amd import nets16
-    out = dict(case='networks', size=size, batch=batch)
+    conv.PRECISION = PRECISION
+    if PRECISION == 'f16':
+        nets16.LOSS_SCALE_LOG2.update(nets16.loss_scale_for(size, batch))
+    out = dict(case='networks', precision=PRECISION, size=size, batch=batch)
     dt = torch.float64
     rs = np.random.RandomState(size)
     stG = synth.generator_state(size, seed=100, noise_strength=0.05)
@@ -90,9 +97,34 @@ def networks(size, batch):
     return out
 
 
+PRECISION = 'bf16'
+
+
+def probe(size, batch, attrs, clamp, transform='face'):
+    from latent2im_amd import constants, nets16
+    conv.PRECISION = PRECISION
+    gr = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform=transform)
+    zs = synth.z_sample(batch, seed=21)
+    rs = np.random.RandomState(22)
+    alpha = np.ones((batch, len(attrs))) * (rs.uniform(-1, 1, len(attrs)) if clamp else rs.uniform(0, 1, len(attrs)))
+    nets16.PROBE = []
+    try:
+        r = selfcheck.run_step(gr, zs, alpha, clamp=clamp, optimize=False)
+        torch.cuda.synchronize()
+    finally:
+        rows, nets16.PROBE = nets16.PROBE, None
+    print('== %s %d^2 batch %d, %d attrs: loss %.6f, walk-gradient max %.3e, finite %s; scales (log2) %s' % (
+        PRECISION, size, batch, len(attrs), float(r['loss']), float(r['grad'].abs().max()), bool(torch.isfinite(r['grad']).all() and torch.isfinite(r['x1']).all()),
+        nets16.LOSS_SCALE_LOG2 if PRECISION == 'f16' else '-'))
+    for tag, shape, mx, med, zf in rows:
+        print('  %-16s %-24s max %.3e (2^%6.1f)  median %.3e (2^%6.1f)  zeros %.3f' % (tag, 'x'.join(str(v) for v in shape), mx, np.log2(mx) if mx > 0 else -999,
+                                                                                    med, np.log2(med) if med > 0 else -999, zf))
+    constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
 def step(size, batch, attrs, clamp, transform='face'):
     from latent2im_amd import constants
-    conv.PRECISION = 'bf16'
+    conv.PRECISION = PRECISION
     gr = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform=transform)
     zs = synth.z_sample(batch, seed=21)
     rs = np.random.RandomState(22)
@@ -108,7 +140,7 @@ def step(size, batch, attrs, clamp, transform='face'):
     po = onets.resnet50_forward(nets['R'], o['x1'])[:, idx].double()
     tgt = o['target'].double()
     per_attr = lambda p: -(tgt * p.clamp(min=1e-12).log() + (1 - tgt) * (1 - p).clamp(min=1e-12).log()).mean(0)
-    out = dict(case='step', size=size, batch=batch, attrs=len(attrs), clamp=clamp,
+    out = dict(case='step', precision=PRECISION, size=size, batch=batch, attrs=len(attrs), clamp=clamp, finite=bool(torch.isfinite(r['grad']).all() and torch.isfinite(r['x1']).all()),
                x0_relmax=rel(r['x0'], o['x0']), x1_relmax=rel(r['x1'], o['x1']), x1_l2=l2rel(r['x1'], o['x1']),
                a0_absmax=float((r['a0'].double().cpu() - o['alpha_org']).abs().max()), eps_absmax=float((r['eps'].double().cpu() - o['eps']).abs().max()),
                reg_rel=abs(float(r['terms']['reg']) - float(o['reg'])) / abs(float(o['reg'])), cont_rel=abs(float(r['terms']['cont']) - float(o['cont'])) / abs(float(o['cont'])),
@@ -120,7 +152,25 @@ def step(size, batch, attrs, clamp, transform='face'):
 
 
 if __name__ == '__main__':
-    sizes = [int(s) for s in sys.argv[1].split(',')] if len(sys.argv) > 1 else [64, 256, 1024]
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('sizes', nargs='?', default='64,256,1024')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f16'])
+    ap.add_argument('--probe', action='store_true')
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--noise_strength', type=float, default=None, help='generator NoiseInjection weights of the synthetic state (default: constants.SYNTH_NOISE_STRENGTH)')
+    a = ap.parse_args()
+    PRECISION = a.precision
+    if a.noise_strength is not None:
+        from latent2im_amd import constants
+        constants.SYNTH_NOISE_STRENGTH = a.noise_strength
+    sizes = [int(s) for s in a.sizes.split(',')]
+    if a.probe:
+        for size in sizes:
+            batch = a.batch or {64: 4, 256: 2, 1024: 1}.get(size, 1)
+            probe(size, batch, ['Smiling'], False)
+            probe(size, batch, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], True, 'scene')
+        sys.exit(0)
     for size in sizes:
         batch = {64: 4, 256: 2, 1024: 1}.get(size, 1)
         if size <= 256:
