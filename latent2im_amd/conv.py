@@ -41,8 +41,8 @@ FAMILIES = ('implicit_gemm_f32', 'gemm1x1_f32', 'cin3_f32', 'direct_small_valu')
 # kernel family -> (kernel name in rocprof, MFMA FLOPs executed per algorithmic FLOP, peak TFLOP/s of the instruction it runs on)
 FAMILY_INFO = {
     'winograd_f32': ('conv_wino_kernel', 16.0 / 36.0, 157.3),
-    'winograd4_f32': ('conv_wino4_kernel', 36.0 / 144.0, 157.3),
-    'implicit_gemm_f32': ('conv_mfma_kernel', 1.0, 157.3),
+    'winograd4_f32': ('conv_wino4s_kernel', 36.0 / 144.0, 157.3),
+    'implicit_gemm_f32': ('conv_mfma_kernel / conv3x3s2_dma_kernel', 1.0, 157.3),
     'gemm1x1_f32': ('gemm1x1_kernel', 1.0, 157.3),
     'transposed_f32': ('convt_mfma_kernel', 1.0, 157.3),
     'cin3_f32': ('conv_cin3_kernel', 28.0 / 27.0, 157.3),

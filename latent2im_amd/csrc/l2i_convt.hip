@@ -14,9 +14,15 @@
 // Block = 256 threads = 4 waves along N; block tile = 32 output channels x (4*WN*32) INPUT-resolution positions t;
 // staging: buffer loads issued two chunks ahead into registers, committed into the other of two LDS stages one chunk ahead,
 // one barrier per chunk.
+// [r5] DMAIN = true (unmasked 3x3 launches with one sample per tile: the generator's up layers and the stride-2 convs' input-gradients on maps >= 32
+// positions wide): the input tile goes global -> LDS by dword DMA as well — a dense [CK][IH][IW] image, one channel plane per wave in turn, 64
+// elements per instruction, the plane pitch padded so that the two lane halves of a fragment read land on disjoint bank halves — into the other
+// stage while the current chunk multiplies: no staging registers (36 fewer per lane), no commit pass.  The rounds 2-4 reviews asked for this path
+// and an A/B on the step's shapes: tools/probes/convt_ab.py, profiles/r05_convt_ab.txt; L2I_CONVT_DMA=0 restores the register path.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "l2i.h"
 #include "l2i_internal.h"
 
@@ -32,6 +38,7 @@ struct ConvTLaunch {
     unsigned magic_iw, magic_rc, magic_ih;
     int in_elems, w_vec;
     int total;                         // blocks with work (grid padded to a multiple of 8)
+    int nslots;                        // DMAIN: 64-element DMA slots per channel plane (IH * IW elements, dense)
 };
 
 __device__ __forceinline__ unsigned fast_div_t(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
@@ -46,10 +53,11 @@ template <int K, int PAD> struct TrGeom {
     static constexpr int Q = q_(0) > q_(1) ? q_(0) : q_(1);                       // halo after the tile
 };
 
-template <int K, int PAD, int WN, bool MASK>
+template <int K, int PAD, int WN, bool MASK, bool DMAIN = false>
 __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const l2i_conv_params p, const ConvTLaunch L) {
     using G = TrGeom<K, PAD>;
-    constexpr int BM = 32, KK = K * K, NIN = 12, P = G::P, Q = G::Q;
+    constexpr int BM = 32, KK = K * K, NIN = DMAIN ? 1 : 12, P = G::P, Q = G::Q;
+    static_assert(!(DMAIN && MASK), "the DMA path has no VALU pass for a gradient mask");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // two stages of [input tile | weights | input scales]: the chunk after the one being multiplied is committed into the other
     // stage at the top of the iteration, so one barrier per chunk suffices
@@ -111,8 +119,21 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
     unsigned rin[NIN], rmk[MASK ? NIN : 1], voff[NIN];
     int loff[NIN];
     unsigned rsc = 0;
+    // DMAIN: element e = 64 s + lane of a dense [IH][IW] channel plane -> byte offset inside the plane (minus the slot's immediate), or out of range
+    constexpr int NSL = 6;
+    unsigned dvoff[DMAIN ? NSL : 1];
+    if constexpr (DMAIN) {
 #pragma unroll
-    for (int u = 0; u < NIN; ++u) {
+        for (int s_ = 0; s_ < NSL; ++s_) {
+            const unsigned e = (unsigned)(s_ * 64 + lane);
+            const unsigned row = fast_div_t(e, L.magic_iw), ixu = e - row * L.IW;
+            const int gy = iy0 + (int)row, gx = ix0 + (int)ixu;
+            const bool ok = (s_ < L.nslots) & ((int)row < L.IH) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
+            dvoff[s_] = ok ? (unsigned)(gy * p.W + gx) * 4u - (unsigned)s_ * 256u : 0x80000000u;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < (DMAIN ? 0 : NIN); ++u) {
         const unsigned e = tid + u * 256;
         voff[u] = in_bytes;
         loff[u] = -1;
@@ -158,6 +179,26 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
             }
         }
     };
+    // DMAIN: the input tile of a chunk: wave w takes channel planes w, w + 4, ...; one M0 per plane, its slots by immediate offsets (the immediate
+    // moves the LDS target and the global address alike: dvoff carries -256 s).  Idle lanes / slots past the plane write zeros into its padding.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_in = [&](int c0, int st) {
+        if constexpr (DMAIN) {
+            const unsigned lds_in0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + st * stage_f);
+            for (int c = wave_u; c < L.CK; c += 4) {
+                const unsigned base = lds_in0 + (unsigned)(c * L.plane * 4);
+                const unsigned so = (unsigned)((size_t)(c0 + c) * plane_x * sizeof(float));
+                asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                             "buffer_load_dword %0, %7, %8 offen lds\n\t"
+                             "buffer_load_dword %1, %7, %8 offen offset:256 lds\n\t"
+                             "buffer_load_dword %2, %7, %8 offen offset:512 lds\n\t"
+                             "buffer_load_dword %3, %7, %8 offen offset:768 lds\n\t"
+                             "buffer_load_dword %4, %7, %8 offen offset:1024 lds\n\t"
+                             "buffer_load_dword %5, %7, %8 offen offset:1280 lds"
+                             :: "v"(dvoff[0]), "v"(dvoff[1]), "v"(dvoff[2]), "v"(dvoff[3]), "v"(dvoff[4]), "v"(dvoff[DMAIN ? 5 : 0]), "s"(base), "s"(rs_x), "s"(so) : "memory");
+            }
+        }
+    };
     constexpr int NREG = NIN * (MASK ? 2 : 1) + 1;            // register loads of one issue(): younger than the DMA they follow
     auto commit = [&](int st) {
         float* lds_in = smem + st * stage_f;
@@ -174,19 +215,39 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
         else for (int i = tid; i < TBCK; i += 256) lds_sc[i] = 1.f;
     };
 
+    // DMAIN: the scale-table entries of a chunk travel through one register per thread and are written after the wait at the end of the chunk before
+    auto load_sc = [&](int c0) { rsc = __builtin_amdgcn_raw_buffer_load_b32(rs_s, scoff, (unsigned)(c0 * sizeof(float)), 0); };
+    auto store_sc = [&](int st) {
+        float* lds_sc = smem + st * stage_f + L.CK * L.plane + L.CK * KK * BM;
+        if (p.in_scale) { if (tid < TBCK) lds_sc[tid] = __uint_as_float(rsc); }
+        else for (int i = tid; i < TBCK; i += 256) lds_sc[i] = 1.f;
+    };
     dma_w(c_begin, 0);
-    issue(c_begin);
-    commit(0);
-    if (c_begin + L.CK < c_end) issue(c_begin + L.CK);
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREG) : "memory");      // the DMA (older than that issue) has landed
+    if constexpr (DMAIN) {
+        dma_in(c_begin, 0);
+        load_sc(c_begin);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        store_sc(0);
+    } else {
+        issue(c_begin);
+        commit(0);
+        if (c_begin + L.CK < c_end) issue(c_begin + L.CK);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREG) : "memory");      // the DMA (older than that issue) has landed
+    }
     __syncthreads();
     int st = 0;
     for (int c0 = c_begin; c0 < c_end; c0 += L.CK, st ^= 1) {
         const bool more = c0 + 2 * L.CK < c_end;
         if (c0 + L.CK < c_end) {
-            commit(st ^ 1);                                  // loads issued one whole chunk ago
-            dma_w(c0 + L.CK, st ^ 1);
-            if (more) issue(c0 + 2 * L.CK);                  // in flight during the MFMAs below and the next chunk's
+            if constexpr (DMAIN) {
+                dma_w(c0 + L.CK, st ^ 1);                    // (every wave is past the barrier that ended chunk c0 - CK: the other stage is free)
+                dma_in(c0 + L.CK, st ^ 1);
+                load_sc(c0 + L.CK);
+            } else {
+                commit(st ^ 1);                              // loads issued one whole chunk ago
+                dma_w(c0 + L.CK, st ^ 1);
+                if (more) issue(c0 + 2 * L.CK);              // in flight during the MFMAs below and the next chunk's
+            }
         }
         const float* lds_in = smem + st * stage_f;
         const float* lds_w = lds_in + L.CK * L.plane;
@@ -279,8 +340,13 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
                 }
             }
         }
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREG) : "memory");     // the next chunk's weights are in LDS; the register loads stay in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (DMAIN) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the next chunk's tile, weights and scales have landed (a chunk of MFMAs went by)
+            if (c0 + L.CK < c_end) store_sc(st ^ 1);
+        } else {
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NREG) : "memory");     // the next chunk's weights are in LDS; the register loads stay in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
     }
 
@@ -409,9 +475,19 @@ static int launch_convt(const l2i_conv_params& p, hipStream_t st) {
     L.planeS = L.IH * L.IWp;
     L.plane = (TB * L.planeS + 3) & ~3;
     L.rows_c = TB * L.IH;
+    L.nslots = 0;
+    static const bool dma_env = !(getenv("L2I_CONVT_DMA") && atoi(getenv("L2I_CONVT_DMA")) == 0);
+    const bool dma_in = dma_env && K == 3 && !p.in_mask && TB == 1 && Tx >= 32 && !(p.ksplit > 1 && p.ws) && L.IH * L.IW <= 6 * 64 &&
+                        (size_t)p.Cin * p.H * p.W * sizeof(float) < 0x7FFF0000ull;
+    if (dma_in) {                                         // dense planes, one per group of DMA slots; the pitch is fixed below once CK is known
+        L.IWp = L.IW;
+        L.planeS = L.IH * L.IW;
+        L.nslots = (L.planeS + 63) / 64;
+        L.plane = 6 * 64 + 32;                            // (upper bound for the CK computation: six slots of zeros / data, plus the bank padding)
+    }
     const size_t per_c = (size_t)(L.plane + KK * BM) * sizeof(float);
-    int ck = (int)((36 * 1024) / per_c);                  // per stage; two stages, two blocks per CU
-    const int ck_in = (12 * 256) / (L.rows_c * L.IW);
+    int ck = (int)(((dma_in && WN == 1 ? 24 : 36) * 1024) / per_c);      // per stage; two stages, two blocks per CU (three of the 128-position tile)
+    const int ck_in = dma_in ? 16 : (12 * 256) / (L.rows_c * L.IW);
     if (ck > ck_in) ck = ck_in;
     if (p.in_scale && ck > (256 >> L.tb_log2)) ck = 256 >> L.tb_log2;      // one scale-table entry per thread
     // channels per chunk: pairs (the two lane halves of an MFMA take one channel each); K == 3 walks two pairs per iteration.
@@ -432,20 +508,36 @@ static int launch_convt(const l2i_conv_params& p, hipStream_t st) {
             if ((per % ck) == 0) { L.ksplit = p.ksplit; L.cin_per = per; }
         }
     }
+    if (dma_in) {
+        // every slot of a plane is written whole (six instructions per plane: idle lanes write zeros), so the pitch is >= 384; the two lane halves of a
+        // fragment read are CK / 2 planes apart: pad until that distance is = 32 (mod 64) banks
+        int plane = 6 * 64;
+        while (((ck / 2) * plane) % 64 != 32 && plane < 6 * 64 + 64) ++plane;
+        if (((ck / 2) * plane) % 64 != 32) plane = 6 * 64 + 16;
+        L.plane = plane;
+    }
     L.CK = ck;
     L.in_elems = ck * L.rows_c * L.IW;
     L.w_vec = ck * KK * BM / 4;
     L.magic_iw = magic_of((unsigned)L.IW);
     L.magic_rc = magic_of((unsigned)L.rows_c);
     L.magic_ih = magic_of((unsigned)L.IH);
-    size_t lds = 2 * (per_c * ck + (size_t)(((ck << L.tb_log2) + 3) & ~3) * sizeof(float));
+    size_t lds = 2 * ((size_t)(L.plane + KK * BM) * sizeof(float) * ck + (size_t)(((ck << L.tb_log2) + 3) & ~3) * sizeof(float));
     if (lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     long grid = (long)L.bgroups * L.tiles_y * L.tiles_x * L.mblocks * L.ksplit;
     if (grid <= 0 || grid > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: grid too large");
     L.total = (int)grid;
     grid = (grid + 7) & ~7L;
+    if (lds > (dma_in ? 80 : 64) * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: tile cannot be staged");
+    if constexpr (K == 3) {
+        if (dma_in) L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_mfma_kernel<K, PAD, WN, false, true>),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    }
     if (p.in_mask) hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, true>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
-    else hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, false>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
+    else if constexpr (K == 3) {
+        if (dma_in) hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, false, true>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
+        else hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, false>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
+    } else hipLaunchKernelGGL((convt_mfma_kernel<K, PAD, WN, false>), dim3((unsigned)grid), dim3(256), lds, st, p, L);
     L2I_CHECK_LAUNCH();
     if (L.ksplit > 1) {                                 // second pass: sum the partials, out_scale / out_gain (l2i_conv.hip)
         l2i_conv_params q = p;

@@ -67,8 +67,15 @@ def loss_scale_for(resolution, batch):
 
 
 # exponents at 256^2, batch 1, and their growth per doubling of the resolution (tools/bf16_study.py --probe, profiles/r05_fp16_gradient_ranges.txt)
-F16_SCALE_BASE = dict(R=0, V=0, D=0, G=0)
-F16_SCALE_RES = dict(R=0, V=0, D=0, G=0)
+# measured largest map of a branch (log2, one attribute; five attributes ~1 lower): R -(9 + lb + 2 (lr - 8)), VGG content -(22 + lb + 2 (lr - 8)) (up to
+# 1.7 above that at 1024^2 batch 8), D -(11 .. 14.5) at its 8^2 end falling 1.75 octaves per block towards the image (14 octaves at 1024^2: the
+# discriminator's backward therefore also doubles the gradient once per block, F16_D_BLOCK_GAIN), G -(8 .. 10.4) at its 4^2 end falling 10 octaves
+# towards the image; lb = log2(batch), lr = log2(resolution).  The scales put the largest map of each branch near 2^5: eleven octaves below fp16's
+# 2^16 (the first choice, 2^8 .. 2^11, went non-finite after ~100 bench steps: the magnitudes move by a few octaves with the alpha draw and the
+# sample), with the MEDIAN of the smallest maps (G at the image end, 1024^2 batch 8) at 2^-10.5: normal numbers (>= 2^-14) throughout.
+F16_SCALE_BASE = dict(R=14, V=26, D=16, G=12)
+F16_SCALE_RES = dict(R=2, V=2, D=0, G=0)
+F16_D_BLOCK_GAIN = 2.0
 
 
 def _gs(net, key):
@@ -326,22 +333,23 @@ class _DBody16Fn(torch.autograd.Function):
         if saved is None:
             raise RuntimeError('discriminator was run without a differentiable input')
         S = _gs(net, 'D')
+        bg = F16_D_BLOCK_GAIN if S != 1.0 else 1.0        # fp16: the gradient is doubled once per block on both branches (undone with S at the image)
         g = K16.cast_to_h8(g32.contiguous() * S if S != 1.0 else g32.contiguous(), dtype=net.dtype)
         for blk, (y1, y2, in_hw) in zip(reversed(net.blocks), reversed(saved[1:])):
             _probe('D.g@%d' % in_hw[0], g)
             h = in_hw[0]
-            gm = K16.mask_mul(g, y2, 1.0, 0.2)                                    # 1/sqrt2 * lrelu' * sqrt2 on the conv2 branch (g also feeds the skip branch)
+            gm = K16.mask_mul(g, y2, bg, 0.2 * bg)                                # 1/sqrt2 * lrelu' * sqrt2 on the conv2 branch (g also feeds the skip branch)
             g_t = blk['c2'].dgrad(gm, (h + 1, h + 1))
             del gm
             g_y1 = K16.upfirdn2d(g_t, blk['kf'], pad=(1, 1, 1, 1), mask=y1, mask_vals=LRELU_MASK, sep=blk['kfsep'])
             del g_t
             g_a = blk['c1'].dgrad(g_y1, in_hw)
             del g_y1
-            g_ts = blk['sk1'].dgrad(g, (h // 2, h // 2), out_gain=1.0 / SQRT2)
+            g_ts = blk['sk1'].dgrad(g, (h // 2, h // 2), out_gain=bg / SQRT2)
             g = K16.upfirdn2d(g_ts, blk['kf'], up=2, pad=(2, 1, 2, 1), addend=g_a, sep=blk['kfsep'])      # adjoint of (blur, every second pixel): zero-insertion FIR
             del g_ts, g_a
         _probe('D.g_last', g)
-        g_img = net.conv0.dgrad(K16.mask_mul(g, saved[0], *LRELU_MASK), ctx.in_hw, out_f32=True, out_gain=1.0 / S)
+        g_img = net.conv0.dgrad(K16.mask_mul(g, saved[0], *LRELU_MASK), ctx.in_hw, out_f32=True, out_gain=1.0 / (S * bg ** len(net.blocks)))
         ctx.saved = None
         return g_img, None
 

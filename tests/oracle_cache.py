@@ -30,6 +30,13 @@ CASES = {
     'g1024': dict(size=1024, batch=1, attrs=['Smiling'], z_seed=12, alpha=lambda: np.ones((1, 1)) * 0.41, clamp=False, bounded=True, f64=True),
     'c5': dict(size=1024, batch=1, attrs=SCENE5, scene=True, z_seed=15, alpha=lambda: np.ones((1, 5)) * np.random.RandomState(16).uniform(-1, 1, 5), clamp=True,
                bounded=True, f64=True),
+    # [r5] the 16-bit path's step tests (tools/bf16_study.py:step: five scene attributes, clamp flow) at their three sizes: float64 evaluations
+    's64': dict(size=64, batch=4, attrs=SCENE5, scene=True, z_seed=21, alpha=lambda: np.ones((4, 5)) * np.random.RandomState(22).uniform(-1, 1, 5), clamp=True,
+                bounded=True, f64=True),
+    's256': dict(size=256, batch=2, attrs=SCENE5, scene=True, z_seed=21, alpha=lambda: np.ones((2, 5)) * np.random.RandomState(22).uniform(-1, 1, 5), clamp=True,
+                 bounded=True, f64=True),
+    's1024': dict(size=1024, batch=1, attrs=SCENE5, scene=True, z_seed=21, alpha=lambda: np.ones((1, 5)) * np.random.RandomState(22).uniform(-1, 1, 5), clamp=True,
+                  bounded=True, f64=True),
 }
 ATTR_IDX = {'Smiling': 31, 'Young': 39, 'Male': 20, 'Eyeglasses': 15, 'Bangs': 5}
 

@@ -12,12 +12,24 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
+@pytest.fixture(autouse=True, params=['bf16', 'f16'])
+def elem(request):
+    """[r5] Every KERNEL test of this file runs on both element types of the h8 path: bf16 (l2i_*_h8) and IEEE fp16 (l2i_*_h8_f16, the same sources
+    compiled with another element type).  conv.PRECISION selects the type new h8 tensors / weight planes get; the references round with the same
+    type.  The network- and step-level tests below carry their precision in their name and run once."""
+    if request.param == 'f16' and request.node.name.startswith(('test_bf16_', 'test_fp16_', 'test_train_multi_attr_cli')):
+        pytest.skip('named-precision test: runs once')
+    old, conv.PRECISION = conv.PRECISION, request.param
+    yield request.param
+    conv.PRECISION = old
+
+
 def T(a):
     return torch.from_numpy(np.ascontiguousarray(a)).float()
 
 
 def bf(x):
-    return x.to(torch.bfloat16).to(torch.float64)
+    return x.to(conv.h8_dtype()).to(torch.float64)
 
 
 def close16(got, want, what=''):
@@ -46,7 +58,7 @@ def test_conv_h8_forward_and_dgrad(case):
     hc = conv.H8Conv(wt, stride, pad, transposed=tr, device=DEV)
     y = hc.forward(conv.to_h8(x.to(DEV), 32))
     torch.cuda.synchronize()
-    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (b, (cout + 7) // 8, ref.shape[2], ref.shape[3], 8)
+    assert y.dtype == conv.h8_dtype() and tuple(y.shape) == (b, (cout + 7) // 8, ref.shape[2], ref.shape[3], 8)
     close16(conv.from_h8(y, cout), ref.detach(), 'forward')
     if cout % 32 == 0 and not (k == 1 and stride == 2):       # the gradient's input tensor carries the conv's Cout channels: whole 32-channel chunks
                                                               # (a strided 1x1's gradient is a compact 1x1 conv + zero insertion: regressor16)
@@ -102,7 +114,7 @@ def test_conv_h8_epilogue_fusions_and_fp32_output():
 # ---- streaming companions (csrc/l2i_stream_h8.hip) against torch on the bf16-rounded operands ---------------------------------------------------
 def rb(x):
     """what an h8 tensor holds of x."""
-    return x.to(torch.bfloat16).float()
+    return x.to(conv.h8_dtype()).float()
 
 
 def test_h8_layout_casts():
@@ -277,21 +289,48 @@ def test_bf16_networks_vs_float64_oracle(size):
     assert max(r['V_loss_rel']) < 4e-3 and r['V_grad_cos'] > 0.99 and r['V_grad_l2'] < 0.13      # (content terms: 3e-4 at 64^2, 1.9e-3 at 256^2)
 
 
+def _cached_step(precision, size, batch):
+    """tools/bf16_study.py:step for BASELINE config 5's flow against the float64 oracle evaluation of tests/golden/oracle_1024.npz (cases s64 / s256 /
+    s1024: the same seeds; [r5] the oracle used to be re-evaluated on every run, 8 - 36 s per case)."""
+    from latent2im_amd import conv
+    from tests import oracle_cache
+    from tests.conftest import GOLDEN
+    st = _study()
+    case = oracle_cache.CASES['s%d' % size]
+    assert (case['batch'], case['z_seed']) == (batch, 21)
+    old, st.PRECISION = conv.PRECISION, precision
+    try:
+        return st.step(size, batch, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], True, 'scene', cached=oracle_cache.load(GOLDEN, 's%d' % size))
+    finally:
+        conv.PRECISION = old
+
+
 @pytest.mark.parametrize('size,batch', [(64, 4), (256, 2), (1024, 1)])
 def test_bf16_training_step_vs_float64_oracle(size, batch):
     """BASELINE config 5's step (SceneGraph, five attributes, clamp flow) on the 16-bit path at 64^2, 256^2 and 1024^2 against the float64 oracle."""
-    from latent2im_amd import conv
-    old = conv.PRECISION
-    try:
-        r = _study().step(size, batch, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], True, 'scene')
-    finally:
-        conv.PRECISION = old
+    r = _cached_step('bf16', size, batch)
     print(r)
     assert r['x0_relmax'] < 4e-2 and r['x1_relmax'] < 4e-2
     assert r['a0_absmax'] < 2e-3 and r['eps_absmax'] < 2e-3
     assert r["loss_rel"] < 5e-3 and r["reg_rel"] < 5e-3 and r["gan_rel"] < 2e-2          # (the GAN term passes nine bf16 residual blocks at 1024^2: measured 8e-3 there)
     assert max(r['per_attr_reg_loss_delta']) < 1e-3
     assert r['grad_cos'] > 0.97 and r['grad_l2'] < 0.27, (r['grad_cos'], r['grad_l2'])
+
+
+@pytest.mark.parametrize('size,batch', [(64, 4), (256, 2), (1024, 1)])
+def test_fp16_training_step_vs_float64_oracle(size, batch):
+    """[r5] The same step with IEEE fp16 h8 maps (conv.PRECISION = 'f16': BASELINE configs[4] says "fp16 MFMA") and the static power-of-two gradient
+    scales of nets16.loss_scale_for.  Three more mantissa bits than bf16: the contract is an order of magnitude tighter — measured (profiles/
+    r05_fp16_tolerance.json) images 1.1e-3 / 1.4e-3 / 2.2e-3 of the largest pixel, alpha 5e-5, losses 1e-4, GAN term 1e-3, per-attribute regressor
+    loss 5e-5, walk gradient cosine 0.9997 / 0.9999 / 0.9999 and relative L2 0.025 / 0.017 / 0.031 (bf16: 0.997 / 0.993 / 0.983 and 0.09 / 0.12 / 0.19)."""
+    r = _cached_step('f16', size, batch)
+    print(r)
+    assert r['finite']
+    assert r['x0_relmax'] < 6e-3 and r['x1_relmax'] < 6e-3
+    assert r['a0_absmax'] < 2e-4 and r['eps_absmax'] < 2e-4
+    assert r["loss_rel"] < 5e-4 and r["reg_rel"] < 5e-4 and r["gan_rel"] < 4e-3
+    assert max(r['per_attr_reg_loss_delta']) < 2e-4
+    assert r['grad_cos'] > 0.998 and r['grad_l2'] < 0.06, (r['grad_cos'], r['grad_l2'])
 
 
 def test_bf16_hipgraph_replay_matches_eager_1024_batch8():

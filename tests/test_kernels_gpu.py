@@ -153,7 +153,8 @@ def test_conv_prologue_epilogue_fusions():
                                                      (64, 3, 7, 3, False, 32, 32, 2), (512, 512, 3, 0, True, 4, 4, 3), (16, 32, 3, 0, False, 9, 9, 2),
                                                      (512, 96, 3, 0, True, 8, 8, 8), (256, 64, 3, 0, True, 16, 16, 4), (64, 256, 3, 0, False, 17, 17, 8),   # these three: split-K
                                                      (20, 40, 3, 0, True, 33, 31, 2), (6, 40, 3, 0, True, 12, 12, 2), (136, 32, 3, 1, False, 40, 40, 1),    # Cin % 8 != 0; Cin % 4 != 0 (not fused)
-                                                     (3, 64, 7, 3, False, 128, 96, 2), (3, 44, 7, 3, False, 72, 40, 1), (2, 16, 7, 3, False, 70, 66, 1)])   # stem gradient onto <= 3 channels: the small-output kernel (several tiles; a partial channel chunk; odd gradient width: per-parity launches)
+                                                     (3, 64, 7, 3, False, 128, 96, 2), (3, 44, 7, 3, False, 72, 40, 1), (2, 16, 7, 3, False, 70, 66, 1),
+                                                     (64, 48, 3, 0, True, 40, 48, 2), (128, 64, 3, 0, True, 64, 64, 1), (32, 32, 3, 0, True, 35, 70, 3), (256, 96, 3, 0, True, 32, 32, 2)])   # [r5] maps >= 32 positions wide, unmasked: the DMA-input variant; before them: stem gradient onto <= 3 channels: the small-output kernel (several tiles; a partial channel chunk; odd gradient width: per-parity launches)
 def test_fused_transposed_conv_matches_per_parity_launches(cin, cout, k, pad, tr, h, w, b):
     """One-launch stride-2 transposed conv (l2i_conv_transpose2d_f32) == the four per-parity l2i_conv2d_f32 launches == torch."""
     rs = np.random.RandomState(cin + cout + h)

@@ -58,6 +58,11 @@ def _train(precision, size, batch, steps, attrs, clamp, transform, lr=1e-3):
         conv.PRECISION = old
 
 
+# [r5] displacement bounds of the fp16 path (three more mantissa bits than bf16): measured values + margin, profiles/r05_trajectory.txt
+FP16_COS = {64: 0.99, 256: 0.98}
+FP16_L2 = {64: 0.15, 256: 0.2}
+
+
 def _cos(a, b):
     a, b = a.reshape(-1), b.reshape(-1)
     return float(torch.dot(a, b) / (a.norm() * b.norm()))
@@ -74,6 +79,7 @@ def test_bf16_training_trajectory_lands_where_fp32_does(size, batch, steps, attr
         a = _train('f32', size, batch, steps, attrs, clamp, transform)
         b = _train('bf16', size, batch, steps, attrs, clamp, transform)
         y = _train('bf16x3', size, batch, steps, attrs, clamp, transform)         # the yardstick: fp32-class arithmetic, another rounding pattern
+        h = _train('f16', size, batch, steps, attrs, clamp, transform)            # [r5] IEEE fp16 elements with static gradient scales
     finally:
         constants.resolution, constants.BATCH_SIZE = 256, 4
     da, db, dy = a['w'] - a['w0'], b['w'] - b['w0'], y['w'] - y['w0']
@@ -85,6 +91,11 @@ def test_bf16_training_trajectory_lands_where_fp32_does(size, batch, steps, attr
           '%.4f), rel L2 %.3f; per-attr reg loss f32 %s bf16 %s (max delta %.2e, yardstick %.2e); last training loss f32 %.5f bf16 %.5f'
           % (size, steps, len(attrs), moved, cos_w, cos, cos_y, float((da - db).norm() / da.norm()), [round(float(v), 5) for v in a['per_attr']],
              [round(float(v), 5) for v in b['per_attr']], float(delta.max()), float((a['per_attr'] - y['per_attr']).abs().max()), a['losses'][-1], b['losses'][-1]))
+    dh = h['w'] - h['w0']
+    cos_h, l2_h, delta_h = _cos(da, dh), float((da - dh).norm() / da.norm()), (a['per_attr'] - h['per_attr']).abs()
+    print('   fp16 vs f32: displacement cosine %.4f, rel L2 %.3f, per-attr reg loss max delta %.2e, finite %s' % (cos_h, l2_h, float(delta_h.max()), bool(torch.isfinite(h['w']).all())))
+    assert bool(torch.isfinite(h['w']).all()) and float(delta_h.max()) < 2e-4, delta_h          # the fp16 walk stays finite over the whole run (static scales: nothing checks at run time)
+    assert cos_h >= FP16_COS[size] and l2_h <= FP16_L2[size], (cos_h, l2_h)
     assert torch.equal(a['w0'], b['w0'])
     assert moved > 0.15                                   # the walk really trained (lr 1e-3: Adam moves a coordinate by at most 0.1 in 100 steps; |w0| ~ 0.02 each)
     assert float(delta.max()) < 1e-3, delta

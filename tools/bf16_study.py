@@ -37,8 +37,8 @@ def l2rel(a, b):
 def networks(size, batch):
     from latent2im_amd import nets16
     conv.PRECISION = PRECISION
-    if PRECISION == 'f16':
-        nets16.LOSS_SCALE_LOG2.update(nets16.loss_scale_for(size, batch))
+    if PRECISION == 'f16':                                  # the networks are driven by unit-scale random upstream gradients here, not by the loss: no scaling
+        nets16.LOSS_SCALE_LOG2.update(dict(R=0, V=0, D=0, G=0))
     out = dict(case='networks', precision=PRECISION, size=size, batch=batch)
     dt = torch.float64
     rs = np.random.RandomState(size)
@@ -122,7 +122,9 @@ def probe(size, batch, attrs, clamp, transform='face'):
     constants.resolution, constants.BATCH_SIZE = 256, 4
 
 
-def step(size, batch, attrs, clamp, transform='face'):
+def step(size, batch, attrs, clamp, transform='face', cached=None):
+    """One training step on the 16-bit path against the float64 oracle.  ``cached``: a tests.oracle_cache.Cached case holding that oracle evaluation
+    (the GPU tests pass the committed one instead of spending 8 - 36 s of CPU per case; image errors are then taken at its 4096 probe pixels)."""
     from latent2im_amd import constants
     conv.PRECISION = PRECISION
     gr = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform=transform)
@@ -132,16 +134,22 @@ def step(size, batch, attrs, clamp, transform='face'):
     r = selfcheck.run_step(gr, zs, alpha, clamp=clamp, optimize=False)
     torch.cuda.synchronize()
     dt = torch.float64
-    nets = dict(G=ostep.to_torch(synth.generator_state(size, seed=100), dt), D=ostep.to_torch(synth.discriminator_state(size, seed=200), dt),
-                R=ostep.to_torch(synth.resnet50_state(seed=300), dt), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400), dt))
-    o = ostep.train_step_bounded(nets, T(synth.walk_init(len(attrs), gr.module.netG.n_latent, seed=7)).to(dt), T(zs).to(dt), T(alpha).to(dt), gr.attrIdx, clamp_variant=clamp)
     idx = gr.attrIdx
     pg = gr.regressor(r['x1'])[:, idx].double().cpu()
-    po = onets.resnet50_forward(nets['R'], o['x1'])[:, idx].double()
+    if cached is not None:
+        o = cached
+        po = o['po'].double()
+        img = dict(x0_relmax=o.image_rel_to_max(r['x0'], 'x0'), x1_relmax=o.image_rel_to_max(r['x1'], 'x1'))
+    else:
+        nets = dict(G=ostep.to_torch(synth.generator_state(size, seed=100), dt), D=ostep.to_torch(synth.discriminator_state(size, seed=200), dt),
+                    R=ostep.to_torch(synth.resnet50_state(seed=300), dt), V=ostep.to_torch(synth.vgg19_prefix_state(seed=400), dt))
+        o = ostep.train_step_bounded(nets, T(synth.walk_init(len(attrs), gr.module.netG.n_latent, seed=7)).to(dt), T(zs).to(dt), T(alpha).to(dt), gr.attrIdx, clamp_variant=clamp)
+        po = onets.resnet50_forward(nets['R'], o['x1'])[:, idx].double()
+        img = dict(x0_relmax=rel(r['x0'], o['x0']), x1_relmax=rel(r['x1'], o['x1']), x1_l2=l2rel(r['x1'], o['x1']))
     tgt = o['target'].double()
     per_attr = lambda p: -(tgt * p.clamp(min=1e-12).log() + (1 - tgt) * (1 - p).clamp(min=1e-12).log()).mean(0)
     out = dict(case='step', precision=PRECISION, size=size, batch=batch, attrs=len(attrs), clamp=clamp, finite=bool(torch.isfinite(r['grad']).all() and torch.isfinite(r['x1']).all()),
-               x0_relmax=rel(r['x0'], o['x0']), x1_relmax=rel(r['x1'], o['x1']), x1_l2=l2rel(r['x1'], o['x1']),
+               **img,
                a0_absmax=float((r['a0'].double().cpu() - o['alpha_org']).abs().max()), eps_absmax=float((r['eps'].double().cpu() - o['eps']).abs().max()),
                reg_rel=abs(float(r['terms']['reg']) - float(o['reg'])) / abs(float(o['reg'])), cont_rel=abs(float(r['terms']['cont']) - float(o['cont'])) / abs(float(o['cont'])),
                gan_rel=abs(float(r['terms']['gan']) - float(o['gan'])) / abs(float(o['gan'])), loss_rel=abs(float(r['loss']) - float(o['loss'])) / abs(float(o['loss'])),

@@ -21,20 +21,21 @@ import json
 import os
 import sys
 
-CONV = ('conv_wino_kernel', 'conv_wino4_kernel', 'conv_mfma_kernel', 'gemm1x1_kernel', 'convt_mfma_kernel', 'conv_direct_small_kernel',
+CONV = ('conv_wino_kernel', 'conv_wino4_kernel', 'conv_wino4s_kernel', 'conv_mfma_kernel', 'conv3x3s2_dma_kernel', 'gemm1x1_kernel', 'convt_mfma_kernel', 'conv_direct_small_kernel',
         'conv_bf16x3_pipe_kernel', 'conv_cin3_kernel', 'splitk_epilogue_kernel', 'conv_h8_kernel')
 WORKLOADS = {'c3': [1024, 8, ['Smiling'], 'f32', False],
-             'c5': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'bf16', False],
+             'c5': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'f16', False],        # [r5] config 5 runs fp16 elements
+             'c5bf16': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'bf16', False],
              'c5x3': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'bf16x3', False]}
 
 
 def family_of(kernel):
     """rocprof kernel name -> the family names of latent2im_amd.conv.FAMILY_INFO."""
-    if kernel.startswith('conv_wino4_kernel'):
+    if kernel.startswith('conv_wino4_kernel') or kernel.startswith('conv_wino4s_kernel'):
         return 'winograd4_f32'
     if kernel.startswith('conv_wino_kernel'):
         return 'winograd_f32'
-    if kernel.startswith('conv_mfma_kernel') or kernel.startswith('splitk_epilogue'):
+    if kernel.startswith('conv_mfma_kernel') or kernel.startswith('conv3x3s2_dma_kernel') or kernel.startswith('splitk_epilogue'):
         return 'implicit_gemm_f32'
     if kernel.startswith('gemm1x1_kernel'):
         return 'gemm1x1_f32'
@@ -57,7 +58,10 @@ def load(d, name):
     out = {}
     for r in csv.DictReader(open('%s/run_counter_collection.csv' % d)):
         if r['Counter_Name'] == name:
-            out[int(r['Dispatch_Id'])] = (r['Kernel_Name'].split('(')[0].replace('void ', ''), int(r['Grid_Size']), float(r['Counter_Value']) * 1024.0)
+            name = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            for ns in ('l2i_h8_bf16::', 'l2i_h8s_bf16::', 'l2i_h8_f16::', 'l2i_h8s_f16::'):      # [r5] the h8 kernels live in per-element-type namespaces
+                name = name.replace(ns, '')
+            out[int(r['Dispatch_Id'])] = (name, int(r['Grid_Size']), float(r['Counter_Value']) * 1024.0)
     return out
 
 

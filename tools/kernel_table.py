@@ -13,7 +13,10 @@ import sys
 
 
 def short(n):
-    return n.replace('void ', '').split('(')[0]
+    n = n.replace('void ', '').split('(')[0]
+    for ns in ('l2i_h8_bf16::', 'l2i_h8s_bf16::', 'l2i_h8_f16::', 'l2i_h8s_f16::'):      # [r5] per-element-type namespaces of the h8 kernels
+        n = n.replace(ns, '')
+    return n
 
 
 def main(stats_csv, traffic_json, sq_csv, dst, steps_in_stats=12):
