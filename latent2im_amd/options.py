@@ -49,7 +49,9 @@ class TrainOptions:
                        help='record forward+backward of the step once and replay it from one hipGraph per iteration (static batch size)')
         p.add_argument('--precision', type=str, default=None, choices=['f32', 'bf16x3', 'bf16', 'f16'],
                        help='matrix path of the frozen networks: exact fp32 MFMA (default), the 3-term bf16 split on fp32 tensors (fp32 accuracy), '
-                            'or the 16-bit path (bf16 feature maps in HBM, one bf16 MFMA per MAC, fp32 accumulation; BASELINE config 5)')
+                            'or the 16-bit path (16-bit feature maps in HBM, one 16-bit MFMA per MAC, fp32 accumulation; BASELINE config 5): '
+                            'f16 = IEEE fp16 elements with static power-of-two gradient scales (gradient within 3 %% of float64), bf16 = bfloat16 elements')
+        p.add_argument('--no_gc_freeze', action='store_true', help='do not move the host objects to the garbage collector\'s permanent generation after the first step')
         p.add_argument('--synthetic_weights', action='store_true',
                        help='run on seeded random-init G / regressor / VGG when the checkpoint paths of constants.py do not exist '
                             '(default: a missing checkpoint is an error, as in the reference)')

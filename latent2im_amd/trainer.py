@@ -82,6 +82,18 @@ def _captured_batch(graphs, zs_batch):
 
 def train(graphs, graph_inputs, output_dir, attrList, layers=None, save_freq=100, trainEmbed=False, updateGAN=False,
           opt=None, multi_attr=False):
+    """train.py:25-134.  Side effect on the host process, undone on return: after the first step every Python object alive is moved to the
+    garbage collector's permanent generation (``gc.freeze``: a full collection over the networks' ~270 000 host objects takes 73 ms on the thread
+    that launches the step's kernels); ``gc.unfreeze()`` runs in a ``finally`` when training ends, so a caller that drops
+    this graph and builds another (notebooks, eval, tests) keeps a working cycle collector.  ``opt.no_gc_freeze`` switches the freeze off."""
+    try:
+        return _train(graphs, graph_inputs, output_dir, attrList, layers, save_freq, trainEmbed, updateGAN, opt, multi_attr)
+    finally:
+        import gc
+        gc.unfreeze()
+
+
+def _train(graphs, graph_inputs, output_dir, attrList, layers, save_freq, trainEmbed, updateGAN, opt, multi_attr):
     is_main = dist.rank() == 0
     if is_main:
         os.makedirs(os.path.join(output_dir, 'results'), exist_ok=True)
@@ -109,7 +121,7 @@ def train(graphs, graph_inputs, output_dir, attrList, layers=None, save_freq=100
             s = slice(batch_start, min(num_samples, batch_start + batch_size))
             zs_batch = hostutil.batch_input(graph_inputs, s)['z'][sl]
             loss, at, out_zs, transformed = train_step(graphs, zs_batch, attrList, layers, trainEmbed, updateGAN, opt, multi_attr)
-            if epoch == 0 and i == 0:
+            if epoch == 0 and i == 0 and not (opt is not None and getattr(opt, 'no_gc_freeze', False)):
                 from . import capture
                 capture.freeze_host_objects()                 # everything built lazily by the first step is long-lived: out of the collector's way
             if sync_log:

@@ -37,7 +37,7 @@ def test_train_options_match_reference_namespace():
         assert str(mine[k]) == str(v) if not isinstance(v, dict) else mine[k] == v, (k, mine[k], v)
     assert opt.output_dir == './models_celeba/stylegan_v2_real_face_linear_lr0.0001_l2_w'
     extra = set(mine) - set(ref)
-    assert extra <= {'resolution', 'batch_size', 'n_epoch', 'max_iters', 'seed', 'no_log_sync', 'synthetic_weights', 'hip_graph', 'precision'}      # additive flags only
+    assert extra <= {'resolution', 'batch_size', 'n_epoch', 'max_iters', 'seed', 'no_log_sync', 'synthetic_weights', 'hip_graph', 'precision', 'no_gc_freeze'}      # additive flags only
 
 
 def test_yaml_config_and_cli_precedence(tmp_path):

@@ -59,8 +59,8 @@ def _train(precision, size, batch, steps, attrs, clamp, transform, lr=1e-3):
 
 
 # [r5] displacement bounds of the fp16 path (three more mantissa bits than bf16): measured values + margin, profiles/r05_trajectory.txt
-FP16_COS = {64: 0.99, 256: 0.98}
-FP16_L2 = {64: 0.15, 256: 0.2}
+FP16_COS = {64: 0.99, 256: 0.99}                # measured 0.9984 / 0.9958 (64^2, one / five attributes), 0.9980 (256^2)
+FP16_L2 = {64: 0.13, 256: 0.1}                  # measured 0.056 / 0.091, 0.063
 
 
 def _cos(a, b):
@@ -70,8 +70,8 @@ def _cos(a, b):
 
 @pytest.mark.parametrize('size,batch,steps,attrs,clamp,transform,cos_min,l2_max', [
     (64, 4, 100, ['Smiling'], False, 'face', 0.98, 0.19),
-    (64, 4, 100, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], True, 'scene', 0.96, 0.29),
-    (256, 4, 30, ['Smiling', 'Young'], False, 'face', 0.93, 0.38),
+    (64, 4, 100, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], True, 'scene', 0.955, 0.30),      # (round 5 re-run: 0.968 / 0.253)
+    (256, 4, 30, ['Smiling', 'Young'], False, 'face', 0.925, 0.40),                                             # (round 5 re-run: 0.939 / 0.344)
 ])
 def test_bf16_training_trajectory_lands_where_fp32_does(size, batch, steps, attrs, clamp, transform, cos_min, l2_max):
     from latent2im_amd import constants
