@@ -231,6 +231,14 @@ int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64_t major, i
                       int channels, const float* noise, float noise_w, const float* bias, const float* addend,
                       int act, float act_slope, float act_gain, void* stream);
 
+/* [r5] The same op with one more fused term, y *= (mask[idx] > 0 ? mask_pos : mask_neg) after the activation: a gradient that passes a (leaky) ReLU on its
+ * way out of the FIR (the discriminator's backward, networks.py:530-536 / 574-583: the 3x3 gradient conv that follows then needs no mask operand and
+ * takes the Winograd F(4x4) kernel).  mask is shaped like y.  NULL mask = l2i_upfirdn2d_f32. */
+int l2i_upfirdn2d_masked_f32(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw,
+                             int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                             int channels, const float* noise, float noise_w, const float* bias, const float* addend,
+                             int act, float act_slope, float act_gain, const float* mask, float mask_pos, float mask_neg, void* stream);
+
 /* upfirdn2d for half tensors (upfirdn2d_kernel.cu:225 dispatches half too): plain reference op, no fused epilogue.  y / x / k point to IEEE
  * binary16; like the reference kernel the taps and products are float and the accumulator is rounded to half after every tap, taps in
  * ascending input row / column order (upfirdn2d_kernel.cu:118-123): bit-identical results. */

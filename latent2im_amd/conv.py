@@ -27,10 +27,11 @@ def h8_dtype():
 
 USE_WINOGRAD = _os.environ.get('L2I_WINOGRAD', '1') != '0'    # 3x3 stride-1 layers on maps >= 32 wide take the F(2x2,3x3) fp32 kernel
 # [r4] Winograd F(4x4,3x3) (csrc/l2i_wino4.hip: 1.78x fewer MFMAs than F(2x2), error ~1e-6..1e-5 of max|y| instead of 3e-7) for the unmasked 3x3
-# stride-1 launches on maps >= 64 wide: 'all' = every eligible launch on the [r5] position-split kernel, 'r4' = the same launches on the round-4
+# stride-1 launches on maps >= 32 wide ([r5]: 32 x 16-pixel tiles below 64): 'all' = every eligible launch on the [r5] position-split kernel, 'r4' = those >= 64 wide on the round-4
 # kernel (kept for A/B runs: the two are bit-identical), 'off' = F(2x2) everywhere.  The parity suite runs 'all' and 'off'.
 WINO4_MODES = ('all', 'r4', 'off')
 WINO4 = _os.environ.get('L2I_WINO4', 'all')
+WINO4_R4_MIN_W = 64      # narrowest map the 'r4' mode sends to the round-4 kernel (its tile is 64 wide; the bit-identity test lowers this)
 if WINO4 not in WINO4_MODES:
     raise ValueError('L2I_WINO4 must be one of %s, got %r' % (WINO4_MODES, WINO4))
 SPLIT_K = _os.environ.get('L2I_SPLIT_K', '1') != '0'    # 4x4 .. 16x16 maps: cut Cin into ranges computed by separate blocks (l2i.h: ksplit / ws)
@@ -418,7 +419,7 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
     elif (USE_WINOGRAD and L.kh == 3 and L.kw == 3 and L.stride == 1 and L.step == 1 and L.w_src is not None and L.cout > 4 and OW >= 32
           and OW % 4 == 0 and tile_hint == 0 and _wino_aligned(y, residual, res_mask, out_mask, noise, res_sub)):
         relu_in = in_mask is not None and in_mask.data_ptr() == x.data_ptr() and tuple(mask) == (1.0, 0.0)
-        if (WINO4 != 'off' and OW >= 64 and (in_mask is None or relu_in) and L.pad_x == 1 and W % 4 == 0 and cin % 4 == 0
+        if (WINO4 != 'off' and OW >= (WINO4_R4_MIN_W if WINO4 == 'r4' else 32) and (in_mask is None or relu_in) and L.pad_x == 1 and W % 4 == 0 and cin % 4 == 0
                 and cin * H * W * 4 < 0x7FFF0000):             # (one sample below 2 GiB: the kernel's out-of-range sentinel)
             pk = L.wino4_pack()
             p.w, p.CoutP = _lib.fptr(pk), pk.shape[1] * 16

@@ -93,6 +93,7 @@ struct UfdParams {
     float* y; const float* x; const float* k;
     long long major; int in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w;
     int channels; const float* noise; float noise_w; const float* bias; const float* addend; int act; float slope, gain;
+    const float* mask; float mask_pos, mask_neg;       // [r5] l2i_upfirdn2d_masked_f32: y *= (mask > 0 ? mask_pos : mask_neg) after the activation (a gradient through a (leaky) ReLU)
 };
 
 // one thread = one output pixel; a block covers a 16x64 output tile of one map so that the <=19x67 input footprint is
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UfdParams p) {
             if (p.addend) v += p.addend[oidx];
             if (p.act == L2I_ACT_LRELU) v = (v > 0.f ? v : v * p.slope) * p.gain;
             else if (p.act == L2I_ACT_RELU) v = v > 0.f ? v : 0.f;
+            if (p.mask) v *= p.mask[oidx] > 0.f ? p.mask_pos : p.mask_neg;
             p.y[oidx] = v;
         }
     }
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_k4_kernel(const UfdParams p) {
                     if (p.addend) o[q] += p.addend[obase + q];
                     if (p.act == L2I_ACT_LRELU) o[q] = (o[q] > 0.f ? o[q] : o[q] * p.slope) * p.gain;
                     else if (p.act == L2I_ACT_RELU) o[q] = o[q] > 0.f ? o[q] : 0.f;
+                    if (p.mask) o[q] *= p.mask[obase + q] > 0.f ? p.mask_pos : p.mask_neg;
                 }
             }
             if (ox + 3 < p.out_w && ((obase & 3) == 0) && (((uintptr_t)p.y & 15) == 0)) {
@@ -433,14 +436,40 @@ __global__ __launch_bounds__(256) void upfirdn2d_k4_stream_kernel(const UfdParam
             if (p.act == L2I_ACT_LRELU) o[q] = (o[q] > 0.f ? o[q] : o[q] * p.slope) * p.gain;
             else if (p.act == L2I_ACT_RELU) o[q] = o[q] > 0.f ? o[q] : 0.f;
         }
+        if (p.mask) {
+            const float4 mk = *reinterpret_cast<const float4*>(p.mask + obase);
+            o[0] *= mk.x > 0.f ? p.mask_pos : p.mask_neg; o[1] *= mk.y > 0.f ? p.mask_pos : p.mask_neg;
+            o[2] *= mk.z > 0.f ? p.mask_pos : p.mask_neg; o[3] *= mk.w > 0.f ? p.mask_pos : p.mask_neg;
+        }
         *reinterpret_cast<float4*>(p.y + obase) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
+
+static int upfirdn2d_launch(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw,
+                            int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                            int channels, const float* noise, float noise_w, const float* bias, const float* addend,
+                            int act, float act_slope, float act_gain, const float* mask, float mask_pos, float mask_neg, void* stream);
 
 extern "C" int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw,
                                  int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                                  int channels, const float* noise, float noise_w, const float* bias, const float* addend,
                                  int act, float act_slope, float act_gain, void* stream) {
+    return upfirdn2d_launch(y, x, k, major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, channels, noise, noise_w, bias, addend,
+                            act, act_slope, act_gain, nullptr, 1.f, 0.f, stream);
+}
+
+extern "C" int l2i_upfirdn2d_masked_f32(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw,
+                                        int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                        int channels, const float* noise, float noise_w, const float* bias, const float* addend,
+                                        int act, float act_slope, float act_gain, const float* mask, float mask_pos, float mask_neg, void* stream) {
+    return upfirdn2d_launch(y, x, k, major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, channels, noise, noise_w, bias, addend,
+                            act, act_slope, act_gain, mask, mask_pos, mask_neg, stream);
+}
+
+static int upfirdn2d_launch(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw,
+                            int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                            int channels, const float* noise, float noise_w, const float* bias, const float* addend,
+                            int act, float act_slope, float act_gain, const float* mask, float mask_pos, float mask_neg, void* stream) {
     if (!y || !x || !k) return l2i_set_error(L2I_E_ARG, "upfirdn2d: null tensor");
     if (major <= 0 || in_h <= 0 || in_w <= 0) return l2i_set_error(L2I_E_ARG, "upfirdn2d: empty input");
     if (kh <= 0 || kw <= 0 || kh * kw > 64) return l2i_set_error(L2I_E_ARG, "upfirdn2d: FIR must have 1..64 taps");
@@ -453,8 +482,9 @@ extern "C" int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64
     if (p.out_h <= 0 || p.out_w <= 0) return l2i_set_error(L2I_E_ARG, "upfirdn2d: empty output");
     p.channels = channels > 0 ? channels : 1;
     p.noise = noise; p.noise_w = noise_w; p.bias = bias; p.addend = addend; p.act = act; p.slope = act_slope; p.gain = act_gain;
+    p.mask = mask; p.mask_pos = mask_pos; p.mask_neg = mask_neg;
     if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 && (pad_x0 == 1 || pad_x0 == 2) && p.out_w >= 192 && (in_w % 4) == 0 &&
-        (p.out_w % 4) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)noise | (uintptr_t)addend) % 16) == 0) {
+        (p.out_w % 4) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)noise | (uintptr_t)addend | (uintptr_t)mask) % 16) == 0) {
         const int strips = (p.out_w + 255) / 256, bands = (p.out_h + 63) / 64;
         const long long grid = major * bands * strips;
         if (grid > 0 && grid <= 0x7fffffffLL) {
@@ -471,7 +501,7 @@ extern "C" int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64
         return L2I_OK;
     }
     if (up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2 && kh == 4 && kw == 4 && pad_x0 == 1 && pad_y0 == 1 && p.out_w >= 96 && (in_w % 4) == 0 &&
-        (p.out_w % 2) == 0 && !noise && !bias && !addend && act == L2I_ACT_NONE && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)y) % 8) == 0) {
+        (p.out_w % 2) == 0 && !noise && !bias && !addend && !mask && act == L2I_ACT_NONE && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)y) % 8) == 0) {
         const int strips = (p.out_w + 127) / 128, bands = (p.out_h + 31) / 32;
         const long long grid = major * bands * strips;
         if (grid > 0 && grid <= 0x7fffffffLL) {
@@ -481,7 +511,7 @@ extern "C" int l2i_upfirdn2d_f32(float* y, const float* x, const float* k, int64
         }
     }
     if (up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 && pad_x0 == 2 && pad_y0 == 2 && p.out_h == 2 * in_h && p.out_w == 2 * in_w &&
-        (p.out_w % 4) == 0 && (((uintptr_t)y | (uintptr_t)addend) % 16) == 0) {
+        (p.out_w % 4) == 0 && !mask && (((uintptr_t)y | (uintptr_t)addend) % 16) == 0) {
         const long long n = major * (p.out_h / 2) * (p.out_w / 4);
         hipLaunchKernelGGL(upfirdn2d_up2k4_kernel, dim3(l2i_grid_for(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p);
         L2I_CHECK_LAUNCH();

@@ -526,10 +526,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const l2i_conv_param
 // conv_wino4_kernel (tests/test_kernels_gpu.py holds the two against each other).
 namespace w4s {
 constexpr int BMG = 2, BM = 16 * BMG, CK = 4;
-constexpr int TW = 64, TH = 8;
-constexpr int IH = TH + 2;                              // 10 halo rows
-constexpr int IWG = 18, IWP = 4 * IWG;                  // 18 16-byte groups = 72 window columns per row
-constexpr int NGRP = IH * IWG;                          // 180 groups per channel plane
+// Tile of a block: 64 x 8 pixels (a wave's 16 tiles = one tile row) or, NARROW, 32 x 16 pixels for maps 32 .. 63 wide (a wave's 16 tiles = two
+// tile rows of 8).  Both halo windows have 180 16-byte groups: 10 rows x 18 groups, or 18 rows x 10 groups.
+template <bool NARROW> struct Geo {
+    static constexpr int TW = NARROW ? 32 : 64, TH = NARROW ? 16 : 8;
+    static constexpr int IH = TH + 2;                   // 10 / 18 halo rows
+    static constexpr int IWG = NARROW ? 10 : 18, IWP = 4 * IWG;       // 16-byte groups / window columns per row (72 / 40)
+    static_assert(IH * IWG == 180, "180 groups per channel plane");
+};
+constexpr int NGRP = 180;                               // groups per channel plane
 constexpr int NRS = 3;                                  // 16-byte DMA slots per plane (wave w fetches channel w of the chunk: 192 lanes >= 180)
 constexpr int PLANE = 770;                              // floats: >= 64 NRS 4 (the idle lanes of the last slot write zeros inside their own plane), = 2 (mod 4)
 constexpr int RAWST = CK * PLANE;
@@ -554,9 +559,11 @@ struct Wino4sLaunch {
     int nchunks;
 };
 
-template <bool SCALE, bool RELU, int H>
+template <bool SCALE, bool RELU, int H, bool NARROW>
 __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino4sLaunch& L, float* smem) {
     using namespace w4s;
+    using GE = Geo<NARROW>;
+    constexpr int TW = GE::TW, TH = GE::TH, IWG = GE::IWG, IWP = GE::IWP;
     float* ubuf = smem;                                // US x UST
     float* rawbuf = smem + RAW0;                       // RS x [CK][PLANE]
     float* dump = smem + US * UST + 4 + RS * RAWST;
@@ -565,7 +572,9 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, n = lane & 15;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int trow = wave_u >> 1;                      // tile row of this wave (H = wave & 1: position rows 3 H .. 3 H + 2)
+    const int trow = wave_u >> 1;                      // tile row (NARROW: pair of tile rows) of this wave (H = wave & 1: position rows 3 H .. 3 H + 2)
+    const int trow_n = NARROW ? 2 * trow + (n >> 3) : trow;          // this lane's tile: row / column inside the block
+    const int tcol_n = NARROW ? (n & 7) : n;
 
     const int G = gridDim.x;
     int w = (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
@@ -672,8 +681,8 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     f32x4 acc[BMG][18];
     f32x2 Ta[3][3], Tb[3][3];                          // [position row][column pair] of this half: the chunk being multiplied / the next chunk
 
-    // patch of (channel kq, tile (trow, n)): its top-left element is window column 3 + 4 n of halo row 4 trow
-    const unsigned pa0 = lds_raw + (unsigned)((kq * PLANE + (4 * trow) * IWP + 3 + 4 * n) * 4);
+    // patch of (channel kq, this lane's tile): its top-left element is window column 3 + 4 tcol_n of halo row 4 trow_n
+    const unsigned pa0 = lds_raw + (unsigned)((kq * PLANE + (4 * trow_n) * IWP + 3 + 4 * tcol_n) * 4);
     auto load_pair = [&](f32x2 (&P)[6], unsigned pa, int cp) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) P[r] = w4_lds_b64(pa, (r * IWP + 2 * cp) * 4);
@@ -815,7 +824,7 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
 
     // ---- epilogue: lane-local inverse transform Y = A^T M A, then 16-byte row stores (lane (g, n): channels m0 + 16 H + 4 g + 0..3, tile (trow, n)) ----
     const size_t plane_o = (size_t)p.OHf * p.OWf;
-    const int oyb = oy0 + 4 * trow, ox = ox0 + 4 * n;
+    const int oyb = oy0 + 4 * trow_n, ox = ox0 + 4 * tcol_n;
     const bool xok = ox < p.OW;
     float sq = 0.f;
     const float rc = p.res_sub ? p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) : 0.f;
@@ -910,18 +919,19 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     }
 }
 
-template <bool SCALE, bool RELU>
+template <bool SCALE, bool RELU, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const l2i_conv_params p, const Wino4sLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // (a wave-uniform branch: the two halves run the same number of barriers)
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino4s_body<SCALE, RELU, 1>(p, L, smem);
-    else wino4s_body<SCALE, RELU, 0>(p, L, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino4s_body<SCALE, RELU, 1, NARROW>(p, L, smem);
+    else wino4s_body<SCALE, RELU, 0, NARROW>(p, L, smem);
 }
 
 static int launch_wino4s(const l2i_conv_params& p, hipStream_t st) {
     Wino4sLaunch L;
-    L.tiles_x = (p.OW + w4s::TW - 1) / w4s::TW;
-    L.tiles_y = (p.OH + w4s::TH - 1) / w4s::TH;
+    const bool narrow = p.OW < 64;                     // maps 32 .. 63 wide: the 32 x 16-pixel tile
+    L.tiles_x = narrow ? (p.OW + 31) / 32 : (p.OW + 63) / 64;
+    L.tiles_y = narrow ? (p.OH + 15) / 16 : (p.OH + 7) / 8;
     L.mblocks = p.CoutP / w4s::BM;
     const long total = (long)p.B * L.tiles_y * L.tiles_x * L.mblocks;
     if (total <= 0 || total > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: too many tiles");
@@ -932,15 +942,17 @@ static int launch_wino4s(const l2i_conv_params& p, hipStream_t st) {
     const bool scale = p.in_scale != nullptr;
     const size_t lds = (size_t)(w4s::LDS_FLOATS + (scale ? ((p.Cin + 3) & ~3) : 0)) * sizeof(float);
     if (lds > 80 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: too many input channels for the style-scale table");
-#define L2I_WINO4S(S_, R_)                                                                                                              \
+#define L2I_WINO4S_(S_, R_, N_)                                                                                                         \
     do {                                                                                                                                \
-        L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4s_kernel<S_, R_>),                        \
+        L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4s_kernel<S_, R_, N_>),                    \
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                         \
-        hipLaunchKernelGGL((conv_wino4s_kernel<S_, R_>), dim3(grid), dim3(256), lds, st, p, L);                                          \
+        hipLaunchKernelGGL((conv_wino4s_kernel<S_, R_, N_>), dim3(grid), dim3(256), lds, st, p, L);                                      \
     } while (0)
+#define L2I_WINO4S(S_, R_) do { if (narrow) L2I_WINO4S_(S_, R_, true); else L2I_WINO4S_(S_, R_, false); } while (0)
     if (relu_in) { if (scale) L2I_WINO4S(true, true); else L2I_WINO4S(false, true); }
     else { if (scale) L2I_WINO4S(true, false); else L2I_WINO4S(false, false); }
 #undef L2I_WINO4S
+#undef L2I_WINO4S_
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }

@@ -150,9 +150,10 @@ class _DBodyFn(torch.autograd.Function):
             # conv2 path: lrelu' * 1/sqrt2 folded into the prologue mask
             # (gradients of the padded blur maps of the forward: the extra rows / columns receive zeros and are cropped by the negative far pad)
             g_t = blk['c2'].dgrad(g, (h + 4, h + 4), in_mask=y2, mask=(1.0, 0.2))
-            g_y1 = K.upfirdn2d(g_t, blk['kf'], pad=(1, -2, 1, -2))
+            g_y1 = K.upfirdn2d(g_t, blk['kf'], pad=(1, -2, 1, -2), mask=y1, mask_vals=LRELU_MASK)     # [r5] the leaky-ReLU mask of y1 rides on the FIR: the 3x3
+                                                                                                     # gradient conv below is unmasked = the F(4x4) kernel
             del g_t
-            g_a = blk['c1'].dgrad(g_y1, in_hw, in_mask=y1, mask=LRELU_MASK)
+            g_a = blk['c1'].dgrad(g_y1, in_hw)
             del g_y1
             # skip path
             if _skip_compact(h):

@@ -34,9 +34,9 @@ def upfirdn2d_out_hw(h, w, kh, kw, up, down, pad):
 
 
 def upfirdn2d(x, kernel, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0), noise=None, noise_w=0.0, bias=None, addend=None,
-              act=ACT_NONE, slope=0.2, gain=1.0, out=None):
+              act=ACT_NONE, slope=0.2, gain=1.0, out=None, mask=None, mask_vals=(1.0, 0.0)):
     """x [N, C, H, W]; up/down = (x, y); pad = (x0, x1, y0, y1) as in op/upfirdn2d.cpp:12-23.  Optional fused
-    epilogue: act(fir(x) + noise*noise_w + bias[c] + addend) * gain."""
+    epilogue: act(fir(x) + noise*noise_w + bias[c] + addend) * gain, then [r5] * (mask > 0 ? mask_vals[0] : mask_vals[1]) (mask shaped like the output)."""
     lib = _lib.load()
     x = x.contiguous()
     n, c, h, w = x.shape
@@ -46,6 +46,14 @@ def upfirdn2d(x, kernel, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0), noise=None, n
     assert y.shape == (n, c, oh, ow), (y.shape, (n, c, oh, ow))
     if addend is not None:
         assert addend.shape == y.shape
+    if mask is not None:
+        assert mask.shape == y.shape
+        _lib.check(lib.l2i_upfirdn2d_masked_f32(_lib.fptr(y), _lib.fptr(x), _lib.fptr(kernel.contiguous()), n * c, h, w, kh, kw,
+                                                up[0], up[1], down[0], down[1], pad[0], pad[1], pad[2], pad[3], c,
+                                                _lib.fptr(noise), float(noise_w), _lib.fptr(bias), _lib.fptr(addend),
+                                                int(act), float(slope), float(gain), _lib.fptr(mask.contiguous()), float(mask_vals[0]), float(mask_vals[1]),
+                                                _lib.stream_ptr()), 'l2i_upfirdn2d_masked_f32')
+        return y
     _lib.check(lib.l2i_upfirdn2d_f32(_lib.fptr(y), _lib.fptr(x), _lib.fptr(kernel.contiguous()), n * c, h, w, kh, kw,
                                      up[0], up[1], down[0], down[1], pad[0], pad[1], pad[2], pad[3], c,
                                      _lib.fptr(noise), float(noise_w), _lib.fptr(bias), _lib.fptr(addend),

@@ -121,6 +121,26 @@ def test_conv3x3_stride2_dma_kernel(cin, cout, pad, h, w, b):
             assert err < 5e-6, (hint, err)
 
 
+@pytest.mark.parametrize('c,h,w,pad', [(3, 40, 260, (1, -2, 1, -2)), (2, 70, 196, (2, 1, 2, 1)), (5, 36, 68, (1, -2, 1, -2)), (2, 19, 33, (1, 1, 1, 1))])
+def test_upfirdn2d_masked_epilogue(c, h, w, pad):
+    """[r5] l2i_upfirdn2d_masked_f32: the reference FIR with the gradient of a (leaky) ReLU fused behind it (the discriminator's backward), on the
+    register-streaming kernel (>= 192 columns), the staged kernel and the generic one; against the unmasked entry point times the mask, bit for bit,
+    and against the reference's upfirdn2d_native arithmetic through it."""
+    rs = np.random.RandomState(c + h + w)
+    x = T(rs.randn(2, c, h, w)).to(DEV)
+    k1 = np.array([1., 3., 3., 1.])
+    k = T(np.outer(k1, k1) / 64.0).to(DEV)
+    add = None
+    y0 = kernels.upfirdn2d(x, k, pad=pad)
+    m = T(rs.randn(*y0.shape)).to(DEV)
+    ym = kernels.upfirdn2d(x, k, pad=pad, mask=m, mask_vals=(2 ** 0.5, 0.2 * 2 ** 0.5))
+    want = y0 * torch.where(m > 0, torch.tensor(2 ** 0.5, device=DEV), torch.tensor(0.2 * 2 ** 0.5, device=DEV))
+    assert torch.equal(ym, want)
+    add = T(rs.randn(*y0.shape)).to(DEV)
+    ya = kernels.upfirdn2d(x, k, pad=pad, addend=add, mask=m, mask_vals=(1.0, 0.0))
+    assert torch.equal(ya, kernels.upfirdn2d(x, k, pad=pad, addend=add) * (m > 0))
+
+
 def test_conv_prologue_epilogue_fusions():
     rs = np.random.RandomState(5)
     wt = T(rs.randn(48, 40, 3, 3) / 19.0)
@@ -263,8 +283,8 @@ def test_winograd_3x3_conv(cin, cout, h, w, b, wino4):
     """F(2x2,3x3) / F(4x4,3x3) fp32 kernels vs a float64 reference: every prologue / epilogue fusion, partial tiles, channel counts that
     do not fill a block, forward and input-gradient; the direct kernel on the same problem for scale.  Bound: 5e-6 of max|y| for F(2x2)
     (measured 3e-7 .. 1e-6), 3e-5 for F(4x4) (its transforms carry constants up to 8: measured 1e-6 .. 1e-5)."""
-    if wino4 == 'all' and w < 64:
-        pytest.skip('F(4x4,3x3) takes maps >= 64 wide: this shape runs the F(2x2) kernel in both settings')
+    if wino4 == 'all' and (w < 32 or cin % 4):
+        pytest.skip('F(4x4,3x3) takes maps >= 32 wide with Cin % 4 == 0: this shape runs the F(2x2) kernel in both settings')
     bound = 3e-5 if wino4 == 'all' else 5e-6
     rs = np.random.RandomState(cin + cout + h)
     wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
@@ -333,7 +353,8 @@ def test_winograd_3x3_conv(cin, cout, h, w, b, wino4):
 
 
 @pytest.mark.parametrize('cin,cout,h,w,b', [(64, 64, 64, 64, 2), (8, 64, 64, 128, 3), (40, 24, 50, 132, 2), (256, 128, 16, 64, 1), (512, 512, 8, 64, 1),
-                                            (32, 32, 40, 96, 1), (128, 96, 7, 64, 2), (16, 40, 9, 72, 1)])
+                                            (32, 32, 40, 96, 1), (128, 96, 7, 64, 2), (16, 40, 9, 72, 1),
+                                            (512, 512, 32, 32, 1), (64, 96, 37, 40, 2), (32, 64, 16, 60, 1)])      # the last three: maps 32 .. 63 wide = the 32 x 16-pixel tile
 def test_wino4_position_split_kernel_bit_identical_to_round4_kernel(cin, cout, h, w, b):
     """[r5] The position-split F(4x4,3x3) kernel (two waves share the 36 Winograd positions of a tile row, 32 output channels per block, 16-byte
     raw-tile DMA through a 72-column aligned window) does the round-4 kernel's arithmetic in the same order: the two must agree BIT FOR BIT on every
@@ -360,6 +381,7 @@ def test_wino4_position_split_kernel_bit_identical_to_round4_kernel(cin, cout, h
             out, sums = {}, {}
             for mode in ('r4', 'all'):
                 conv.WINO4 = mode
+                conv.WINO4_R4_MIN_W = 32                   # (the round-4 kernel is the reference on the narrow maps too: 64-wide tiles, half empty)
                 launched = conv.PROFILE = []
                 try:
                     sq_acc, fused = torch.zeros(_lib.SQ_SLOTS, device=DEV), [False]
@@ -374,6 +396,7 @@ def test_wino4_position_split_kernel_bit_identical_to_round4_kernel(cin, cout, h
             assert abs(float(sums['all']) - want_sq) <= 1e-5 * want_sq and abs(float(sums['r4']) - want_sq) <= 1e-5 * want_sq
     finally:
         conv.WINO4 = prev
+        conv.WINO4_R4_MIN_W = 64
 
 
 def test_content_loss_sum_fused_into_the_three_channel_conv():

@@ -58,10 +58,10 @@ def load(d, name):
     out = {}
     for r in csv.DictReader(open('%s/run_counter_collection.csv' % d)):
         if r['Counter_Name'] == name:
-            name = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            kname = r['Kernel_Name'].split('(')[0].replace('void ', '')
             for ns in ('l2i_h8_bf16::', 'l2i_h8s_bf16::', 'l2i_h8_f16::', 'l2i_h8s_f16::'):      # [r5] the h8 kernels live in per-element-type namespaces
-                name = name.replace(ns, '')
-            out[int(r['Dispatch_Id'])] = (name, int(r['Grid_Size']), float(r['Counter_Value']) * 1024.0)
+                kname = kname.replace(ns, '')
+            out[int(r['Dispatch_Id'])] = (kname, int(r['Grid_Size']), float(r['Counter_Value']) * 1024.0)
     return out
 
 

@@ -52,4 +52,4 @@ def main(stats_csv, traffic_json, sq_csv, dst, steps_in_stats=12):
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:5], **({'steps_in_stats': int(sys.argv[5])} if len(sys.argv) > 5 else {}))
