@@ -103,13 +103,15 @@ def test_bf16_training_trajectory_lands_where_fp32_does(size, batch, steps, attr
     assert rel_l2 <= l2_max, rel_l2
 
 
-def test_streaming_kernels_bit_stable_beside_bf16_mfma_on_another_stream():
+@pytest.mark.parametrize('elem', ['bf16', 'f16'])
+def test_streaming_kernels_bit_stable_beside_bf16_mfma_on_another_stream(elem):
     """(i) torgb_fwd_h8 / upfirdn2d_h8 (separable and generic) and the lean / general conv_h8 epilogues on stream B while conv_h8 launches keep
     stream A busy: 200 repeats on identical inputs -> exactly one distinct checksum each (with hipcc's SLP vectorizer these kernels gave
     150 - 290 distinct checksums in 300, profiles/r03_packed_fp32_beside_bf16_mfma.txt)."""
     from latent2im_amd import conv
     from latent2im_amd import kernels16 as K16
-    BF = torch.bfloat16
+    prev_precision, conv.PRECISION = conv.PRECISION, elem      # [r5] aggressor and victims of both element types of the 16-bit path (v_mfma_f32_32x32x16_{bf16,f16})
+    BF = conv.h8_dtype()
     reps, b = 200, 4
     torch.manual_seed(0)
 
@@ -150,15 +152,19 @@ def test_streaming_kernels_bit_stable_beside_bf16_mfma_on_another_stream():
                 sums[i] = f().float().double().abs().sum()
         torch.cuda.synchronize()
         distinct = len(np.unique(sums.cpu().numpy()))
+        if distinct != 1:
+            conv.PRECISION = prev_precision
         assert distinct == 1, '%s: %d distinct checksums in %d repeats beside conv_h8 on another stream' % (name, distinct, reps)
+    conv.PRECISION = prev_precision
 
 
-def test_bf16_step_with_three_loss_streams_repeats_bit_identically():
+@pytest.mark.parametrize('elem', ['bf16', 'f16'])
+def test_bf16_step_with_three_loss_streams_repeats_bit_identically(elem):
     """(ii) the whole 16-bit step at 256^2 with the three loss-branch streams (D, VGG, regressor forward + backward run concurrently, torch's
     elementwise / rocBLAS kernels between ours), 30 repeats on identical inputs in a fresh process with L2I_H8_DET=1 (one strip per reduction:
     fp32 atomics would otherwise reorder sums) -> exactly one distinct walk gradient."""
     env = dict(os.environ, L2I_H8_DET='1')
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'probes', 'bf16_repeat.py'), 'bf16', '256', '2', '30'], env=env, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'probes', 'bf16_repeat.py'), elem, '256', '2', '30'], env=env, capture_output=True, text=True,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     last = [l for l in r.stdout.splitlines() if 'distinct gradients' in l][-1]
