@@ -958,8 +958,6 @@ def test_regressor_training_step_vs_oracle(tmp_path):
         blk, saved = model.blocks[bi], sv['blocks'][bi]
         cur, y1, s1, y2, s2, s3, sd, out = saved
         gin = torch.randn(out.shape, generator=torch.Generator().manual_seed(bi)).to(DEV)
-        grads = {}
-        gx = RT.TrainableResNet50.block_backward(blk, saved, gin, grads)
         x = D(cur).requires_grad_(True)
         prm = {}
         for c_, b_ in (('c1', 'b1'), ('c2', 'b2'), ('c3', 'b3'), ('cd', 'bd')):
@@ -968,9 +966,18 @@ def test_regressor_training_step_vs_oracle(tmp_path):
                 prm[blk[b_].name + '.weight'], prm[blk[b_].name + '.bias'] = D(blk[b_].weight).requires_grad_(True), D(blk[b_].bias).requires_grad_(True)
         bn = lambda t, b_: F.batch_norm(t, None, None, prm[blk[b_].name + '.weight'], prm[blk[b_].name + '.bias'], training=True, eps=1e-5)
         cv = lambda t, c_: F.conv2d(t, prm[blk[c_].name + '.weight'], stride=blk[c_].stride, padding=blk[c_].padding)
-        o = bn(cv(F.relu(bn(cv(F.relu(bn(cv(x, 'c1'), 'b1')), 'c2'), 'b2')), 'c3'), 'b3')
-        o = F.relu(o + (bn(cv(x, 'cd'), 'bd') if blk['cd'] is not None else x))
-        assert int((D(out) > 0).ne(o > 0).sum()) == 0                            # same ReLU pattern: the comparison below is exact arithmetic
+        pre = bn(cv(F.relu(bn(cv(F.relu(bn(cv(x, 'c1'), 'b1')), 'c2'), 'b2')), 'c3'), 'b3')
+        pre = pre + (bn(cv(x, 'cd'), 'bd') if blk['cd'] is not None else x)
+        o = F.relu(pre)
+        # same ReLU pattern (the comparison below is then exact arithmetic) — except where the float64 pre-activation is a rounding error away
+        # from zero (the 3x3 of blocks on maps >= 32 wide runs on F(4x4): ~1e-5 of the largest value): at most a handful of entries, and the
+        # incoming gradient is zeroed there on both sides so the mask's value at them does not matter
+        flip = (D(out) > 0).ne(o > 0)
+        assert int(flip.sum()) <= 4 and (int(flip.sum()) == 0 or float(pre.detach()[flip].abs().max()) < 1e-5 * float(pre.detach().abs().max())), \
+            (bi, int(flip.sum()), float(pre.detach()[flip].abs().max()) / float(pre.detach().abs().max()))
+        gin = gin * (~flip).to(DEV)
+        grads = {}
+        gx = RT.TrainableResNet50.block_backward(blk, saved, gin, grads)
         ref = torch.autograd.grad(o, [x] + list(prm.values()), D(gin))
         assert rel(gx, ref[0]) < 1e-4, (bi, 'input', rel(gx, ref[0]))
         for k, r in zip(prm, ref[1:]):
