@@ -93,6 +93,12 @@ typedef struct l2i_conv_params {
     int64_t w_bstride;      /* l2i_conv2d_h8 / l2i_conv_transpose2d_h8: bytes between the weight planes of consecutive samples (the generator's */
                             /* modulated convs: style and demodulation folded into one plane set per sample), 0 = one set for every sample    */
     int32_t out_f32;        /* l2i_conv2d_h8: 1 = the output (and residual / res_mask / out_mask / res_sub) is fp32 NCHW instead of bf16 h8      */
+    /* ---- ABI version 5: fp32 <-> 16-bit boundaries of the 16-bit path without a cast pass (see also l2i_conv_img_h8) ------------------------- */
+    int32_t in_h8;          /* l2i_conv_transpose2d_f32, 7x7 / pad 3 onto <= 3 channels (the ResNet stem's input gradient): 1 / 2 = x and in_mask are      */
+                            /* bf16 / fp16 h8 tensors [B, Cin/8, H, W, 8] (Cin % 8 == 0)                                                                  */
+    const float* rgb_w;     /* l2i_conv2d_h8 with the h8 output and every output channel in one block (Cout <= 64): not NULL = the launch also writes the   */
+    const float* rgb_bias;  /* ToRGB image of its output, rgb_out[b, o, oy, ox] = rgb_bias[o] + sum_c rgb_w[b, o, c] * epi(.)[b, c, oy, ox] (o < 3; fp32     */
+    float* rgb_out;         /* NCHW [B, 3, OHf, OWf]; networks.py:349-358 on the 512^2 / 1024^2 StyledConv outputs), instead of a pass that re-reads y        */
 } l2i_conv_params;
 #define L2I_SQ_SLOTS 1024
 
@@ -161,6 +167,15 @@ int l2i_conv2d_wino4_f32(const l2i_conv_params* p, void* stream);
 int l2i_conv2d_h8(const l2i_conv_params* p, void* stream);
 int l2i_conv_transpose2d_h8(const l2i_conv_params* p, void* stream);
 
+/* [r5] The image-side convolutions of the 16-bit path (csrc/l2i_img_h8.hip): x = fp32 NCHW image [B, Cin <= 4, H, W], y = 16-bit h8
+ * [B, Cout/8, OHf, OWf, 8], 16-bit MFMA with fp32 accumulation on operands rounded to the element type inside the kernel — VGG-19 conv1_1
+ * (3x3 / stride 1; transform_base.py:426-454), the discriminator's from-RGB 1x1 (networks.py:568-575), ResNet-50's 7x7 / stride 2 stem
+ * (transform_base.py:396-403) without a zero-padded 16-bit copy of the image, an fp32 stem map or a cast pass.  Built for (KH, stride) in
+ * {(1, 1), (3, 1), (7, 2)}, any symmetric padding.  `w_hi`: 16-bit planes [ceil(Cin KH / 2)][2][CoutP][8] whose element (s, half, co, e) is
+ * w[co, c, ky, kx = e] for (c, ky) = divmod(2 s + half, KH), zero for e >= KW or 2 s + half >= Cin KH (latent2im_amd/conv.py:
+ * pack_weight_img_h8).  Fused: bias, act, out_gain (> 0), sq_ref / sq_out (sq_ref h8 like y).  Everything else must be unset. */
+int l2i_conv_img_h8(const l2i_conv_params* p, void* stream);
+
 /* Streaming companions on h8 maps (csrc/l2i_stream_h8.hip; same functions as the fp32 entry points below, arithmetic in fp32 registers):
  * layout casts fp32 NCHW <-> bf16 h8 (Cpad = channel count of the h8 tensor, a multiple of 8, zero filled above C);
  * the reference's upfirdn2d on h8 planes (kernels up to 4x4, up / down in {1, 2}) with the generator's fused epilogue
@@ -195,6 +210,7 @@ int l2i_modulate_planes_h8(void* planes, const float* w32, const float* s, int B
  * gradients inside its range with power-of-two loss scales (latent2im_amd/nets16.py: one per loss branch, undone on the fp32 side: exact). */
 int l2i_conv2d_h8_f16(const l2i_conv_params* p, void* stream);
 int l2i_conv_transpose2d_h8_f16(const l2i_conv_params* p, void* stream);
+int l2i_conv_img_h8_f16(const l2i_conv_params* p, void* stream);
 int l2i_cast_f32_to_h8_f16(void* y, const float* x, int B, int C, int Cpad, int64_t HW, void* stream);
 int l2i_cast_h8_to_f32_f16(float* y, const void* x, int B, int C, int Cpad, int64_t HW, void* stream);
 int l2i_upfirdn2d_h8_f16(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
@@ -347,8 +363,8 @@ int l2i_segmented_matvec_f32(float* out, const float* in, const float* in2, cons
 
 const char* l2i_last_error(void);
 /* Bumped whenever a struct of this header grows or an entry point changes meaning (1: round 1-2; 2: round 3, l2i_conv_params gained w_bstride /
- * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
-#define L2I_ABI_VERSION 4
+ * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
+#define L2I_ABI_VERSION 5
 int l2i_abi_version(void);
 int l2i_sizeof_conv_params(void);       /* sizeof(struct l2i_conv_params) of THIS build */
 

@@ -36,6 +36,7 @@ class ConvParams(ctypes.Structure):
         ('ws', c_p), ('ksplit', c_i), ('res_sub', c_p), ('res_coef', c_f), ('res_coef_dev', c_p),
         ('sq_ref', c_p), ('sq_out', c_p),
         ('w_bstride', c_l), ('out_f32', c_i),
+        ('in_h8', c_i), ('rgb_w', c_p), ('rgb_bias', c_p), ('rgb_out', c_p),
     ]
 
 
@@ -64,6 +65,7 @@ _SIGNATURES = {
     'l2i_conv2d_wino4_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv_transpose2d_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
+    'l2i_conv_img_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_fused_bias_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
     'l2i_fused_bias_act_f16': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
     'l2i_upfirdn2d_f16': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -111,7 +113,7 @@ _SIGNATURES = {
 for _n in [k for k in _SIGNATURES if k.endswith('_h8') or k in ('l2i_cast_f32_to_h8', 'l2i_cast_h8_to_f32')]:
     _SIGNATURES[_n + '_f16'] = _SIGNATURES[_n]
 
-ABI_VERSION = 4          # L2I_ABI_VERSION of include/l2i.h this binding mirrors
+ABI_VERSION = 5          # L2I_ABI_VERSION of include/l2i.h this binding mirrors
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -282,17 +282,24 @@ class SmallTransposed:
 
 def run_small_transposed(F, x, y, in_mask=None, mask=(1.0, 0.0), out_gain=1.0):
     lib = _lib.load()
-    B, cin, H, W = x.shape
+    h8 = x.dim() == 5                                      # [r5] 16-bit h8 gradient (and mask) in: l2i_conv_params::in_h8
+    if h8:
+        B, cg, H, W, _ = x.shape
+        cin = cg * 8
+        assert x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous() and (in_mask is None or (in_mask.dtype == x.dtype and in_mask.is_contiguous()))
+    else:
+        B, cin, H, W = x.shape
     assert cin == F.cin and y.shape[0] == B and y.shape[1] == F.cout
     p = ConvParams()
-    p.x, p.w, p.y = _lib.fptr(x), _lib.fptr(F.w), _lib.fptr(y)
+    p.x, p.w, p.y = (_lib.ptr(x) if h8 else _lib.fptr(x)), _lib.fptr(F.w), _lib.fptr(y)
+    p.in_h8 = 0 if not h8 else (2 if x.dtype == torch.float16 else 1)
     p.B, p.Cin, p.H, p.W, p.Cout, p.CoutP = B, cin, H, W, F.cout, 4
     p.KH = p.KW = F.k
     p.stride, p.pad_y, p.pad_x = 2, F.pad, F.pad
     p.OHf, p.OWf = y.shape[2], y.shape[3]
     p.OH, p.OW = (p.OHf + 1) // 2, (p.OWf + 1) // 2
     p.oy_step = p.ox_step = 2
-    p.in_mask = _lib.fptr(in_mask)
+    p.in_mask = _lib.ptr(in_mask) if h8 else _lib.fptr(in_mask)
     p.mask_pos, p.mask_neg = mask
     p.act_gain, p.out_gain = 1.0, out_gain
     if in_mask is not None:
@@ -530,6 +537,13 @@ class FrozenConv2d:
             return run_fused_transposed(self.fwd_fused, x, out, **kw)
         return run_plan(self.fwd, x, out, **kw)
 
+    def dgrad_h8in(self, gy, in_hw, in_mask=None, mask=(1.0, 0.0), out_gain=1.0):
+        """[r5] Input-gradient of the 7x7 / stride 2 stem conv from a 16-bit h8 gradient (and h8 ReLU mask): fp32 NCHW image gradient out
+        (l2i_conv_params::in_h8, csrc/l2i_convt_small.hip)."""
+        assert self.bwd_small is not None and gy.dim() == 5 and gy.shape[1] * 8 == self.cout
+        out = torch.empty(gy.shape[0], self.cin, in_hw[0], in_hw[1], device=gy.device, dtype=torch.float32)
+        return run_small_transposed(self.bwd_small, gy, out, in_mask=in_mask, mask=mask, out_gain=out_gain)
+
     def dgrad(self, gy, in_hw, out=None, **kw):
         """Gradient w.r.t. the input of ``forward`` given the gradient ``gy`` w.r.t. its (pre-epilogue) output."""
         if out is None:
@@ -588,6 +602,67 @@ def pack_weight_h8(w, cin_pad=32, dtype=None):
     full = torch.zeros(coutp, cinp, kh, kw, dtype=torch.float32, device=w.device)
     full[:cout] = w
     return full.to(torch.float16).reshape(coutp, cinp // 16, 2, 8, kh * kw).permute(1, 4, 2, 0, 3).contiguous().view(torch.int16)
+
+
+def pack_weight_img_h8(w, dtype=None):
+    """[Cout, Cin <= 4, K, K] fp32 -> the 16-bit planes of l2i_conv_img_h8 (include/l2i.h): [ceil(Cin K / 2)][1][2][CoutP][8] (int16 view), element
+    (s, half, co, e) = w[co, c, ky, e] for (c, ky) = divmod(2 s + half, K), zero for e >= K and rows past Cin K — a 1x1 weight over the kernel's
+    own contraction index k' = 16 s + 8 half + e, packed like every other h8 weight."""
+    w = torch.as_tensor(w, dtype=torch.float32)
+    cout, cin, k, _ = w.shape
+    assert cin <= 4 and k <= 8
+    ns = (cin * k + 1) // 2
+    rows = torch.zeros(cout, 2 * ns, 8, dtype=torch.float32)
+    rows[:, :cin * k, :k] = w.reshape(cout, cin * k, k)
+    return pack_weight_h8(rows.reshape(cout, 16 * ns, 1, 1), cin_pad=16, dtype=dtype)
+
+
+class ImgConvH8:
+    """[r5] An image-side convolution of the 16-bit path (csrc/l2i_img_h8.hip): fp32 NCHW image in, h8 map out; forward only (the input gradients
+    land on the fp32 image through the generic kernels: H8Conv.dgrad(out_f32=True), FrozenConv2d.dgrad_h8in)."""
+
+    def __init__(self, weight, stride=1, padding=0, device='cuda'):
+        w = torch.as_tensor(np.asarray(weight) if not torch.is_tensor(weight) else weight, dtype=torch.float32).cpu()
+        self.cout, self.cin, self.k, _ = w.shape
+        assert (self.k, stride) in ((1, 1), (3, 1), (7, 2)) and self.cout % 8 == 0, (self.k, stride, self.cout)
+        self.stride, self.padding = stride, padding
+        self.dtype = h8_dtype()
+        self.planes = pack_weight_img_h8(w).to(device)
+
+    def out_hw(self, h, w):
+        return (h + 2 * self.padding - self.k) // self.stride + 1, (w + 2 * self.padding - self.k) // self.stride + 1
+
+    def forward(self, x, bias=None, act=ACT_NONE, slope=0.2, gain=1.0, out_gain=1.0, sq=None):
+        lib = _lib.load()
+        B, cin, H, W = x.shape
+        assert cin == self.cin and x.dtype == torch.float32
+        oh, ow = self.out_hw(H, W)
+        y = torch.empty(B, self.cout // 8, oh, ow, 8, device=x.device, dtype=self.dtype)
+        p = ConvParams()
+        p.x, p.w_hi, p.y = _lib.fptr(x), _lib.ptr(self.planes), _lib.ptr(y)
+        p.B, p.Cin, p.H, p.W, p.Cout, p.CoutP = B, cin, H, W, self.cout, self.planes.shape[-2]
+        p.KH = p.KW = self.k
+        p.stride, p.pad_y, p.pad_x = self.stride, self.padding, self.padding
+        p.OH, p.OW, p.OHf, p.OWf = oh, ow, oh, ow
+        p.oy_step = p.ox_step = 1
+        p.bias = _lib.fptr(bias)
+        p.act, p.act_slope, p.act_gain, p.out_gain = act, slope, gain, out_gain
+        if sq is not None:                                            # (reference like y, [SQ_SLOTS] zeroed accumulator, [fused flag])
+            assert sq[0].shape == y.shape and sq[0].dtype == y.dtype and sq[1].numel() == _lib.SQ_SLOTS
+            p.sq_ref, p.sq_out = _lib.ptr(sq[0]), _lib.fptr(sq[1])
+            sq[2][0] = True
+        name = 'l2i_conv_img_h8' + ('_f16' if self.dtype == torch.float16 else '')
+        entry = getattr(lib, name)
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(entry(p, _lib.stream_ptr()), name)
+            e1.record()
+            PROFILE.append((e0, e1, 2.0 * B * self.cout * cin * self.k * self.k * oh * ow,
+                            (B, cin, self.cout, self.k, self.k, self.stride, H, W, oh, ow, 1, False, False, ('b' if bias is not None else '') + str(act)), name, 'conv_h8'))
+            return y
+        _lib.check(entry(p, _lib.stream_ptr()), name)
+        return y
 
 
 class H8Conv:

@@ -562,6 +562,7 @@ extern "C" int l2i_conv_transpose2d_f32(const l2i_conv_params* pp, void* stream)
         if (p.OHf > 2 * p.H + 8 || p.OWf > 2 * p.W + 8) return l2i_set_error(L2I_E_ARG, "conv_transpose2d(small): output window too large for the input");
         return l2i_launch_convt_small(p, (hipStream_t)stream);
     }
+    if (p.in_h8) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: in_h8 is built for the 7x7 / pad 3 kernel onto <= 3 channels only");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: CoutP must be Cout rounded up to 32");
     const int full_h = (p.H - 1) * 2 - 2 * p.pad_y + p.KH, full_w = (p.W - 1) * 2 - 2 * p.pad_x + p.KW;
     // larger than natural: the extra rows / columns (no input reaches them) are written as zeros — output_padding, and the discriminator's

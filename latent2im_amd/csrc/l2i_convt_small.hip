@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include "l2i.h"
 #include "l2i_internal.h"
+#include "l2i_epilogue.h"      // [r5] l2i_h8_lo / l2i_h8_hi: the 16-bit unpack of the in_h8 variant
 
 namespace cts {
 constexpr int K = 7, PAD = 3, KK = K * K;
@@ -23,9 +24,13 @@ constexpr int TH = 16, TW = 32;                    // input positions per block
 constexpr int IH = TH + 3, IWV = (TW + 8) / 4;     // staged rows; float4 per staged row: columns s0 - 4 .. s0 + TW + 3
 constexpr int PITCH = IWV * 4, CK = 8;
 constexpr int NV = (CK * IH * IWV + 255) / 256;    // staging vectors per thread
+constexpr int NS = (IH * PITCH + 255) / 256;       // [r5] in_h8: 16-byte pixel slots (8 channels = one chunk) per thread
 }
 
-template <bool MASK>
+// [r5] H8: x and in_mask are 16-bit h8 tensors [B, Cin/8, H, W, 8] (l2i_conv_params::in_h8): a chunk of CK = 8 channels is ONE 8-channel group, a
+// staged element one 16-byte pixel slot (unpacked to the same fp32 [channel][row][column] LDS tile), half the bytes of the fp32 form and no cast pass
+// between the 16-bit pool gradient and this kernel.
+template <bool MASK, bool H8 = false>
 __global__ __launch_bounds__(256) void convt7_small_kernel(const l2i_conv_params p, int tiles_x, int tiles_y) {
     using namespace cts;
     __shared__ __attribute__((aligned(16))) float tile[CK * IH * PITCH];
@@ -47,6 +52,41 @@ __global__ __launch_bounds__(256) void convt7_small_kernel(const l2i_conv_params
     // (measured, not kept: fetching the next chunk's vectors into registers during the FMAs — 48 more registers, one block per CU less: 0.82 -> 1.07 ms)
     for (int c0 = 0; c0 < p.Cin; c0 += CK) {
         __syncthreads();
+        if constexpr (H8) {
+            const bool f16 = p.in_h8 == 2;
+            const size_t gbase = ((size_t)b * (p.Cin >> 3) + (c0 >> 3)) * plane_x;
+            l2i_u32x4 q[NS], qm[NS];
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                const int e = threadIdx.x + n * 256;
+                const int r = e / PITCH, col = e - r * PITCH;
+                const int gy = t0 - 1 + r, gx = s0 - 4 + col;
+                q[n] = l2i_u32x4{0u, 0u, 0u, 0u};
+                qm[n] = q[n];
+                if (e < IH * PITCH && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                    const size_t slot = gbase + (size_t)gy * p.W + gx;
+                    q[n] = reinterpret_cast<const l2i_u32x4*>(p.x)[slot];
+                    if constexpr (MASK) qm[n] = reinterpret_cast<const l2i_u32x4*>(p.in_mask)[slot];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                const int e = threadIdx.x + n * 256;
+                if (e < IH * PITCH) {
+                    const unsigned u[4] = {q[n].x, q[n].y, q[n].z, q[n].w}, m[4] = {qm[n].x, qm[n].y, qm[n].z, qm[n].w};
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        float a0 = l2i_h8_lo(u[h], f16), a1 = l2i_h8_hi(u[h], f16);
+                        if constexpr (MASK) {
+                            a0 *= l2i_h8_lo(m[h], f16) > 0.f ? p.mask_pos : p.mask_neg;
+                            a1 *= l2i_h8_hi(m[h], f16) > 0.f ? p.mask_pos : p.mask_neg;
+                        }
+                        tile[(2 * h) * IH * PITCH + e] = a0;
+                        tile[(2 * h + 1) * IH * PITCH + e] = a1;
+                    }
+                }
+            }
+        } else {
         float4 v[NV];
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
@@ -69,6 +109,7 @@ __global__ __launch_bounds__(256) void convt7_small_kernel(const l2i_conv_params
         for (int n = 0; n < NV; ++n) {
             const int e = threadIdx.x + n * 256;
             if (e < CK * IH * IWV) *reinterpret_cast<float4*>(&tile[e * 4]) = v[n];          // e * 4 == (c * IH + r) * PITCH + 4 q
+        }
         }
         __syncthreads();
         const int cn = p.Cin - c0 < CK ? p.Cin - c0 : CK;
@@ -125,8 +166,8 @@ __global__ __launch_bounds__(256) void convt7_small_kernel(const l2i_conv_params
 // (CoutP == 4), whole 16-byte rows on both sides, no style / output scale
 bool l2i_convt_small_eligible(const l2i_conv_params& p) {
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
-    return p.KH == 7 && p.KW == 7 && p.pad_y == 3 && p.pad_x == 3 && p.Cout <= 3 && p.CoutP == 4 && !p.in_scale && !p.out_scale && (p.W % 4) == 0 &&
-           (p.OWf % 4) == 0 && al16(p.x) && al16(p.in_mask) && al16(p.y) && al16(p.w) && p.ksplit <= 1;
+    return p.KH == 7 && p.KW == 7 && p.pad_y == 3 && p.pad_x == 3 && p.Cout <= 3 && p.CoutP == 4 && !p.in_scale && !p.out_scale && ((p.W % 4) == 0 || p.in_h8) &&
+           (p.OWf % 4) == 0 && al16(p.x) && al16(p.in_mask) && al16(p.y) && al16(p.w) && p.ksplit <= 1 && (!p.in_h8 || ((p.in_h8 == 1 || p.in_h8 == 2) && (p.Cin % 8) == 0));
 }
 
 int l2i_launch_convt_small(const l2i_conv_params& p, hipStream_t st) {
@@ -136,7 +177,9 @@ int l2i_launch_convt_small(const l2i_conv_params& p, hipStream_t st) {
     const int tiles_x = (tw + TW - 1) / TW, tiles_y = (th + TH - 1) / TH;
     const long grid = (long)p.B * tiles_x * tiles_y;
     if (grid <= 0 || grid > 0x7fffffffL) return l2i_set_error(L2I_E_ARG, "conv_transpose2d(small): grid too large");
-    if (p.in_mask) hipLaunchKernelGGL((convt7_small_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, p, tiles_x, tiles_y);
+    if (p.in_h8 && p.in_mask) hipLaunchKernelGGL((convt7_small_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, st, p, tiles_x, tiles_y);
+    else if (p.in_h8) hipLaunchKernelGGL((convt7_small_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, st, p, tiles_x, tiles_y);
+    else if (p.in_mask) hipLaunchKernelGGL((convt7_small_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, p, tiles_x, tiles_y);
     else hipLaunchKernelGGL((convt7_small_kernel<false>), dim3((unsigned)grid), dim3(256), 0, st, p, tiles_x, tiles_y);
     L2I_CHECK_LAUNCH();
     return L2I_OK;

@@ -17,6 +17,26 @@ static inline bool l2i_epilogue_vec_ok(const l2i_conv_params& p) {
            al16(p.res_mask) && al16(p.res_sub) && al16(p.out_mask) && al16(p.noise);
 }
 
+// ---- [r5] 16-bit elements of the h8 layout inside fp32 translation units (`f16`: IEEE fp16, else bf16): l2i_convt_small.hip (in_h8), l2i_img_h8.hip ----
+__device__ __forceinline__ unsigned l2i_cvt_pk_h8(float lo, float hi, bool f16) {
+    unsigned r;
+    if (f16) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    else asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float l2i_h8_lo(unsigned u, bool f16) {
+    float r;
+    if (f16) asm("v_cvt_f32_f16 %0, %1" : "=v"(r) : "v"(u));
+    else r = __uint_as_float(u << 16);
+    return r;
+}
+__device__ __forceinline__ float l2i_h8_hi(unsigned u, bool f16) {
+    float r;
+    if (f16) asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(u));
+    else r = __uint_as_float(u & 0xffff0000u);
+    return r;
+}
+typedef unsigned int l2i_u32x4 __attribute__((ext_vector_type(4)));
 template <int WM, int WN>
 __device__ __forceinline__ void l2i_epilogue_32x32(const l2i_conv_params& p, f32x16 (&acc)[WM][WN], float* smemf, int b, int m0, int oy0, int ox0, bool vec) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;

@@ -39,6 +39,11 @@ LRELU_MASK = (SQRT2, 0.2 * SQRT2)
 # out: exact in every fp32 quantity, and inside a branch all maps are linear in the incoming gradient.  The exponents are STATIC per (branch,
 # resolution, batch): `loss_scale` below — measured with tools/bf16_study.py --probe (max / median magnitude of every gradient map), chosen to put the
 # largest map of a branch near 2^8 .. 2^11; nothing is checked at run time.  bf16 elements: every scale is 1 (not applied).
+# [r5] the three image-side convs (VGG conv1_1, the discriminator's from-RGB 1x1, ResNet-50's 7x7 stem) read the fp32 3-channel image and STORE h8
+# (l2i_conv_img_h8, csrc/l2i_img_h8.hip), the stem's input gradient READS h8 (l2i_conv_params::in_h8): no padded 16 / 32-channel 16-bit copy of the
+# image, no fp32 stem map, no cast passes (-6 GB of the step's HBM traffic at 1024^2 batch 8).  L2I_H8_IMG_CONVS=0: the round-4 form (A/B).
+IMG_CONVS = os.environ.get('L2I_H8_IMG_CONVS', '1') != '0'
+
 PROBE = None            # tools/bf16_study.py --probe: a list that receives (tag, shape, max |g|, median |g| of the non-zero entries) per gradient map
 
 
@@ -98,18 +103,22 @@ class VGG19Prefix:
         ws = [w0] + [torch.as_tensor(np.asarray(P['%d.weight' % i]), dtype=torch.float32) for i in (2, 5, 7)]
         self.convs = [C.H8Conv(w, 1, 1, device=device, cin_pad=16 if i == 0 else 32) for i, w in enumerate(ws)]      # conv1_1: three real channels of ONE 16-channel chunk
         self.biases = [torch.as_tensor(np.asarray(P['%d.bias' % i]), dtype=torch.float32).contiguous().to(device) for i in (0, 2, 5, 7)]
+        self.conv0_img = C.ImgConvH8(w0, 1, 1, device=device) if IMG_CONVS else None      # conv1_1 forward on the fp32 image, h8 out (its gradient: convs[0].dgrad)
         self.neg_mean = (-torch.tensor(VGG_MEAN, dtype=torch.float32)).to(device)
 
     def taps(self, img, org=None):
         """[B,3,H,W] fp32 -> (c1, c2, p, c3, c4, pool_idx) h8: pre-ReLU conv outputs conv_1..conv_4, p = relu(maxpool(c2)).  ``org`` = the four
         taps of the original image: a seventh element, the four sums of (c_k - org_k)^2, formed in the conv epilogues."""
         xc = K.fused_bias_act(img.contiguous(), self.neg_mean, None, 1, 0, 0.0, 1.0)        # x - mean (fp32: the padding stays exactly zero)
-        xh = K16.cast_to_h8(xc, 16, dtype=self.dtype)              # three real channels of a 16-channel chunk
         sq = [None] * 4
         if org is not None:
             acc = torch.zeros(4, C._lib.SQ_SLOTS, device=img.device, dtype=torch.float32)
             sq = [(org[k], acc[k], [False]) for k in range(4)]
-        c1 = self.convs[0].forward(xh, bias=self.biases[0], sq=sq[0])
+        if self.conv0_img is not None:
+            c1 = self.conv0_img.forward(xc, bias=self.biases[0], sq=sq[0])
+        else:
+            xh = K16.cast_to_h8(xc, 16, dtype=self.dtype)          # three real channels of a 16-channel chunk
+            c1 = self.convs[0].forward(xh, bias=self.biases[0], sq=sq[0])
         c2 = self.convs[1].forward(c1, relu_in=True, bias=self.biases[1], sq=sq[1])
         p, idx = K16.maxpool2d_fwd(c2, 2, 2, 0, relu=True)          # relu(maxpool(.)) == maxpool(relu(.)); the stored map is already rectified
         c3 = self.convs[2].forward(p, bias=self.biases[2], sq=sq[2])
@@ -178,7 +187,10 @@ class ResNet50:
         P = state
         self.device = device
         self.dtype = K16.h8_dtype()
-        self.stem = _CB(P, 'conv1', 'bn1', 2, 3, device)            # 7x7 stride 2 on the 3-channel fp32 image: the fp32 kernels (0.3 % of the net's MACs)
+        self.stem = _CB(P, 'conv1', 'bn1', 2, 3, device)            # 7x7 stride 2 on the 3-channel fp32 image: fp32 kernels (L2I_H8_IMG_CONVS=0) and the input gradient
+        self.stem_img = C.ImgConvH8(_fold_bn(P, 'conv1', 'bn1')[0], 2, 3, device=device) if IMG_CONVS else None
+        if IMG_CONVS:       # the input gradient contracts with the weights the forward multiplied by: the folded weights rounded to the element type
+            self.stem_bwd = C.FrozenConv2d(_fold_bn(P, 'conv1', 'bn1')[0].to(self.dtype).float(), 2, 3, device=device)
         self.blocks = []
         for li, (planes, blocks, stride) in enumerate(RESNET50_LAYERS):
             for b in range(blocks):
@@ -200,8 +212,12 @@ class _ResNet16Fn(torch.autograd.Function):
     def forward(ctx, img, net):
         keep = img.requires_grad
         x = img.detach().contiguous()
-        a0 = net.stem.conv.forward(x, bias=net.stem.bias, act=C.ACT_RELU)              # fp32 [B,64,H/2,W/2]
-        p0, idx0 = K16.maxpool2d_fwd(K16.cast_to_h8(a0, dtype=net.dtype), 3, 2, 1)
+        if IMG_CONVS:
+            a0 = net.stem_img.forward(x, bias=net.stem.bias, act=C.ACT_RELU)            # h8 [B,8,H/2,W/2,8] from the fp32 image (csrc/l2i_img_h8.hip)
+            p0, idx0 = K16.maxpool2d_fwd(a0, 3, 2, 1)
+        else:
+            a0 = net.stem.conv.forward(x, bias=net.stem.bias, act=C.ACT_RELU)          # fp32 [B,64,H/2,W/2]
+            p0, idx0 = K16.maxpool2d_fwd(K16.cast_to_h8(a0, dtype=net.dtype), 3, 2, 1)
         saved = dict(in_hw=(x.shape[2], x.shape[3]), a0=a0 if keep else None, idx0=idx0 if keep else None, blocks=[])
         cur = p0
         for blk in net.blocks:
@@ -255,8 +271,12 @@ class _ResNet16Fn(torch.autograd.Function):
             if PROBE is not None and (bi in (0, n - 1) or net.blocks[bi]['down'] is not None):
                 _probe('R.G%d' % bi, G)
         a0 = saved['a0']
-        g_a0 = K16.cast_from_h8(K16.maxpool2d_bwd(G, saved['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1), a0.shape[1])
-        g_img = net.stem.conv.dgrad(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0), out_gain=1.0 / S)
+        if a0.dim() == 5:                                  # [r5] h8 stem map: the 7x7 gradient kernel reads the 16-bit pool gradient and mask
+            g_a0 = K16.maxpool2d_bwd(G, saved['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1)
+            g_img = net.stem_bwd.dgrad_h8in(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0), out_gain=1.0 / S)
+        else:
+            g_a0 = K16.cast_from_h8(K16.maxpool2d_bwd(G, saved['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1), a0.shape[1])
+            g_img = net.stem.conv.dgrad(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0), out_gain=1.0 / S)
         ctx.saved = ctx.last = None
         return g_img, None
 
@@ -279,6 +299,8 @@ class Discriminator(_Discriminator32):
         self.dtype = K16.h8_dtype()
         log_size = int(math.log2(size))
         self.conv0 = _eq16(P, 'convs.0.0.weight', 1, 0, device)
+        w0 = torch.as_tensor(np.asarray(P['convs.0.0.weight']), dtype=torch.float32)
+        self.conv0_img = C.ImgConvH8(w0 * (1.0 / math.sqrt(w0.shape[1] * w0.shape[2] * w0.shape[3])), 1, 0, device=device) if IMG_CONVS else None
         self.bias0 = _vec(P, 'convs.0.1.bias', device)
         self.blocks = []
         for n in range(1, log_size - 1):
@@ -308,7 +330,10 @@ class _DBody16Fn(torch.autograd.Function):
         keep = img.requires_grad
         x = img.detach().contiguous()
         lr = dict(act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
-        y0 = net.conv0.forward(K16.cast_to_h8(x, 32, dtype=net.dtype), bias=net.bias0, **lr)
+        if net.conv0_img is not None:
+            y0 = net.conv0_img.forward(x, bias=net.bias0, **lr)                            # from-RGB 1x1 on the fp32 image, h8 out
+        else:
+            y0 = net.conv0.forward(K16.cast_to_h8(x, 32, dtype=net.dtype), bias=net.bias0, **lr)
         saved = [y0]
         cur = y0
         for blk in net.blocks:

@@ -1,5 +1,5 @@
 """Oracle for the 16-bit path's ResNet-50: the float64 network of oracle/nets.py with the STORAGE ROUNDING of latent2im_amd/nets16.py restated
-— eval-mode BatchNorm folded into the conv weights, the folded weights of every conv but the stem rounded to bfloat16, and every feature map
+— eval-mode BatchNorm folded into the conv weights, the folded weights of every conv rounded to bfloat16, the image rounded where the stem kernel reads it, and every feature map
 rounded to bfloat16 where the GPU path stores it (after the stem's ReLU, after each conv's bias / residual / ReLU epilogue) — while every sum
 stays float64.  The rounding is a straight-through estimator for autograd, so the gradient is the exact gradient of the piecewise-linear network
 whose ReLU / max-pool masks come from the ROUNDED activations: what the GPU path computes, up to the order of its fp32 sums and the bf16 rounding
@@ -46,8 +46,8 @@ def resnet50_forward_bf16(P, x, perturb=0.0):
 
 
 def _resnet50_q(P, x, q):
-    w, b = _fold(P, 'conv1', 'bn1', round_w=False)                 # the 7x7 stem runs on the fp32 kernels (nets16.ResNet50.__init__)
-    x = q(F.relu(F.conv2d(x, w, b, stride=2, padding=3)))          # cast_to_h8 of the fp32 stem output
+    w, b = _fold(P, 'conv1', 'bn1')                                # [r5] the 7x7 stem runs on l2i_conv_img_h8: 16-bit weights, the image rounded to 16 bits
+    x = q(F.relu(F.conv2d(q(x), w, b, stride=2, padding=3)))       # inside the kernel, the h8 store of its epilogue (rounds 1-4: fp32 kernels + cast_to_h8)
     x = F.max_pool2d(x, 3, 2, 1)
     for li, (planes, blocks, stride) in enumerate(RESNET50_LAYERS):
         for bi in range(blocks):

@@ -68,6 +68,59 @@ def test_conv_h8_forward_and_dgrad(case):
         close16(conv.from_h8(gx, cin), gref, 'dgrad')
 
 
+IMG_CASES = [  # cin, cout, k, stride, pad, h, w, batch, act           (the three image-side convs of the 16-bit path, odd sizes, > 64 channels)
+    (3, 64, 7, 2, 3, 64, 96, 2, 'relu'), (3, 32, 1, 1, 0, 40, 64, 2, 'lrelu'), (3, 128, 1, 1, 0, 33, 37, 1, 'lrelu'), (3, 64, 3, 1, 1, 32, 64, 2, 'none'),
+    (3, 64, 3, 1, 1, 21, 36, 1, 'none'), (3, 64, 7, 2, 3, 31, 45, 1, 'relu'), (3, 64, 7, 2, 3, 256, 256, 1, 'relu'), (1, 40, 3, 1, 1, 19, 70, 2, 'relu'),
+    (4, 96, 3, 1, 0, 18, 67, 1, 'lrelu'),
+]
+
+
+@pytest.mark.parametrize('case', IMG_CASES)
+def test_conv_img_h8(case):
+    """[r5] l2i_conv_img_h8 (ResNet-50 stem, discriminator from-RGB, VGG conv1_1 of the 16-bit path: transform_base.py:396-403, networks.py:568-575,
+    transform_base.py:426-454): fp32 image in, h8 out, against float64 torch on the operands rounded to the element type (the kernel rounds them
+    itself); the fused (y - ref)^2 sum against float64 on the rounded output."""
+    from latent2im_amd import kernels16 as K16
+    cin, cout, k, stride, pad, h, w, b, act = case
+    rs = np.random.RandomState(cin + cout + k + h)
+    wt, bias = T(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)), T(rs.randn(cout))
+    x = T(rs.randn(b, cin, h, w))
+    ic = conv.ImgConvH8(wt, stride, pad, device=DEV)
+    gain, og = 2.0 ** 0.5, (1.0 if act != 'none' else 0.75)
+    ref = F.conv2d(bf(x), bf(wt), stride=stride, padding=pad) + bias.double().reshape(1, -1, 1, 1)
+    ref = {'relu': torch.relu(ref), 'lrelu': F.leaky_relu(ref, 0.2) * gain, 'none': ref}[act] * og
+    ref16 = K16.cast_to_h8(T(rs.randn(*ref.shape)).to(DEV), dtype=conv.h8_dtype())
+    sq = (ref16, torch.zeros(_lib.SQ_SLOTS, device=DEV), [False])
+    got = ic.forward(x.to(DEV), bias=bias.to(DEV), act={'relu': conv.ACT_RELU, 'lrelu': conv.ACT_LRELU, 'none': conv.ACT_NONE}[act], slope=0.2, gain=gain, out_gain=og, sq=sq)
+    torch.cuda.synchronize()
+    assert got.dtype == conv.h8_dtype() and tuple(got.shape) == (b, cout // 8, ref.shape[2], ref.shape[3], 8)
+    close16(conv.from_h8(got, cout), ref, 'image conv')
+    exact = float(((got.double() - ref16.double()) ** 2).sum())
+    assert sq[2][0] and abs(float(sq[1].sum()) - exact) <= 1e-4 * exact
+
+
+def test_stem_input_gradient_from_h8():
+    """[r5] l2i_conv_params::in_h8: the 7x7 / stride-2 stem's input gradient reads the 16-bit pool gradient and ReLU mask (regressor backward,
+    transform_base.py:396-403).  Same FMAs on the same values as the fp32 launch of the same kernel on the casts: bit-identical."""
+    from latent2im_amd import kernels16 as K16
+    rs = np.random.RandomState(3)
+    wt = T(rs.randn(64, 3, 7, 7) / np.sqrt(147))
+    fc = conv.FrozenConv2d(wt, 2, 3, device=DEV)
+    for b, h, w in ((2, 64, 96), (1, 38, 52)):
+        oh, ow = fc.out_hw(h, w)
+        g16 = K16.cast_to_h8(T(rs.randn(b, 64, oh, ow)).to(DEV), dtype=conv.h8_dtype())
+        m16 = K16.cast_to_h8(T(rs.randn(b, 64, oh, ow)).to(DEV).clamp_(min=0), dtype=conv.h8_dtype())
+        want = fc.dgrad(K16.cast_from_h8(g16), (h, w), in_mask=K16.cast_from_h8(m16), mask=(1.0, 0.0), out_gain=0.5)
+        got = fc.dgrad_h8in(g16, (h, w), in_mask=m16, mask=(1.0, 0.0), out_gain=0.5)
+        torch.cuda.synchronize()
+        if ow % 4 == 0:                                       # (odd widths: the fp32 launch is four per-parity launches, another summation order)
+            assert torch.equal(got, want), float((got - want).abs().max())
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        ref = torch.autograd.grad(F.conv2d(xr := torch.zeros(b, 3, h, w, dtype=torch.float64, requires_grad=True), wt.double(), stride=2, padding=3), xr,
+                                  (g16.double().cpu().permute(0, 1, 4, 2, 3).reshape(b, 64, oh, ow) * (m16.double().cpu().permute(0, 1, 4, 2, 3).reshape(b, 64, oh, ow) > 0)))[0] * 0.5
+        assert float((got.double().cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
 def test_conv_h8_epilogue_fusions_and_fp32_output():
     rs = np.random.RandomState(5)
     b, cin, cout, h, w = 2, 64, 64, 24, 40
