@@ -729,7 +729,7 @@ H8Conv.dgrad_compact = _h8_dgrad_compact
 
 def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=0, out_f32=False, out_scale=None, noise=None, noise_w=0.0, bias=None,
            residual=None, res_mask=None, out_mask=None, mask=(1.0, 0.0), act=ACT_NONE, slope=0.2, gain=1.0, out_gain=1.0, accumulate=False, res_sub=None, res_coef=1.0,
-           res_coef_dev=None, sq=None, relu_in=False):
+           res_coef_dev=None, sq=None, relu_in=False, rgb=None):
     """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels."""
     lib = _lib.load()
     B, cg, H, W, _ = x.shape
@@ -772,6 +772,9 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
         assert sq[0].shape == y.shape and sq[0].dtype == y.dtype and sq[1].numel() == _lib.SQ_SLOTS
         p.sq_ref, p.sq_out = _lib.ptr(sq[0]), _lib.fptr(sq[1])
         sq[2][0] = True
+    if rgb is not None:                                           # [r5] (wmod [B, 3, Cout], bias [3], out [B, 3, OHf, OWf]) fp32: ToRGB of the output in the epilogue (l2i.h: rgb_w)
+        assert not transposed and not out_f32 and cout <= 64 and tuple(rgb[0].shape) == (B, 3, cout) and tuple(rgb[2].shape) == (B, 3, OHf, OWf)
+        p.rgb_w, p.rgb_bias, p.rgb_out = _lib.fptr(rgb[0]), _lib.fptr(rgb[1]), _lib.fptr(rgb[2])
     name = ('l2i_conv_transpose2d_h8' if transposed else 'l2i_conv2d_h8') + ('_f16' if f16 else '')
     entry = getattr(lib, name)
     if PROFILE is not None:

@@ -77,6 +77,7 @@ struct H8Launch {
     int tiles_x, tiles_y, mblocks, total, nchunks;
     int vec_epi;                       // fp32 NCHW output: the LDS-transposed epilogue with 16-byte accesses applies
     int lean_epi;                      // h8 output without per-pixel operand maps (no out_mask / residual / accumulate / sq_ref): the lean epilogue
+    int rgb;                           // [r5] lean epilogue + ToRGB: the block holds every output channel of its pixels and also writes their 3-channel image (l2i.h: rgb_w)
 };
 
 #ifdef L2I_H8_F16
@@ -228,6 +229,8 @@ __device__ __forceinline__ void h8_gather(const f32x16& a, int pr, int half, flo
 // at 1.21 kW).  Under a power cap time follows energy: every part that is removed gives its share back, nothing overlaps "for free", and
 // re-arranging the same work (deeper pipeline, roles, stagger, a 16-row register tile with half the weight traffic: 0.790 against 0.795 ms) changes
 // nothing.  What moves it is less energy per output: fewer bytes (this path), fewer VALU instructions (the lean epilogue), fewer MFMA passes.
+// [r5] Measured again with a 128-channel block (WM = 4, two blocks per CU: half the B-fragment reads and half the L2 -> LDS input traffic per MFMA): 256 -> 256
+// @128^2 0.1301 against 0.1306 ms, 512 -> 512 @64^2 0.1286 / 0.1291, 128 -> 128 @512^2 0.636 / 0.617, 512 -> 512 @32^2 0.0735 / 0.0461 (too few blocks): not kept.
 template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false, int KS = 2>
 __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
     using G = g8::Geo<WN, K, S, TR, KS>;
@@ -465,6 +468,14 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
                 nz[n][a] = p.noise ? p.noise[(size_t)b * plane + off] * p.noise_w : 0.f;
             }
         constexpr int NQ = WM * 2;
+        // [r5] ToRGB on the way out (networks.py:349-358 on the 512^2 / 1024^2 StyledConv outputs): the block holds all Cout <= 32 WM channels of its
+        // pixels, so rgb[o] = rgb_bias[o] + sum_c rgb_w[b, o, c] * y[c] is 24 FMAs per stored slot and one lane-half exchange per pixel instead of a
+        // pass that reads the whole feature map again (fp32 values before the 16-bit rounding of the store)
+        float racc[WN][NACC][3];
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) racc[n][a][0] = racc[n][a][1] = racc[n][a][2] = 0.f;
         const float gpos = (p.act == L2I_ACT_LRELU ? p.act_gain : 1.f) * p.out_gain;
         const float gneg = p.act == L2I_ACT_LRELU ? p.act_slope * p.act_gain * p.out_gain : (p.act == L2I_ACT_RELU ? 0.f : p.out_gain);
         const bool plain_relu = p.act == L2I_ACT_RELU && p.out_gain == 1.f, identity = p.act == L2I_ACT_NONE && p.out_gain == 1.f;
@@ -486,6 +497,16 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
                 bs2[0] = f32x2_{b0.x, b0.y}; bs2[1] = f32x2_{b0.z, b0.w}; bs2[2] = f32x2_{b1.x, b1.y}; bs2[3] = f32x2_{b1.z, b1.w};
             }
             u32x4* const yq = yb + (size_t)(4 * m + 2 * pr) * plane;
+            float rw[3][8];
+            if (L.rgb) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const float* wp = p.rgb_w + ((size_t)b * 3 + o) * p.Cout + cc;
+                    const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+                    rw[o][0] = gok ? w0.x : 0.f; rw[o][1] = gok ? w0.y : 0.f; rw[o][2] = gok ? w0.z : 0.f; rw[o][3] = gok ? w0.w : 0.f;
+                    rw[o][4] = gok ? w1.x : 0.f; rw[o][5] = gok ? w1.y : 0.f; rw[o][6] = gok ? w1.z : 0.f; rw[o][7] = gok ? w1.w : 0.f;
+                }
+            }
 #pragma unroll
             for (int n = 0; n < WN; ++n) {
 #pragma unroll
@@ -512,6 +533,12 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
                         }
                     }
                     g[0] = v[0].x; g[1] = v[0].y; g[2] = v[1].x; g[3] = v[1].y; g[4] = v[2].x; g[5] = v[2].y; g[6] = v[3].x; g[7] = v[3].y;
+                    if (L.rgb) {
+#pragma unroll
+                        for (int o = 0; o < 3; ++o)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) racc[n][a][o] += g[e] * rw[o][e];
+                    }
                     const u32x4 out = {cvt_pk_bf16_h8(g[0], g[1]), cvt_pk_bf16_h8(g[2], g[3]), cvt_pk_bf16_h8(g[4], g[5]), cvt_pk_bf16_h8(g[6], g[7])};
                     unsigned off;
                     const bool ok = pix(n, a, off);
@@ -521,6 +548,22 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
                     if (ok && gok) yq[off] = out;
                 }
             }
+        }
+        if (L.rgb) {
+            // the two lane halves hold the partial sums of different channel groups of the SAME pixel: exchange, add, lanes 0-31 store three fp32 rows
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) {
+                    unsigned off;
+                    const bool ok = pix(n, a, off);
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(racc[n][a][o]), __float_as_uint(racc[n][a][o]), false, false);
+                        const float sum = __uint_as_float(r[0]) + __uint_as_float(r[1]) + p.rgb_bias[o];
+                        if (ok && half == 0) p.rgb_out[((size_t)b * 3 + o) * plane + off] = sum;
+                    }
+                }
         }
     } else {
         H8Out o{p, b, p.Cout / 8, p.res_sub ? p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) : 1.f, 0.f};
@@ -577,6 +620,9 @@ static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
     // identity / ReLU / leaky ReLU as max(g * gpos, g * gneg) needs 0 <= gneg <= gpos
     const bool gains_ok = p.out_gain > 0.f && (p.act != L2I_ACT_LRELU || (p.act_gain > 0.f && p.act_slope >= 0.f && p.act_slope <= 1.f));
     L.lean_epi = (!OUT32 && lean_env && !p.out_mask && !p.residual && !p.accumulate && !p.sq_ref && gains_ok && (size_t)p.OHf * p.OWf < 0xFFFFFFFFull) ? 1 : 0;
+    L.rgb = p.rgb_w ? 1 : 0;
+    if (L.rgb && !(L.lean_epi && L.mblocks == 1 && TR == 0 && p.rgb_bias && p.rgb_out && (p.Cout % 8) == 0 && (((uintptr_t)p.rgb_w) % 16) == 0))
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: rgb_w needs the lean h8 epilogue (no per-pixel operand maps), every output channel in one block (Cout <= 64), rgb_bias / rgb_out, a 16-byte aligned rgb_w");
     size_t lds = (size_t)(2 * G::IN_STAGE + 2 * WSLOTS) * 16;
     if (OUT32 && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: tile does not fit the LDS");

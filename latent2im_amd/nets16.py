@@ -43,6 +43,9 @@ LRELU_MASK = (SQRT2, 0.2 * SQRT2)
 # (l2i_conv_img_h8, csrc/l2i_img_h8.hip), the stem's input gradient READS h8 (l2i_conv_params::in_h8): no padded 16 / 32-channel 16-bit copy of the
 # image, no fp32 stem map, no cast passes (-6 GB of the step's HBM traffic at 1024^2 batch 8).  L2I_H8_IMG_CONVS=0: the round-4 form (A/B).
 IMG_CONVS = os.environ.get('L2I_H8_IMG_CONVS', '1') != '0'
+# [r5] ToRGB of the 512^2 / 1024^2 StyledConv outputs (64 / 32 channels: one block of the conv holds them all) in that conv's epilogue
+# (l2i_conv_params::rgb_w) instead of a pass that reads the feature map again.  L2I_H8_RGB_FUSED=0: the separate l2i_torgb_fwd_h8 launch (A/B).
+RGB_FUSED = os.environ.get('L2I_H8_RGB_FUSED', '1') != '0'
 
 PROBE = None            # tools/bf16_study.py --probe: a list that receives (tag, shape, max |g|, median |g| of the non-zero entries) per gradient map
 
@@ -455,7 +458,12 @@ class _Synthesis16Fn(torch.autograd.Function):
                 y = K16.upfirdn2d(t, L.blur_k, pad=(1, 1, 1, 1), noise=nz, noise_w=L.noise_w, bias=L.bias, sep=L.blur_sep, **lr)
                 del t
             else:
-                y = L.conv.forward(x, planes=planes, w_bstride=bstride, out_scale=demod, noise=nz, noise_w=L.noise_w, bias=L.bias, **lr)
+                has_rgb = li == 0 or li % 2 == 0
+                rgb = None
+                if has_rgb and RGB_FUSED and L.cout <= 64:                     # ToRGB in this conv's epilogue (the block holds every channel of its pixels)
+                    rgb = torch.empty(B, 3, res, res, device=dev, dtype=torch.float32)
+                y = L.conv.forward(x, planes=planes, w_bstride=bstride, out_scale=demod, noise=nz, noise_w=L.noise_w, bias=L.bias,
+                                   rgb=None if rgb is None else (plan.wmod(w_all, B, li // 2), gen.rgbs[li // 2].bias, rgb), **lr)
             del planes
             if PROBE is not None and li % 2 == 0:
                 _probe('G.fwd.y%d@%d' % (li, res), y)
@@ -463,7 +471,8 @@ class _Synthesis16Fn(torch.autograd.Function):
             if li == 0 or (li % 2 == 0):
                 R = gen.rgbs[li // 2]
                 wmod = plan.wmod(w_all, B, li // 2)
-                rgb = K16.torgb_fwd(y, wmod, R.bias)                           # fp32 [B,3,H,W]: the skip image stays fp32
+                if L.up or not (RGB_FUSED and L.cout <= 64):
+                    rgb = K16.torgb_fwd(y, wmod, R.bias)                       # fp32 [B,3,H,W]: the skip image stays fp32
                 skip = K.upfirdn2d(skip, R.up_k, up=(2, 2), pad=(2, 1, 2, 1), addend=rgb) if R.up else rgb
                 rec['wmod'] = wmod
             saved.append(rec)

@@ -121,6 +121,32 @@ def test_stem_input_gradient_from_h8():
         assert float((got.double().cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize('cout, cin, h, w', [(32, 64, 24, 40), (64, 64, 17, 70), (32, 32, 40, 33)])
+def test_conv_h8_fused_torgb(cout, cin, h, w):
+    """[r5] l2i_conv_params::rgb_w: the modulated 3x3 conv of the 512^2 / 1024^2 generator blocks also writes the ToRGB image of its output
+    (networks.py:349-358 after 503-505): rgb = bias + sum_c wmod[b, o, c] * y[c] with y the conv's epilogue value (demodulation, noise, bias, leaky
+    ReLU) in fp32, before the 16-bit store; the h8 output itself is unchanged (bit-identical to the launch without rgb_w)."""
+    rs = np.random.RandomState(cout + h)
+    b = 2
+    wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    x, d, bias, nz = T(rs.randn(b, cin, h, w)), T(rs.rand(b, cout) + 0.5), T(rs.randn(cout)), T(rs.randn(b, 1, h, w))
+    wmod, rb = T(rs.randn(b, 3, cout) / np.sqrt(cout)), T(rs.randn(3))
+    g = lambda t: t.to(DEV)
+    hc = conv.H8Conv(wt, 1, 1, device=DEV)
+    xh = conv.to_h8(g(x), 32)
+    kw = dict(out_scale=g(d), noise=g(nz), noise_w=0.3, bias=g(bias), act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)
+    y0 = hc.forward(xh, **kw)
+    rgb = torch.full((b, 3, h, w), float('nan'), device=DEV)
+    y1 = hc.forward(xh, rgb=(g(wmod), g(rb), rgb), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    ref = F.leaky_relu(F.conv2d(bf(x), bf(wt), padding=1) * d.double()[:, :, None, None] + nz.double() * 0.3 + bias.double()[None, :, None, None], 0.2) * 2 ** 0.5
+    want = torch.einsum('boc,bchw->bohw', wmod.double(), ref) + rb.double()[None, :, None, None]
+    assert float((rgb.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    with pytest.raises(_lib.L2IError):                       # the lean epilogue only: a per-pixel operand map is refused, not silently dropped
+        hc.forward(xh, rgb=(g(wmod), g(rb), rgb), out_mask=y0, **kw)
+
+
 def test_conv_h8_epilogue_fusions_and_fp32_output():
     rs = np.random.RandomState(5)
     b, cin, cout, h, w = 2, 64, 64, 24, 40
