@@ -203,6 +203,11 @@ int l2i_sqdiff_h8(float* sum_out, void* grad, const void* a, const void* b, int6
 int l2i_add_zero_insert_h8(void* y, const void* c, const void* mask, int64_t planes, int H, int W, int OH, int OW, void* stream);   /* mask (h8 like y, or NULL): c * (mask[2oy,2ox] > 0) */
 int l2i_mask_mul_h8(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream);                     /* y = g * (ref > 0 ? pos : neg) */
 int l2i_modulate_planes_h8(void* planes, const float* w32, const float* s, int B, int Cs, int CinP, int KK, int CoutP, void* stream);
+/* [r5] l2i_modulate_planes_h8 for every modulated conv of a generator pass in one launch.  `table` (device): nseg rows of eight int64 — w32 offset
+ * (floats from `w32`), scale offset (floats from `s`: the layer's [B, Cs] block), output offset (16-byte slots from `planes`: the layer's
+ * [B][slots per sample] block), slots per sample (= CinP/16 * KK * 2 * CoutP), KK, CoutP, Cs (= CinP), first block of the segment (ascending,
+ * row 0 = 0); `nblocks` = grid size (blocks of a segment = next row's first block - its own).  networks.py:234-235 per layer. */
+int l2i_modulate_planes_multi_h8(void* planes, const float* w32, const float* s, const void* table, int nseg, int B, int nblocks, void* stream);
 
 /* [r5] The same sixteen entry points with IEEE fp16 (binary16) elements instead of bf16 — BASELINE configs[4] names "fp16 MFMA"; what the reference
  * would run under autocast on networks.py:231-272.  Identical signatures, layouts and fusions; the contraction is v_mfma_f32_32x32x16_f16 (same rate
@@ -227,6 +232,7 @@ int l2i_sqdiff_h8_f16(float* sum_out, void* grad, const void* a, const void* b, 
 int l2i_add_zero_insert_h8_f16(void* y, const void* c, const void* mask, int64_t planes, int H, int W, int OH, int OW, void* stream);
 int l2i_mask_mul_h8_f16(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream);
 int l2i_modulate_planes_h8_f16(void* planes, const float* w32, const float* s, int B, int Cs, int CinP, int KK, int CoutP, void* stream);
+int l2i_modulate_planes_multi_h8_f16(void* planes, const float* w32, const float* s, const void* table, int nseg, int B, int nblocks, void* stream);
 
 /* out[i] = act_grad_table(x[i] + b[(i / step_b) % size_b], ref[i]) * scale   — the reference op, all six
  * act*10+grad cases (fused_bias_act_kernel.cu:36-47).  b / ref may be NULL (= the reference's empty tensors). */

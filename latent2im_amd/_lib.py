@@ -103,6 +103,7 @@ _SIGNATURES = {
     'l2i_add_zero_insert_h8': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p]),
     'l2i_mask_mul_h8': (c_i, [c_p, c_p, c_p, c_f, c_f, c_l, c_p]),
     'l2i_modulate_planes_h8': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'l2i_modulate_planes_multi_h8': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     'l2i_segmented_matvec_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     'l2i_last_error': (ctypes.c_char_p, []),
     'l2i_abi_version': (c_i, []),

@@ -859,6 +859,39 @@ extern "C" int H8_NAME(l2i_modulate_planes_h8)(void* planes, const float* w32, c
     return L2I_OK;
 }
 
+// [r5] Every layer of a pass in ONE launch (the generator's forward folds the style into 17 plane sets, its backward the demodulation factor into 17
+// more: 51 launches of 15 us per step).  `table`: nseg rows of 8 int64 on the device — {w32 offset (floats), s offset (floats: the layer's [B, Cs]
+// block), output offset (16-byte slots: the layer's [B][slots per sample] block), slots per sample, KK, CoutP, Cs, first block of the segment} —
+// blocks [first, next first) walk their segment grid-stride.
+struct ModSeg { long long w_off, s_off, out_off, sps, KK, CoutP, Cs, first; };
+__global__ __launch_bounds__(256) void modulate_planes_multi_kernel(u32x4* __restrict__ planes, const float* __restrict__ w32, const float* __restrict__ s, const ModSeg* __restrict__ table,
+                                                                    int nseg, int B, int nblocks) {
+    int sg = 0;
+    while (sg + 1 < nseg && (long long)blockIdx.x >= table[sg + 1].first) ++sg;
+    const ModSeg t = table[sg];
+    const long long nb = (sg + 1 < nseg ? table[sg + 1].first : (long long)nblocks) - t.first;
+    const long long total = t.sps * B;
+    const float* wl = w32 + t.w_off;
+    const float* sl = s + t.s_off;
+    u32x4* out = planes + t.out_off;
+    const int KK = (int)t.KK, CoutP = (int)t.CoutP, Cs = (int)t.Cs;
+    for (long long i = ((long long)blockIdx.x - t.first) * 256 + threadIdx.x; i < total; i += nb * 256) {
+        const long long b = i / t.sps, slot = i - b * t.sps;
+        const long long r = slot / CoutP;                      // ((c16 * KK + tap) * 2 + half)
+        const int half = (int)(r & 1), c16 = (int)((r >> 1) / KK);
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + slot * 8), w1 = *reinterpret_cast<const float4*>(wl + slot * 8 + 4);
+        const float* sp = sl + b * Cs + 16 * c16 + 8 * half;
+        float v[8] = {w0.x * sp[0], w0.y * sp[1], w0.z * sp[2], w0.w * sp[3], w1.x * sp[4], w1.y * sp[5], w1.z * sp[6], w1.w * sp[7]};
+        out[i] = pack8(v);
+    }
+}
+extern "C" int H8_NAME(l2i_modulate_planes_multi_h8)(void* planes, const float* w32, const float* s, const void* table, int nseg, int B, int nblocks, void* stream) {
+    if (!planes || !w32 || !s || !table || nseg <= 0 || B <= 0 || nblocks < nseg) return l2i_set_error(L2I_E_ARG, "modulate_planes_multi_h8: bad arguments");
+    hipLaunchKernelGGL(modulate_planes_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (u32x4*)planes, w32, s, (const ModSeg*)table, nseg, B, nblocks);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
+}
+
 // ---- y = g * (ref > 0 ? pos : neg): a gradient through a (leaky) ReLU whose output `ref` was saved (the conv kernels of this path have no
 // prologue, so a mask that cannot ride on the producing epilogue — the gradient also feeds an unmasked branch — is one pass) ----------------------
 __global__ __launch_bounds__(256) void mask_mul_h8_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ g, const u32x4* __restrict__ ref, float pos, float neg, long long n) {

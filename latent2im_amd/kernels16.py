@@ -171,3 +171,45 @@ def modulate_planes(w32, s, dtype=None):
     planes = torch.empty((B,) + tuple(w32.shape), device=w32.device, dtype=torch.int16)
     _lib.check(_fn(lib, 'l2i_modulate_planes_h8', dtype)(_lib.ptr(planes), _lib.fptr(w32), _lib.fptr(s), B, c16 * 16, c16 * 16, kk, coutp, _lib.stream_ptr()), 'l2i_modulate_planes_h8')
     return planes
+
+
+class ModulatePlan:
+    """[r5] The weight planes of EVERY modulated conv of a generator pass in one launch (l2i_modulate_planes_multi_h8): ``w32s`` = the layers' fp32
+    weights in plane order (conv.pack_weight_h8_f32), ``s_offsets`` = rows before each layer's block in the per-layer-contiguous scale buffer
+    ([layer][B][C], generator._ModPlan: s_all for the forward, demod_all for the backward).  ``run(scales, B)`` returns one int16 view
+    [B, Cin/16, KK, 2, CoutP, 8] per layer of one buffer."""
+    BLOCK_SLOTS = 256 * 8                      # slots a block handles at most per pass of its grid-stride loop
+
+    def __init__(self, w32s, s_offsets, device):
+        self.shapes = [tuple(w.shape) for w in w32s]
+        self.w32 = torch.cat([w.reshape(-1) for w in w32s]).contiguous().to(device)
+        self.w_off = [0]
+        for w in w32s[:-1]:
+            self.w_off.append(self.w_off[-1] + w.numel())
+        self.s_off = list(s_offsets)
+        self.sps = [w.numel() // 8 for w in w32s]
+        self.device = device
+        self._tables = {}
+
+    def _table(self, B):
+        if B not in self._tables:
+            rows, out_off, first = [], 0, 0
+            for (c16, kk, _, coutp, _), w_off, s_off, sps in zip(self.shapes, self.w_off, self.s_off, self.sps):
+                rows.append([w_off, s_off * B, out_off, sps, kk, coutp, c16 * 16, first])
+                out_off += sps * B
+                first += max(1, min((sps * B + self.BLOCK_SLOTS - 1) // self.BLOCK_SLOTS, 1024))
+            self._tables[B] = (torch.tensor(rows, dtype=torch.int64).to(self.device), out_off, first)
+        return self._tables[B]
+
+    def run(self, scales, B, dtype=None):
+        lib = _lib.load()
+        dtype = dtype or h8_dtype()
+        table, slots, nblocks = self._table(B)
+        planes = torch.empty(slots * 8, device=self.w32.device, dtype=torch.int16)
+        _lib.check(_fn(lib, 'l2i_modulate_planes_multi_h8', dtype)(_lib.ptr(planes), _lib.fptr(self.w32), _lib.fptr(scales), _lib.ptr(table), len(self.shapes), B, nblocks, _lib.stream_ptr()),
+                   'l2i_modulate_planes_multi_h8')
+        views, off = [], 0
+        for shp, sps in zip(self.shapes, self.sps):
+            views.append(planes[off * 8:(off + sps * B) * 8].view((B,) + shp))
+            off += sps * B
+        return views

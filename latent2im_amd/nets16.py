@@ -46,6 +46,9 @@ IMG_CONVS = os.environ.get('L2I_H8_IMG_CONVS', '1') != '0'
 # [r5] ToRGB of the 512^2 / 1024^2 StyledConv outputs (64 / 32 channels: one block of the conv holds them all) in that conv's epilogue
 # (l2i_conv_params::rgb_w) instead of a pass that reads the feature map again.  L2I_H8_RGB_FUSED=0: the separate l2i_torgb_fwd_h8 launch (A/B).
 RGB_FUSED = os.environ.get('L2I_H8_RGB_FUSED', '1') != '0'
+# [r5] the per-sample weight planes of all modulated convs of a pass in ONE launch (kernels16.ModulatePlan) instead of one 15 us launch per layer and
+# pass (51 per step).  L2I_H8_MOD_MULTI=0: per layer (A/B).
+MOD_MULTI = os.environ.get('L2I_H8_MOD_MULTI', '1') != '0'
 
 PROBE = None            # tools/bf16_study.py --probe: a list that receives (tag, shape, max |g|, median |g| of the non-zero entries) per gradient map
 
@@ -427,6 +430,10 @@ class Generator(_Generator32):
             self.rgbs.append(_ToRGB(P, 'to_rgbs.%d' % j, geo[2 + 2 * j][2], True, device))
         self.randomize_noise = True
         self.modplan = _ModPlan(self, device)
+        self.mod_fwd = self.mod_bwd = None
+        if MOD_MULTI:
+            self.mod_fwd = K16.ModulatePlan([L.w32_fwd for L in self.layers], self.modplan.s_off[:len(self.layers)], device)
+            self.mod_bwd = K16.ModulatePlan([L.w32_bwd for L in self.layers], self.modplan.d_off, device)
 
     def synthesis(self, latent, noise=None):
         return _Synthesis16Fn.apply(latent, self, noise)
@@ -446,12 +453,13 @@ class _Synthesis16Fn(torch.autograd.Function):
         skip = None
         lr = dict(act=C.ACT_LRELU, slope=0.2, gain=SQRT2)
         drawn = _draw_noise(gen, noise, B, dev)
+        planes_all = gen.mod_fwd.run(s_all, B, gen.dtype) if gen.mod_fwd is not None else None      # weight * style for every layer (networks.py:234-235)
         for li, L in enumerate(gen.layers):
             s, demod = plan.s(s_all, B, li), plan.demod(d_all, B, li)
             h = x.shape[2]
             res = h * 2 if L.up else h
             nz = _noise_for(gen, noise, li, B, res, dev, drawn)
-            planes = K16.modulate_planes(L.w32_fwd, s, dtype=gen.dtype)        # weight * style, one plane set per sample (networks.py:234-235)
+            planes = planes_all[li] if planes_all is not None else K16.modulate_planes(L.w32_fwd, s, dtype=gen.dtype)        # weight * style, one plane set per sample
             bstride = planes[0].numel() * 2
             if L.up:
                 t = L.conv.forward(x, planes=planes, w_bstride=bstride, out_scale=demod)          # (2H+1)^2
@@ -477,6 +485,7 @@ class _Synthesis16Fn(torch.autograd.Function):
                 rec['wmod'] = wmod
             saved.append(rec)
             x = y
+        planes_all = None
         ctx.gen, ctx.saved, ctx.B = gen, saved if keep else None, B
         ctx.mod = (s_all, d_all) if keep else None
         return skip
@@ -499,6 +508,7 @@ class _Synthesis16Fn(torch.autograd.Function):
             if j > 0:
                 g = K.upfirdn2d(g, gen.rgbs[j].up_k_flip, up=(1, 1), down=(2, 2), pad=(1, 1, 1, 1))
         gin, gin_scale = None, None
+        planes_all = gen.mod_bwd.run(d_all, B, gen.dtype) if gen.mod_bwd is not None else None     # the gradient convs' weights carry the demodulation factor
         for li in range(len(gen.layers) - 1, -1, -1):
             L, rec = gen.layers[li], saved[li]
             has_rgb = 'wmod' in rec
@@ -508,7 +518,7 @@ class _Synthesis16Fn(torch.autograd.Function):
             demod, s = rec['demod'], rec['s']
             x = rec['x']
             hw = (x.shape[2], x.shape[3])
-            planes = K16.modulate_planes(L.w32_bwd, demod, dtype=gen.dtype)    # the gradient conv's weights carry the demodulation factor
+            planes = planes_all[li] if planes_all is not None else K16.modulate_planes(L.w32_bwd, demod, dtype=gen.dtype)
             bstride = planes[0].numel() * 2
             if L.up:
                 dt = K16.upfirdn2d(dz, L.blur_k_flip, pad=(2, 2, 2, 2), sep=L.blur_flip_sep)        # gradient of the (2H+1)^2 map under the blur

@@ -515,3 +515,22 @@ def test_train_multi_attr_cli_config5_flow_bf16_hipgraph(tmp_path):
     finally:
         conv.PRECISION = old
         constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
+def test_modulate_planes_multi_matches_per_layer():
+    """[r5] l2i_modulate_planes_multi_h8 (every modulated conv of a pass in one launch; networks.py:234-235 per layer) against the per-layer
+    l2i_modulate_planes_h8: bit-identical planes."""
+    from latent2im_amd import kernels16 as K16
+    rs = np.random.RandomState(9)
+    shapes = [(64, 32, 9), (32, 96, 9), (128, 64, 1), (32, 32, 9)]                 # cin, cout, taps
+    w32s = [conv.pack_weight_h8_f32(T(rs.randn(co, ci, int(kk ** 0.5), int(kk ** 0.5)))).to(DEV) for ci, co, kk in shapes]
+    B = 3
+    rows = [ci for ci, _, _ in shapes]
+    offs = [int(v) for v in np.concatenate([[0], np.cumsum(rows)[:-1]])]
+    s_all = T(rs.rand(B * sum(rows)) + 0.5).to(DEV)
+    plan = K16.ModulatePlan(w32s, offs, DEV)
+    views = plan.run(s_all, B)
+    torch.cuda.synchronize()
+    for w32, off, ci, v in zip(w32s, offs, rows, views):
+        want = K16.modulate_planes(w32, s_all[B * off:B * (off + ci)].view(B, ci).contiguous())
+        assert v.shape == want.shape and torch.equal(v, want)
