@@ -33,6 +33,9 @@ template <int K, int S> struct Geo {
     static constexpr int IWP = IW | 1;                                     // odd pitch: the stride-2 reads of the stem spread over the banks
     static constexpr int PLANE = IH * IWP;
     static constexpr int ZPAD = 8;                                         // zeros behind the tile: rows p >= Cin K read them
+    // tiles a block walks along x (the next tile's image loads fly during this tile's MFMAs and stores).  Measured at 1024^2 batch 8, NT = 1 / 4:
+    // 1x1 0.192 / 0.160 ms, 7x7 stride 2 0.233 / 0.200, 3x3 0.364 / 0.400 (0.503 / 0.634 with the ContentLoss sum): the 3x3 keeps one tile per block
+    static constexpr int NT = K == 3 ? 1 : 4;
 };
 
 template <bool F16> struct Elem;
@@ -49,7 +52,7 @@ template <> struct Elem<true> {
 }  // namespace img8
 
 template <bool F16, int K, int S>
-__global__ __launch_bounds__(256, 2) void conv_img_h8_kernel(const l2i_conv_params p, int tiles_x, int tiles_y, int mblocks, int nsteps, int tile_f) {
+__global__ __launch_bounds__(256, K <= 3 ? 4 : 2) void conv_img_h8_kernel(const l2i_conv_params p, int tiles_x, int tiles_y, int mblocks, int nsteps, int tile_f) {
     using namespace img8;
     using G = Geo<K, S>;
     using E = Elem<F16>;
@@ -59,30 +62,47 @@ __global__ __launch_bounds__(256, 2) void conv_img_h8_kernel(const l2i_conv_para
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     int bid = blockIdx.x;
     const int mblk = bid % mblocks; bid /= mblocks;
-    const int tx = bid % tiles_x; bid /= tiles_x;
+    constexpr int NT = G::NT;
+    const int xgroups = (tiles_x + NT - 1) / NT;
+    const int txg = bid % xgroups; bid /= xgroups;
     const int ty = bid % tiles_y; bid /= tiles_y;
     const int b = bid, m0 = mblk * BM;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - p.pad_y, ix0 = ox0 * S - p.pad_x;
+    const int oy0 = ty * TH;
+    const int iy0 = oy0 * S - p.pad_y;
+    const int tx_first = txg * NT, nt = tiles_x - tx_first < NT ? tiles_x - tx_first : NT;
 
-    // ---- stage: weights (16-byte slots) and the halo tile (rows across waves, columns across lanes: no divisions) ----
+    // ---- stage: weights (16-byte slots) and the halo tile ----
     const u32x4* wg = reinterpret_cast<const u32x4*>(p.w_hi);
     for (int e = tid; e < nsteps * 2 * BM; e += 256) {
         const int r = e / BM, i = e - r * BM;                              // r = 2 step + half
         wl[e] = (m0 + i < p.CoutP) ? wg[(size_t)r * p.CoutP + m0 + i] : u32x4{0u, 0u, 0u, 0u};
     }
+    // every load of the thread is issued before the first LDS write (a row-by-row loop exposed one memory round trip per row: 8 - 16 per block)
     const size_t plane_x = (size_t)p.H * p.W;
-    for (int rr = wave; rr < p.Cin * G::IH; rr += 4) {
-        const int c = rr / G::IH, r = rr - c * G::IH;
-        const int gy = iy0 + r;
-        const bool rok = gy >= 0 && gy < p.H;
-        const float* src = p.x + ((size_t)b * p.Cin + c) * plane_x + (size_t)(rok ? gy : 0) * p.W;
-        float* dst = tile + c * G::PLANE + r * G::IWP;
-        for (int col = lane; col < G::IWP; col += 64) {
-            const int gx = ix0 + col;
-            dst[col] = (rok && col < G::IW && gx >= 0 && gx < p.W) ? src[gx] : 0.f;
+    const float* xs = p.x + (size_t)b * p.Cin * plane_x;
+    constexpr int NE = (4 * G::PLANE + 255) / 256;                          // tile elements per thread at 4 input channels
+    const int nelem = p.Cin * G::PLANE;
+    float stg[NE];
+    auto load_tile = [&](int tx) {
+        const int ix0 = tx * TW * S - p.pad_x;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * 256;
+            const int c = e / G::PLANE, r2 = e - c * G::PLANE;
+            const int r = r2 / G::IWP, col = r2 - r * G::IWP;
+            const int gy = iy0 + r, gx = ix0 + col;
+            stg[i] = (e < nelem && col < G::IW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? xs[(size_t)c * plane_x + (size_t)gy * p.W + gx] : 0.f;
         }
-    }
+    };
+    auto commit_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * 256;
+            if (e < nelem) tile[e] = stg[i];
+        }
+    };
+    load_tile(tx_first);
+    commit_tile();
     float* const zpad = tile + p.Cin * G::PLANE;
     if (tid < G::ZPAD) zpad[tid] = 0.f;
     __syncthreads();
@@ -103,6 +123,10 @@ __global__ __launch_bounds__(256, 2) void conv_img_h8_kernel(const l2i_conv_para
     const float gneg = p.act == L2I_ACT_LRELU ? p.act_slope * p.act_gain * p.out_gain : (p.act == L2I_ACT_RELU ? 0.f : p.out_gain);
     float sq = 0.f;
 
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+    const int ox0 = (tx_first + t) * TW;
+    if (t + 1 < nt) load_tile(tx_first + t + 1);
 #pragma unroll 1
     for (int st = 0; st < 4; ++st) {
         const int row = 2 * wave + (st >> 1), cx = (st & 1) * 32;
@@ -165,6 +189,12 @@ __global__ __launch_bounds__(256, 2) void conv_img_h8_kernel(const l2i_conv_para
             }
         }
     }
+    if (t + 1 < nt) {
+        __syncthreads();                                                   // every wave is done with this tile
+        commit_tile();
+        __syncthreads();
+    }
+    }
     if (p.sq_ref) {                                                        // one atomic per block into L2I_SQ_SLOTS slots
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
@@ -181,7 +211,7 @@ static int launch_img(const l2i_conv_params& p, hipStream_t st) {
     using G = Geo<K, S>;
     const int nsteps = (p.Cin * K + 1) / 2;
     const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH, mblocks = (p.CoutP + BM - 1) / BM;
-    const long total = (long)p.B * tiles_y * tiles_x * mblocks;
+    const long total = (long)p.B * tiles_y * ((tiles_x + G::NT - 1) / G::NT) * mblocks;
     if (total <= 0 || total > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv_img_h8: grid too large");
     const int tile_f = (p.Cin * G::PLANE + G::ZPAD + 3) & ~3;
     const size_t lds = (size_t)tile_f * sizeof(float) + (size_t)nsteps * 2 * BM * 16;
