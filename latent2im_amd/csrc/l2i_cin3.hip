@@ -58,13 +58,24 @@ __global__ __launch_bounds__(256, 3) void conv_cin3_kernel(const l2i_conv_params
 
     // halo tile: 3 channels x 10 rows x 66 columns, zero outside the image (= the padding)
     const size_t plane_x = (size_t)p.H * p.W;
-    for (int e = tid; e < 3 * IH * IW; e += 256) {
+    // [r5] every load of the thread is issued before the first LDS write: the loop form (load, store, next element) exposed one memory round trip
+    // per element — eight per block, three blocks per CU
+    constexpr int NE = (3 * IH * IW + 255) / 256;
+    float stg[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + i * 256;
         const int c = e / (IH * IW), r2 = e - c * (IH * IW);
         const int iy = r2 / IW, ix = r2 - iy * IW;
         const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
-        float v = 0.f;
-        if (c < p.Cin && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = p.x[((size_t)b * p.Cin + c) * plane_x + (size_t)gy * p.W + gx];
-        tile[c * PLANE + iy * IWp + ix] = v;
+        stg[i] = (e < 3 * IH * IW && c < p.Cin && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? p.x[((size_t)b * p.Cin + c) * plane_x + (size_t)gy * p.W + gx] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + i * 256;
+        const int c = e / (IH * IW), r2 = e - c * (IH * IW);
+        const int iy = r2 / IW, ix = r2 - iy * IW;
+        if (e < 3 * IH * IW) tile[c * PLANE + iy * IWp + ix] = stg[i];
     }
     __syncthreads();
 
