@@ -194,7 +194,7 @@ int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t planes, int
                         register-streaming separable kernel) */
 int l2i_torgb_fwd_h8(float* rgb, const void* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream);
 int l2i_sg2_act_bwd_h8(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
-                       const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream);
+                       const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, float* red_gin_y, int B, int C, int64_t HW, void* stream);
 int l2i_dot_reduce_h8(float* out, const void* a, const void* b, int B, int C, int64_t HW, void* stream);
 int l2i_maxpool2d_fwd_h8(void* y, void* idx, const void* x, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, int relu, void* stream);
 int l2i_maxpool2d_bwd_h8(void* gx, const void* gy, const void* idx, const void* a, const void* b, float coef, const float* coef_dev, int64_t planes, int H, int W,
@@ -223,7 +223,7 @@ int l2i_upfirdn2d_h8_f16(void* y, const void* x, const float* k, int64_t planes,
                          float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, void* stream);
 int l2i_torgb_fwd_h8_f16(float* rgb, const void* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream);
 int l2i_sg2_act_bwd_h8_f16(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
-                           const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream);
+                           const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, float* red_gin_y, int B, int C, int64_t HW, void* stream);
 int l2i_dot_reduce_h8_f16(float* out, const void* a, const void* b, int B, int C, int64_t HW, void* stream);
 int l2i_maxpool2d_fwd_h8_f16(void* y, void* idx, const void* x, int64_t planes, int H, int W, int k, int s, int pad, int OH, int OW, int relu, void* stream);
 int l2i_maxpool2d_bwd_h8_f16(void* gx, const void* gy, const void* idx, const void* a, const void* b, float coef, const float* coef_dev, int64_t planes, int H, int W,
@@ -278,10 +278,13 @@ int l2i_torgb_fwd_f32(float* rgb, const float* x, const float* wmod, const float
  *   dz     = g * (y > 0 ? gain : gain*slope)                                        -> dz[idx]
  *   zpre   = (y > 0 ? y/gain : y/(gain*slope)) - bias[c] - noise[b,p]*noise_w
  *   red_dz_z[b,c] += sum_p dz*zpre            (-> d demod)        red_x_grgb[b,c,o] += sum_p y*grgb[b,o,p]  (-> d s_rgb)
+ *   [r5] red_gin_y[b,c] += sum_p gin*y  (NULL: not formed) — y is the INPUT of the next layer and gin the gradient w.r.t. that layer's modulated input,
+ *   so this is the next layer's style gradient d s (networks.py:234-235: x * s), formed while both maps pass through registers instead of by a
+ *   l2i_dot_reduce pass that reads them again.
  * Reduction buffers must be zeroed by the caller. */
 int l2i_sg2_act_bwd_f32(float* dz, const float* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb,
                         const float* y, const float* bias, const float* noise, float noise_w, float slope, float gain,
-                        float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream);
+                        float* red_dz_z, float* red_x_grgb, float* red_gin_y, int B, int C, int64_t HW, void* stream);
 
 /* out[r] (+)= sum_p a[r,p] * (b ? b[r,p] : 1), r < rows (rows = B*C).  `out` must be zeroed by the caller. */
 int l2i_dot_reduce_f32(float* out, const float* a, const float* b, int64_t rows, int64_t cols, void* stream);

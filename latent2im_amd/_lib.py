@@ -74,7 +74,7 @@ _SIGNATURES = {
     'l2i_upfirdn2d_masked_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                        c_i, c_p, c_f, c_p, c_p, c_i, c_f, c_f, c_p, c_f, c_f, c_p]),
     'l2i_torgb_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
-    'l2i_sg2_act_bwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_l, c_p]),
+    'l2i_sg2_act_bwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
     'l2i_dot_reduce_f32': (c_i, [c_p, c_p, c_p, c_l, c_l, c_p]),
     'l2i_maxpool2d_fwd_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'l2i_maxpool2d_bwd_f32': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -95,7 +95,7 @@ _SIGNATURES = {
     'l2i_cast_h8_to_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_l, c_p]),
     'l2i_upfirdn2d_h8': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_f, c_p, c_i, c_f, c_f, c_p, c_f, c_f, c_p, c_p, c_p, c_p]),
     'l2i_torgb_fwd_h8': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
-    'l2i_sg2_act_bwd_h8': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_l, c_p]),
+    'l2i_sg2_act_bwd_h8': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
     'l2i_dot_reduce_h8': (c_i, [c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
     'l2i_maxpool2d_fwd_h8': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'l2i_maxpool2d_bwd_h8': (c_i, [c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -585,7 +585,7 @@ extern "C" int l2i_torgb_fwd_f32(float* rgb, const float* x, const float* wmod, 
 // ---------------------------------------------------------------------------------------------------------------
 struct ActBwdParams {
     float* dz; const float* gin; const float* gin_scale; const float* grgb; const float* wmod_rgb; const float* y;
-    const float* bias; const float* noise; float noise_w, slope, gain; float* red_dz_z; float* red_x_grgb;
+    const float* bias; const float* noise; float noise_w, slope, gain; float* red_dz_z; float* red_x_grgb; float* red_gin_y;
     int B, C; long long HW; int chunks;
 };
 
@@ -610,11 +610,15 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(const ActBwdParams p) 
     const float4* r1 = r0 ? r0 + hw4 : nullptr;
     const float4* r2 = r0 ? r1 + hw4 : nullptr;
     float4* d4 = reinterpret_cast<float4*>(p.dz + (long long)row * p.HW);
-    float s_dz = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float s_dz = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s_gy = 0.f;
     for (long long i = (long long)chunk * 256 + threadIdx.x; i < hw4; i += (long long)p.chunks * 256) {
         const float4 yv = y4[i];
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g4) { const float4 t = g4[i]; g.x = t.x * gs; g.y = t.y * gs; g.z = t.z * gs; g.w = t.w * gs; }
+        if (g4) {
+            const float4 t = g4[i];
+            g.x = t.x * gs; g.y = t.y * gs; g.z = t.z * gs; g.w = t.w * gs;
+            s_gy += t.x * yv.x + t.y * yv.y + t.z * yv.z + t.w * yv.w;         // [r5] red_gin_y: both maps are in registers anyway
+        }
         if (r0) {
             const float4 a = r0[i], bq = r1[i], cq = r2[i];
             g.x += a.x * w0 + bq.x * w1 + cq.x * w2; g.y += a.y * w0 + bq.y * w1 + cq.y * w2;
@@ -632,14 +636,16 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(const ActBwdParams p) 
                 d.z * (yv.z * (yv.z > 0.f ? ipos : ineg) - bia - nz.z) + d.w * (yv.w * (yv.w > 0.f ? ipos : ineg) - bia - nz.w);
         d4[i] = d;
     }
-    __shared__ float red[4][4];
+    __shared__ float red[4][5];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     s_dz = wave_sum(s_dz);
     if (r0) { s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); }
-    if (lane == 0) { red[wv][0] = s_dz; red[wv][1] = s0; red[wv][2] = s1; red[wv][3] = s2; }
+    if (g4 && p.red_gin_y) s_gy = wave_sum(s_gy);
+    if (lane == 0) { red[wv][0] = s_dz; red[wv][1] = s0; red[wv][2] = s1; red[wv][3] = s2; red[wv][4] = s_gy; }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (p.red_dz_z) atomicAdd(p.red_dz_z + row, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+        if (g4 && p.red_gin_y) atomicAdd(p.red_gin_y + row, red[0][4] + red[1][4] + red[2][4] + red[3][4]);
         if (r0 && p.red_x_grgb) {
             atomicAdd(p.red_x_grgb + (long long)row * 3 + 0, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
             atomicAdd(p.red_x_grgb + (long long)row * 3 + 1, red[0][2] + red[1][2] + red[2][2] + red[3][2]);
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(const ActBwdParams p) 
 
 extern "C" int l2i_sg2_act_bwd_f32(float* dz, const float* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb,
                                    const float* y, const float* bias, const float* noise, float noise_w, float slope, float gain,
-                                   float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream) {
+                                   float* red_dz_z, float* red_x_grgb, float* red_gin_y, int B, int C, int64_t HW, void* stream) {
     if (!dz || !y) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd: null tensor");
     if (!gin && !grgb) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd: need gin and/or grgb");
     if (grgb && !wmod_rgb) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd: grgb needs wmod_rgb");
@@ -658,7 +664,7 @@ extern "C" int l2i_sg2_act_bwd_f32(float* dz, const float* gin, const float* gin
     if (gain == 0.f || slope == 0.f) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd: gain and slope must be non-zero");
     ActBwdParams p;
     p.dz = dz; p.gin = gin; p.gin_scale = gin_scale; p.grgb = grgb; p.wmod_rgb = wmod_rgb; p.y = y; p.bias = bias; p.noise = noise;
-    p.noise_w = noise_w; p.slope = slope; p.gain = gain; p.red_dz_z = red_dz_z; p.red_x_grgb = red_x_grgb; p.B = B; p.C = C; p.HW = HW;
+    p.noise_w = noise_w; p.slope = slope; p.gain = gain; p.red_dz_z = red_dz_z; p.red_x_grgb = red_x_grgb; p.red_gin_y = red_gin_y; p.B = B; p.C = C; p.HW = HW;
     const long long rows = (long long)B * C;
     long long chunks = (HW / 4 + 1023) / 1024;          // >= 4 float4 per thread
     const long long cap = (256 * 16 + rows - 1) / rows;

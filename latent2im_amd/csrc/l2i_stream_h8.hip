@@ -537,7 +537,7 @@ static int h8_strips(long long groups, long long HW) {
 __global__ __launch_bounds__(256) void sg2_act_bwd_h8_kernel(u32x4* __restrict__ dz, const u32x4* __restrict__ gin, const float* __restrict__ gin_scale,
                                                              const float* __restrict__ grgb, const float* __restrict__ wmod_rgb, const u32x4* __restrict__ y,
                                                              const float* __restrict__ bias, const float* __restrict__ noise, float noise_w, float slope, float gain,
-                                                             float* __restrict__ red_dz_z, float* __restrict__ red_x_grgb, int C, long long HW, int strips) {
+                                                             float* __restrict__ red_dz_z, float* __restrict__ red_x_grgb, float* __restrict__ red_gin_y, int C, long long HW, int strips) {
     const int G8 = C / 8;
     int bid = blockIdx.x;
     const int strip = bid % strips; bid /= strips;
@@ -551,9 +551,9 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_h8_kernel(u32x4* __restrict__
 #pragma unroll
         for (int o = 0; o < 3; ++o) wr[o][e] = wmod_rgb ? wmod_rgb[((size_t)b * 3 + o) * C + 8 * g + e] : 0.f;
     }
-    float r1[8], r2[3][8];
+    float r1[8], r2[3][8], r3[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { r1[e] = 0.f; r2[0][e] = r2[1][e] = r2[2][e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { r1[e] = 0.f; r2[0][e] = r2[1][e] = r2[2][e] = 0.f; r3[e] = 0.f; }
     const float gp = gain, gn = gain * slope, ip = 1.f / gain, in_ = 1.f / (gain * slope);
     const long long step = (long long)strips * 256;
     // two pixel slots per iteration, all loads of both issued before the arithmetic (a lane's second slot is `step` further: both coalesced)
@@ -580,6 +580,7 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_h8_kernel(u32x4* __restrict__
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float gg = gv[e] * sc[e];
+                r3[e] += gv[e] * yv[e];                               // [r5] red_gin_y: both maps are in registers anyway
                 gg += wr[0][e] * q[h][0] + wr[1][e] * q[h][1] + wr[2][e] * q[h][2];
                 const bool pos = yv[e] > 0.f;
                 d[e] = gg * (pos ? gp : gn);
@@ -592,12 +593,16 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_h8_kernel(u32x4* __restrict__
     }
     // block-level reduction: wave sums meet in LDS, ONE atomic per block and sum (the per-wave atomics of the first version were the
     // kernel's bound on the mid-resolution layers: 0.5 M same-address atomics per launch)
-    __shared__ float part[4][32];
+    __shared__ float part[4][40];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float s0 = wave_sum(r1[e]);
         if (lane == 0) part[wv][e] = s0;
+        if (gin && red_gin_y) {
+            const float t = wave_sum(r3[e]);
+            if (lane == 0) part[wv][32 + e] = t;
+        }
         if (red_x_grgb) {
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
@@ -613,15 +618,18 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_h8_kernel(u32x4* __restrict__
     } else if (threadIdx.x < 32 && red_x_grgb) {
         const int i = threadIdx.x;                              // 8 + 3 e + o
         atomicAdd(red_x_grgb + ((size_t)b * C + 8 * g) * 3 + (i - 8), part[0][i] + part[1][i] + part[2][i] + part[3][i]);
+    } else if (threadIdx.x >= 32 && threadIdx.x < 40 && gin && red_gin_y) {
+        const int i = threadIdx.x;                              // 32 + e
+        atomicAdd(red_gin_y + (size_t)b * C + 8 * g + (i - 32), part[0][i] + part[1][i] + part[2][i] + part[3][i]);
     }
 }
 extern "C" int H8_NAME(l2i_sg2_act_bwd_h8)(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
-                                  const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, int B, int C, int64_t HW, void* stream) {
+                                  const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, float* red_gin_y, int B, int C, int64_t HW, void* stream) {
     if (!dz || !y || !red_dz_z || B <= 0 || C <= 0 || (C % 8) != 0 || HW <= 0) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd_h8: bad arguments");
     if ((grgb != nullptr) != (wmod_rgb != nullptr)) return l2i_set_error(L2I_E_ARG, "sg2_act_bwd_h8: grgb and wmod_rgb go together");
     const int strips = h8_strips(B * (C / 8), HW);
     hipLaunchKernelGGL(sg2_act_bwd_h8_kernel, dim3((unsigned)(B * (C / 8) * strips)), dim3(256), 0, (hipStream_t)stream, (u32x4*)dz, (const u32x4*)gin, gin_scale, grgb, wmod_rgb,
-                       (const u32x4*)y, bias, noise, noise_w, slope, gain, red_dz_z, grgb ? red_x_grgb : nullptr, C, (long long)HW, strips);
+                       (const u32x4*)y, bias, noise, noise_w, slope, gain, red_dz_z, grgb ? red_x_grgb : nullptr, gin ? red_gin_y : nullptr, C, (long long)HW, strips);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
 }

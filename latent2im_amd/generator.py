@@ -354,8 +354,11 @@ class _SynthesisFn(torch.autograd.Function):
             L, rec = gen.layers[li], saved[li]
             has_rgb = 'wmod' in rec
             grgb = g_rgb[li // 2] if has_rgb else None
+            # [r5] gin (the gradient w.r.t. layer li + 1's modulated input) and y (that layer's input) both pass through this kernel: layer li + 1's
+            # style gradient sum_p gin * y is formed here instead of by a dot_reduce pass that reads both maps again
             dz, _, _ = K.sg2_act_bwd(rec['y'], gin, gin_scale, grgb, rec.get('wmod'), L.bias, rec['nz'], L.noise_w, 0.2, SQRT2,
-                                     red=plan.demod(red_dz, B, li), red_rgb=plan.red_rgb(red_rgb, B, li // 2) if has_rgb else None)
+                                     red=plan.demod(red_dz, B, li), red_rgb=plan.red_rgb(red_rgb, B, li // 2) if has_rgb else None,
+                                     red_q=plan.s(q_all, B, li + 1).view(-1) if gin is not None else None)
             demod, s = rec['demod'], rec['s']
             x = rec['x']
             hw = (x.shape[2], x.shape[3])
@@ -369,7 +372,8 @@ class _SynthesisFn(torch.autograd.Function):
             else:
                 dxmod = L.conv.dgrad(dz, hw, in_scale=demod)
                 del dz
-            K.dot_reduce(dxmod, x, out=plan.s(q_all, B, li).view(-1))                # [B,Cin] = d s via x*s
+            if li == 0:                                                               # (the constant input has no producing layer)
+                K.dot_reduce(dxmod, x, out=plan.s(q_all, B, li).view(-1))            # [B,Cin] = d s via x*s
             gin, gin_scale = dxmod, s
             rec['y'] = rec['x'] = None
         # d s = q - s * ((d demod * demod^3) T) for every conv, then the whole latent gradient (d s A, and d s_rgb A of the ToRGBs): two launches

@@ -72,9 +72,9 @@ def torgb_fwd(x, wmod, bias):
 
 
 def sg2_act_bwd(y, gin=None, gin_scale=None, grgb=None, wmod_rgb=None, bias=None, noise=None, noise_w=0.0,
-                slope=0.2, gain=SQRT2, want_rgb_red=True, red=None, red_rgb=None):
-    """Fused StyledConv elementwise backward (see l2i.h).  Returns (dz, red_dz_z [B,C], red_x_grgb [B,C,3] or None).  ``red`` / ``red_rgb``:
-    ZEROED destination buffers of the two reductions (views of one buffer zeroed once per backward pass); allocated here when absent."""
+                slope=0.2, gain=SQRT2, want_rgb_red=True, red=None, red_rgb=None, red_q=None):
+    """Fused StyledConv elementwise backward (see l2i.h).  Returns (dz, red_dz_z [B,C], red_x_grgb [B,C,3] or None).  ``red`` / ``red_rgb`` /
+    ``red_q`` ([r5] [B*C]: sum_p gin * y, the NEXT layer's style gradient): ZEROED destination buffers of the reductions (views of one buffer zeroed once per backward pass); allocated here when absent."""
     lib = _lib.load()
     b, c, h, w = y.shape
     dz = torch.empty_like(y)
@@ -86,7 +86,7 @@ def sg2_act_bwd(y, gin=None, gin_scale=None, grgb=None, wmod_rgb=None, bias=None
         red_rgb = None
     _lib.check(lib.l2i_sg2_act_bwd_f32(_lib.fptr(dz), _lib.fptr(gin), _lib.fptr(gin_scale), _lib.fptr(grgb),
                                        _lib.fptr(wmod_rgb), _lib.fptr(y), _lib.fptr(bias), _lib.fptr(noise),
-                                       float(noise_w), float(slope), float(gain), _lib.fptr(red), _lib.fptr(red_rgb),
+                                       float(noise_w), float(slope), float(gain), _lib.fptr(red), _lib.fptr(red_rgb), _lib.fptr(red_q),
                                        b, c, h * w, _lib.stream_ptr()), 'l2i_sg2_act_bwd_f32')
     return dz, red, red_rgb
 

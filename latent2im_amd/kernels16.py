@@ -95,13 +95,13 @@ def torgb_fwd(x, wmod, bias):
     return rgb
 
 
-def sg2_act_bwd(y, gin, gin_scale, grgb, wmod_rgb, bias, noise, noise_w, slope, gain, red, red_rgb=None):
-    """Fused StyledConv elementwise backward on h8 maps (l2i_sg2_act_bwd_h8): returns dz (h8); ``red`` [B,C] / ``red_rgb`` [B,C,3] are ZEROED fp32 buffers."""
+def sg2_act_bwd(y, gin, gin_scale, grgb, wmod_rgb, bias, noise, noise_w, slope, gain, red, red_rgb=None, red_q=None):
+    """Fused StyledConv elementwise backward on h8 maps (l2i_sg2_act_bwd_h8): returns dz (h8); ``red`` [B,C] / ``red_rgb`` [B,C,3] / ``red_q`` ([r5] [B*C]: sum_p gin * y, the next layer's style gradient) are ZEROED fp32 buffers."""
     lib = _lib.load()
     B, G8, H, W, _ = y.shape
     dz = torch.empty_like(y)
     _lib.check(_fn(lib, 'l2i_sg2_act_bwd_h8', y.dtype)(_lib.ptr(dz), None if gin is None else _h8(gin), _lib.fptr(gin_scale), _lib.fptr(grgb), _lib.fptr(wmod_rgb), _h8(y), _lib.fptr(bias),
-                                      _lib.fptr(noise), float(noise_w), float(slope), float(gain), _lib.fptr(red), _lib.fptr(red_rgb), B, G8 * 8, H * W,
+                                      _lib.fptr(noise), float(noise_w), float(slope), float(gain), _lib.fptr(red), _lib.fptr(red_rgb), _lib.fptr(red_q), B, G8 * 8, H * W,
                                       _lib.stream_ptr()), 'l2i_sg2_act_bwd_h8')
     return dz
 

@@ -514,7 +514,8 @@ class _Synthesis16Fn(torch.autograd.Function):
             has_rgb = 'wmod' in rec
             grgb = g_rgb[li // 2] if has_rgb else None
             dz = K16.sg2_act_bwd(rec['y'], gin, gin_scale, grgb, rec.get('wmod'), L.bias, rec['nz'], L.noise_w, 0.2, SQRT2,
-                                 plan.demod(red_dz, B, li), plan.red_rgb(red_rgb, B, li // 2) if has_rgb else None)
+                                 plan.demod(red_dz, B, li), plan.red_rgb(red_rgb, B, li // 2) if has_rgb else None,
+                                 red_q=plan.s(q_all, B, li + 1).view(-1) if gin is not None else None)      # layer li + 1's d s = sum_p gin * y (generator.py)
             demod, s = rec['demod'], rec['s']
             x = rec['x']
             hw = (x.shape[2], x.shape[3])
@@ -529,7 +530,8 @@ class _Synthesis16Fn(torch.autograd.Function):
                 dxmod = L.conv.dgrad(dz, hw, planes=planes, w_bstride=bstride)
                 del dz
             del planes
-            K16.dot_reduce(dxmod, x, out=plan.s(q_all, B, li).view(-1))          # d s via x * s
+            if li == 0:
+                K16.dot_reduce(dxmod, x, out=plan.s(q_all, B, li).view(-1))      # d s via x * s (layers >= 1: inside the next sg2_act_bwd)
             if PROBE is not None and (li % 2 == 0 or li == len(gen.layers) - 1):
                 _probe('G.dx%d@%d' % (li, hw[0]), dxmod)
             gin, gin_scale = dxmod, s

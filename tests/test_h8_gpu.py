@@ -265,9 +265,11 @@ def test_h8_torgb_act_bwd_reductions_sqdiff():
     assert float((rgb.double().cpu() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
     y, gin, gs, grgb = T(rs.randn(B, C, H, H)), T(rs.randn(B, C, H, H)), T(rs.rand(B, C) + 0.5), T(rs.randn(B, 3, H, H))
     cb, nz = T(rs.randn(C)), T(rs.randn(B, 1, H, H))
-    red, red_rgb = torch.zeros(B, C, device=DEV), torch.zeros(B, C, 3, device=DEV)
-    dz = K16.sg2_act_bwd(H8(y), H8(gin), g(gs), g(grgb), g(wm), g(cb), g(nz), 0.3, 0.2, 2 ** 0.5, red, red_rgb)
+    red, red_rgb, red_q = torch.zeros(B, C, device=DEV), torch.zeros(B, C, 3, device=DEV), torch.zeros(B * C, device=DEV)
+    dz = K16.sg2_act_bwd(H8(y), H8(gin), g(gs), g(grgb), g(wm), g(cb), g(nz), 0.3, 0.2, 2 ** 0.5, red, red_rgb, red_q=red_q)
     yb, gb = rb(y).double(), rb(gin).double()
+    # [r5] red_gin_y: the next layer's style gradient sum_p gin * y (what l2i_dot_reduce_h8 formed in a separate pass)
+    assert float((red_q.view(B, C).double().cpu() - (gb * yb).sum((2, 3))).abs().max()) < 1e-4 * float((gb * yb).abs().sum((2, 3)).max())
     gg = gb * gs.double()[:, :, None, None] + torch.einsum('bohw,boc->bchw', grgb.double(), wm.double())
     dz_ref = gg * torch.where(yb > 0, torch.tensor(2 ** 0.5, dtype=torch.float64), torch.tensor(0.2 * 2 ** 0.5, dtype=torch.float64))
     zpre = torch.where(yb > 0, yb / 2 ** 0.5, yb / (0.2 * 2 ** 0.5)) - cb.double()[None, :, None, None] - 0.3 * nz.double()

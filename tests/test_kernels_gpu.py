@@ -552,7 +552,9 @@ def test_torgb_and_act_bwd_and_reductions():
     # fused backward pass
     y, gin, gs, grgb = T(rs.randn(B, C, H, H)), T(rs.randn(B, C, H, H)), T(rs.rand(B, C) + 0.5), T(rs.randn(B, 3, H, H))
     cb, nz = T(rs.randn(C)), T(rs.randn(B, 1, H, H))
-    dz, red, red_rgb = kernels.sg2_act_bwd(y.to(DEV), gin.to(DEV), gs.to(DEV), grgb.to(DEV), wm.to(DEV), cb.to(DEV), nz.to(DEV), 0.3)
+    red_q = torch.zeros(B * C, device=DEV)
+    dz, red, red_rgb = kernels.sg2_act_bwd(y.to(DEV), gin.to(DEV), gs.to(DEV), grgb.to(DEV), wm.to(DEV), cb.to(DEV), nz.to(DEV), 0.3, red_q=red_q)
+    close(red_q.view(B, C), (gin * y).sum((2, 3)), 1e-4, 1e-3)          # [r5] red_gin_y: the next layer's style gradient, formed in the same pass
     g = gin * gs[:, :, None, None] + torch.einsum('bohw,boc->bchw', grgb, wm)
     dz_ref = g * torch.where(y > 0, torch.tensor(2 ** 0.5), torch.tensor(0.2 * 2 ** 0.5))
     zpre = torch.where(y > 0, y / 2 ** 0.5, y / (0.2 * 2 ** 0.5)) - cb[None, :, None, None] - 0.3 * nz
