@@ -22,7 +22,7 @@ import os
 import sys
 
 CONV = ('conv_wino_kernel', 'conv_wino4_kernel', 'conv_wino4s_kernel', 'conv_mfma_kernel', 'conv3x3s2_dma_kernel', 'gemm1x1_kernel', 'convt_mfma_kernel', 'conv_direct_small_kernel',
-        'conv_bf16x3_pipe_kernel', 'conv_cin3_kernel', 'splitk_epilogue_kernel', 'conv_h8_kernel')
+        'conv_bf16x3_pipe_kernel', 'conv_cin3_kernel', 'splitk_epilogue_kernel', 'conv_h8_kernel', 'conv_img_h8_kernel')
 WORKLOADS = {'c3': [1024, 8, ['Smiling'], 'f32', False],
              'c5': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'f16', False],        # [r5] config 5 runs fp16 elements
              'c5bf16': [1024, 8, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], 'bf16', False],
@@ -45,6 +45,8 @@ def family_of(kernel):
         return 'cin3_f32'
     if kernel.startswith('conv_direct_small_kernel'):
         return 'direct_small_valu'
+    if kernel.startswith('conv_img_h8_kernel'):           # [r5] the image-side convs of the 16-bit path: bench.py prices them in the conv_h8 family
+        return 'conv_h8'
     if kernel.startswith('conv_h8_kernel'):               # <WM, WN, K, S, TR, OUT32, RELU_IN, KS>
         args = kernel[kernel.index('<') + 1:kernel.rindex('>')].split(',')
         return 'transposed_h8' if args[4].strip() != '0' else 'conv_h8'
