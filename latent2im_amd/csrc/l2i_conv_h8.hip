@@ -664,7 +664,14 @@ extern "C" int H8_NAME(l2i_conv2d_h8)(const l2i_conv_params* pp, void* stream) {
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: 1x1 (pad 0) or 3x3 (pad 0 / 1) layers, stride 1 or 2, dense output window");
     if (p.oy_off < 0 || p.ox_off < 0 || p.OH + p.oy_off > p.OHf || p.OW + p.ox_off > p.OWf) return l2i_set_error(L2I_E_ARG, "conv2d_h8: output window exceeds the output tensor");
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = (p.CoutP % 64) == 0;
+    bool wide = (p.CoutP % 64) == 0;
+    {   // [r5] small maps: with 64-channel blocks a launch of a <= 32^2 map has fewer blocks than the chip has CUs and every block walks its 48 - 96
+        // phases alone on its CU (1 wave per SIMD: every barrier and DMA wait exposed); 32-channel blocks double the blocks (L2I_H8_SMALL_WM1=0: off)
+        static const int small_env = getenv("L2I_H8_SMALL_WM1") ? atoi(getenv("L2I_H8_SMALL_WM1")) : 1;
+        const int th = (p.KH == 3 && p.stride == 2) ? 4 : 8;
+        const long blocks64 = (long)p.B * ((p.OW + 31) / 32) * ((p.OH + th - 1) / th) * ((p.CoutP + 63) / 64);
+        if (small_env && wide && !p.out_f32 && !p.rgb_w && blocks64 < 256) wide = false;      // (measured, batch 8, 512 -> 512 3x3: 4^2 34.8 -> 26.5 us, 8^2 35.7 -> 27.5, 16^2 37.8 -> 30.4; 32^2 = 256 blocks: no difference)
+    }
     if (p.out_f32) {                                       // fp32 NCHW output (gradients landing on images, the last layer in front of an fp32 consumer)
         if (p.in_mask) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: ReLU-on-load needs the h8 output");
         if (p.sq_ref) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: sq_ref needs the h8 output");
