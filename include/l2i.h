@@ -151,7 +151,8 @@ int l2i_conv2d_wino_f32(const l2i_conv_params* p, void* stream);
  * U = G g G^T (6x6 per (cin, cout)) in the kernel's LDS image order [Cin/4][CoutP/16][ [6 i][4 cin][16 cout][4 j=0..3] ++ [6][4][16][2 j=4,5] ]
  * (latent2im_amd/conv.py:pack_weight_wino4); CoutP = Cout rounded up to 32.  Same epilogue fusions as l2i_conv2d_wino_f32 (incl. sq_ref).
  * tile_hint 0: the position-split kernel (round 5: a block owns 32 output channels, two waves share the 36 Winograd positions of a tile row;
- * needs pad_x == 1 and W % 4 == 0); tile_hint 1: the round-4 kernel (16 channels per block), same arithmetic, bit-identical results. */
+ * needs pad_x == 1 and W % 4 == 0); tile_hint 1: the round-4 kernel (16 channels per block), same arithmetic, bit-identical results;
+ * tile_hint 2: the position-split kernel on 64 x 16-pixel tiles / eight waves where the map has >= 64 columns and >= 16 rows (an A/B form: slower). */
 int l2i_conv2d_wino4_f32(const l2i_conv_params* p, void* stream);
 
 /* ---- the 16-bit path (BASELINE config 5: "fp16 MFMA"; bf16 here: fp32's exponent range, so gradients of 1e-9 need no loss scaling) ----

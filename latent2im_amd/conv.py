@@ -29,7 +29,7 @@ USE_WINOGRAD = _os.environ.get('L2I_WINOGRAD', '1') != '0'    # 3x3 stride-1 lay
 # [r4] Winograd F(4x4,3x3) (csrc/l2i_wino4.hip: 1.78x fewer MFMAs than F(2x2), error ~1e-6..1e-5 of max|y| instead of 3e-7) for the unmasked 3x3
 # stride-1 launches on maps >= 32 wide ([r5]: 32 x 16-pixel tiles below 64): 'all' = every eligible launch on the [r5] position-split kernel, 'r4' = those >= 64 wide on the round-4
 # kernel (kept for A/B runs: the two are bit-identical), 'off' = F(2x2) everywhere.  The parity suite runs 'all' and 'off'.
-WINO4_MODES = ('all', 'r4', 'off')
+WINO4_MODES = ('all', 'tall', 'r4', 'off')        # 'tall' ([r5], A/B): the position-split kernel on 64 x 16-pixel tiles / eight waves where the map has >= 16 rows
 WINO4 = _os.environ.get('L2I_WINO4', 'all')
 WINO4_R4_MIN_W = 64      # narrowest map the 'r4' mode sends to the round-4 kernel (its tile is 64 wide; the bit-identity test lowers this)
 if WINO4 not in WINO4_MODES:
@@ -430,7 +430,7 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
                 and cin * H * W * 4 < 0x7FFF0000):             # (one sample below 2 GiB: the kernel's out-of-range sentinel)
             pk = L.wino4_pack()
             p.w, p.CoutP = _lib.fptr(pk), pk.shape[1] * 16
-            p.tile_hint = 1 if WINO4 == 'r4' else 0            # (A/B: the round-4 kernel on the same pack)
+            p.tile_hint = 1 if WINO4 == 'r4' else (2 if WINO4 == 'tall' else 0)          # (A/B: the round-4 kernel / the eight-wave tile on the same pack)
             entry, name = lib.l2i_conv2d_wino4_f32, 'l2i_conv2d_wino4_f32'
         else:
             p.w = _lib.fptr(L.wino_pack())

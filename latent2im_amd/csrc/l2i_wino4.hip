@@ -528,16 +528,24 @@ namespace w4s {
 constexpr int BMG = 2, BM = 16 * BMG, CK = 4;
 // Tile of a block: 64 x 8 pixels (a wave's 16 tiles = one tile row) or, NARROW, 32 x 16 pixels for maps 32 .. 63 wide (a wave's 16 tiles = two
 // tile rows of 8).  Both halo windows have 180 16-byte groups: 10 rows x 18 groups, or 18 rows x 10 groups.
-template <bool NARROW> struct Geo {
-    static constexpr int TW = NARROW ? 32 : 64, TH = NARROW ? 16 : 8;
+// [r5, late] VAR 2 = TALL: 64 x 16 pixels = FOUR tile rows, eight waves (512 threads, one block per CU): the 18 KiB U slice of a chunk feeds 288
+// MFMAs instead of 144 (U is 60 % of the kernel's L2 -> LDS traffic, 4 GB per 512 -> 512 @64^2 launch) and every wave issues three U slots per chunk
+// instead of five; the raw window (18 x 18 groups per channel) is fetched three slots per wave as before, two waves per channel plane.
+template <int VAR> struct Geo {
+    static constexpr bool NARROW = VAR == 1, TALL = VAR == 2;
+    static constexpr int NW = TALL ? 8 : 4;             // waves per block
+    static constexpr int TW = NARROW ? 32 : 64, TH = (NARROW || TALL) ? 16 : 8;
     static constexpr int IH = TH + 2;                   // 10 / 18 halo rows
     static constexpr int IWG = NARROW ? 10 : 18, IWP = 4 * IWG;       // 16-byte groups / window columns per row (72 / 40)
-    static_assert(IH * IWG == 180, "180 groups per channel plane");
+    static constexpr int NGRP = IH * IWG;               // groups per channel plane: 180 (10 x 18 or 18 x 10) / 324 (18 x 18)
+    static constexpr int NRSP = (NGRP + 63) / 64;       // 16-byte DMA slots per plane: 3 / 6
+    static constexpr int PLANE = NRSP * 256 + 2;        // floats: >= 64 NRSP 4 (the idle lanes of the last slot write zeros inside their own plane), = 2 (mod 4)
+    static constexpr int RAWST = 4 * PLANE;             // (CK planes)
+    static_assert(NGRP == (TALL ? 324 : 180), "groups per channel plane");
 };
-constexpr int NGRP = 180;                               // groups per channel plane
-constexpr int NRS = 3;                                  // 16-byte DMA slots per plane (wave w fetches channel w of the chunk: 192 lanes >= 180)
-constexpr int PLANE = 770;                              // floats: >= 64 NRS 4 (the idle lanes of the last slot write zeros inside their own plane), = 2 (mod 4)
-constexpr int RAWST = CK * PLANE;
+constexpr int NRS = 3;                                  // raw DMA slots per WAVE and chunk (4 waves: wave w fetches channel w; TALL: waves w, w + 4 share channel w & 3)
+constexpr int PLANE = 770;
+constexpr int RAWST = CK * PLANE;                       // (VAR 0 / 1; the body uses Geo<VAR>::RAWST)
 constexpr int UG = CK * 36 * 16;                        // floats of one 16-channel group image of a chunk (9216 B, as w4::UST)
 constexpr int UST = BMG * UG;                           // a block's slice of a chunk: two consecutive group images = 18432 contiguous bytes of the pack
 constexpr int UA = 6 * 64 * 4;
@@ -548,7 +556,7 @@ constexpr int RAW0 = US * UST + 1;                      // float index of the ra
 constexpr int DUMP = 256;
 constexpr int LDS_FLOATS = US * UST + 4 + RS * RAWST + DUMP;
 constexpr int XCH = 18 * 64 * 4;                        // floats a wave hands over in the epilogue (18 positions x 64 lanes x float4)
-static_assert(PLANE % 4 == 2 && PLANE >= 64 * NRS * 4, "plane pitch");
+static_assert(Geo<0>::PLANE == PLANE && Geo<1>::PLANE == PLANE && Geo<2>::PLANE % 4 == 2, "plane pitch");
 static_assert(4 * XCH <= US * UST + 4 + RS * RAWST, "the exchange area lives in the dead rings");
 static_assert(NUS * 4 >= NUSLOT && (NUS - 1) * 4 < NUSLOT, "U slots");
 }
@@ -559,11 +567,12 @@ struct Wino4sLaunch {
     int nchunks;
 };
 
-template <bool SCALE, bool RELU, int H, bool NARROW>
+template <bool SCALE, bool RELU, int H, int VAR>
 __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino4sLaunch& L, float* smem) {
     using namespace w4s;
-    using GE = Geo<NARROW>;
-    constexpr int TW = GE::TW, TH = GE::TH, IWG = GE::IWG, IWP = GE::IWP;
+    using GE = Geo<VAR>;
+    constexpr bool NARROW = GE::NARROW, TALL = GE::TALL;
+    constexpr int TW = GE::TW, TH = GE::TH, IWG = GE::IWG, IWP = GE::IWP, NGRP = GE::NGRP, PLANE = GE::PLANE, RAWST = GE::RAWST, NW = GE::NW;
     float* ubuf = smem;                                // US x UST
     float* rawbuf = smem + RAW0;                       // RS x [CK][PLANE]
     float* dump = smem + US * UST + 4 + RS * RAWST;
@@ -572,7 +581,9 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, n = lane & 15;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int trow = wave_u >> 1;                      // tile row (NARROW: pair of tile rows) of this wave (H = wave & 1: position rows 3 H .. 3 H + 2)
+    const int trow = wave_u >> 1;                      // tile row (NARROW: pair of tile rows; TALL: 0 .. 3) of this wave (H = wave & 1: position rows 3 H .. 3 H + 2)
+    const int rpl = TALL ? (wave_u & 3) : wave_u;      // raw DMA: channel plane of the chunk this wave fetches ...
+    const int rsl = TALL ? 3 * (wave_u >> 2) : 0;      // ... and its first 16-byte slot of that plane
     const int trow_n = NARROW ? 2 * trow + (n >> 3) : trow;          // this lane's tile: row / column inside the block
     const int tcol_n = NARROW ? (n & 7) : n;
 
@@ -597,7 +608,7 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     unsigned voff[NRS];                                // group 64 u + lane of the [10][18] plane -> byte offset in the channel plane (minus the immediate)
 #pragma unroll
     for (int u = 0; u < NRS; ++u) {
-        const int e = u * 64 + lane;
+        const int e = (rsl + u) * 64 + lane;
         const int iy = e / IWG, ig = e - iy * IWG;
         const int gy = iy0 + iy, gx = ox0 - 4 + 4 * ig;
         const bool ok = (e < NGRP) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
@@ -615,6 +626,14 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
         const unsigned so = (unsigned)(W4_HOTU ? 0 : cu) * uchunk_b + (unsigned)mblk * (unsigned)(UST * 4) + (unsigned)wave_u * 1024u;
         const bool w01 = wave_u < 2;
         if (W4_NOUDMA) on = false;
+        if constexpr (TALL) {                          // 18 slots over 8 waves: slots wave, wave + 8 and (waves 0, 1) wave + 16; the third slot of the others goes to the dump
+            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %6 offen lds\n\t"
+                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %7 offen lds\n\t"
+                         "s_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %8 offen lds"
+                         :: "v"(wvoff), "s"((on && !W4_NODMA) ? rs_w : rs_null), "s"((on && w01 && !W4_NODMA) ? rs_w : rs_null),
+                            "s"(base), "s"(base + 8192u), "s"(w01 ? base + 16384u : lds_dump),
+                            "s"(so), "s"(so + 8192u), "s"(so + 16384u) : "memory");
+        } else {
         asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %8 offen lds\n\t"
                      "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %9 offen lds\n\t"
                      "s_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %10 offen lds\n\t"
@@ -623,10 +642,11 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
                      :: "v"(wvoff), "s"((on && !W4_NODMA) ? rs_w : rs_null), "s"((on && w01 && !W4_NODMA) ? rs_w : rs_null),
                         "s"(base), "s"(base + 4096u), "s"(base + 8192u), "s"(base + 12288u), "s"(w01 ? base + 16384u : lds_dump),
                         "s"(so), "s"(so + 4096u), "s"(so + 8192u), "s"(so + 12288u), "s"(so + 16384u) : "memory");
+        }
     };
     auto issue_raw = [&](int cr, int rst, bool on) {
-        const unsigned base = lds_raw + (unsigned)((rst * RAWST + wave_u * PLANE) * 4);
-        const unsigned so = (unsigned)((W4_HOTR ? 0 : cr) * CK + wave_u) * plane_b;
+        const unsigned base = lds_raw + (unsigned)((rst * RAWST + rpl * PLANE) * 4) + (unsigned)rsl * 1024u;
+        const unsigned so = (unsigned)((W4_HOTR ? 0 : cr) * CK + rpl) * plane_b;
         if (W4_NORDMA) on = false;
         asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
                      "buffer_load_dwordx4 %0, %4, %5 offen lds\n\t"
@@ -648,7 +668,7 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     };
 
     if constexpr (SCALE) {
-        for (int i = tid; i < p.Cin; i += 256) stab[i] = p.in_scale[(size_t)b * p.Cin + i];
+        for (int i = tid; i < p.Cin; i += 64 * NW) stab[i] = p.in_scale[(size_t)b * p.Cin + i];
     }
 
     const f32x2 km4 = {-4.f, -4.f}, k4 = {4.f, 4.f}, km5 = {-5.f, -5.f}, k2 = {2.f, 2.f}, km2 = {-2.f, -2.f};
@@ -915,23 +935,30 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
         __syncthreads();                                           // every wave has read its partner's exchange area: the partial sums may overwrite it
         if (lane == 0) smem[wave_u] = sq;
         __syncthreads();
-        if (tid == 0) atomicAdd(p.sq_out + (blockIdx.x & (L2I_SQ_SLOTS - 1)), (smem[0] + smem[1]) + (smem[2] + smem[3]));
+        if (tid == 0) {
+            float t = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+            if constexpr (TALL) t += (smem[4] + smem[5]) + (smem[6] + smem[7]);
+            atomicAdd(p.sq_out + (blockIdx.x & (L2I_SQ_SLOTS - 1)), t);
+        }
     }
 }
 
-template <bool SCALE, bool RELU, bool NARROW = false>
-__global__ __launch_bounds__(256, 2) void conv_wino4s_kernel(const l2i_conv_params p, const Wino4sLaunch L) {
+template <bool SCALE, bool RELU, int VAR = 0>
+__global__ __launch_bounds__(VAR == 2 ? 512 : 256, VAR == 2 ? 1 : 2) void conv_wino4s_kernel(const l2i_conv_params p, const Wino4sLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // (a wave-uniform branch: the two halves run the same number of barriers)
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino4s_body<SCALE, RELU, 1, NARROW>(p, L, smem);
-    else wino4s_body<SCALE, RELU, 0, NARROW>(p, L, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) wino4s_body<SCALE, RELU, 1, VAR>(p, L, smem);
+    else wino4s_body<SCALE, RELU, 0, VAR>(p, L, smem);
 }
 
 static int launch_wino4s(const l2i_conv_params& p, hipStream_t st) {
     Wino4sLaunch L;
     const bool narrow = p.OW < 64;                     // maps 32 .. 63 wide: the 32 x 16-pixel tile
+    // TALL (64 x 16 pixels, eight waves): L2I_W4_TALL=1 takes it on every launch with >= 16 rows, 0 = never (the A/B: DESIGN.md section 4.0)
+    static const int tall_env = getenv("L2I_W4_TALL") ? atoi(getenv("L2I_W4_TALL")) : 0;
+    const bool tall = !narrow && p.OH >= 16 && (tall_env != 0 || p.tile_hint == 2);
     L.tiles_x = narrow ? (p.OW + 31) / 32 : (p.OW + 63) / 64;
-    L.tiles_y = narrow ? (p.OH + 15) / 16 : (p.OH + 7) / 8;
+    L.tiles_y = (narrow || tall) ? (p.OH + 15) / 16 : (p.OH + 7) / 8;
     L.mblocks = p.CoutP / w4s::BM;
     const long total = (long)p.B * L.tiles_y * L.tiles_x * L.mblocks;
     if (total <= 0 || total > 0x7ffffff0L) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: too many tiles");
@@ -940,15 +967,21 @@ static int launch_wino4s(const l2i_conv_params& p, hipStream_t st) {
     const unsigned grid = (unsigned)((total + 7) & ~7L);
     const bool relu_in = p.in_mask != nullptr;
     const bool scale = p.in_scale != nullptr;
-    const size_t lds = (size_t)(w4s::LDS_FLOATS + (scale ? ((p.Cin + 3) & ~3) : 0)) * sizeof(float);
-    if (lds > 80 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: too many input channels for the style-scale table");
-#define L2I_WINO4S_(S_, R_, N_)                                                                                                         \
+    const int stab_f = scale ? ((p.Cin + 3) & ~3) : 0;
+    size_t lds = (size_t)(w4s::LDS_FLOATS + stab_f) * sizeof(float);
+    if (tall) {                                        // rings: U as before, three raw stages of 4 x 1538 floats; the epilogue's exchange area: eight waves x 18 KiB
+        const size_t ring = (size_t)(w4s::US * w4s::UST + 4 + w4s::RS * w4s::Geo<2>::RAWST + w4s::DUMP + stab_f) * sizeof(float);
+        const size_t xch = (size_t)8 * w4s::XCH * sizeof(float);
+        lds = ring > xch ? ring : xch;
+    }
+    if (lds > (tall ? 160u : 80u) * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: too many input channels for the style-scale table");
+#define L2I_WINO4S_(S_, R_, V_)                                                                                                         \
     do {                                                                                                                                \
-        L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4s_kernel<S_, R_, N_>),                    \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                         \
-        hipLaunchKernelGGL((conv_wino4s_kernel<S_, R_, N_>), dim3(grid), dim3(256), lds, st, p, L);                                      \
+        L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4s_kernel<S_, R_, V_>),                    \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (V_ == 2 ? 160 : 80) * 1024));       \
+        hipLaunchKernelGGL((conv_wino4s_kernel<S_, R_, V_>), dim3(grid), dim3(V_ == 2 ? 512 : 256), lds, st, p, L);                      \
     } while (0)
-#define L2I_WINO4S(S_, R_) do { if (narrow) L2I_WINO4S_(S_, R_, true); else L2I_WINO4S_(S_, R_, false); } while (0)
+#define L2I_WINO4S(S_, R_) do { if (narrow) L2I_WINO4S_(S_, R_, 1); else if (tall) L2I_WINO4S_(S_, R_, 2); else L2I_WINO4S_(S_, R_, 0); } while (0)
     if (relu_in) { if (scale) L2I_WINO4S(true, true); else L2I_WINO4S(false, true); }
     else { if (scale) L2I_WINO4S(true, false); else L2I_WINO4S(false, false); }
 #undef L2I_WINO4S
@@ -1008,7 +1041,7 @@ extern "C" int l2i_conv2d_wino4_f32(const l2i_conv_params* pp, void* stream) {
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: output rows must be 16-byte aligned multiples of 4 pixels");
     if ((size_t)p.Cin * p.H * p.W * sizeof(float) >= 0x7FFF0000ull || (size_t)p.Cin * 36 * p.CoutP * sizeof(float) >= 0xFFFFFFF0ull)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: one sample must stay below 2 GiB, the weight pack below 4 GiB (32-bit buffer offsets)");
-    if (p.tile_hint != 0 && p.tile_hint != 1) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: tile_hint must be 0 (position-split kernel) or 1 (the round-4 kernel)");
+    if (p.tile_hint < 0 || p.tile_hint > 2) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: tile_hint must be 0 (position-split kernel), 1 (the round-4 kernel) or 2 (position-split, 64 x 16 tile on eight waves)");
     if ((p.sq_ref != nullptr) != (p.sq_out != nullptr) || (((uintptr_t)p.sq_ref) % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: sq_ref (16-byte aligned) and sq_out go together");
     if (p.tile_hint == 1) return launch_wino4(p, (hipStream_t)stream);
     if (p.pad_x != 1 || (p.W % 4) != 0)

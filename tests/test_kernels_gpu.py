@@ -379,7 +379,7 @@ def test_wino4_position_split_kernel_bit_identical_to_round4_kernel(cin, cout, h
     try:
         for kw in calls:
             out, sums = {}, {}
-            for mode in ('r4', 'all'):
+            for mode in ('r4', 'all', 'tall'):             # ('tall' [r5]: the same kernel body on a 64 x 16-pixel tile / eight waves where the map has >= 16 rows and >= 64 columns)
                 conv.WINO4 = mode
                 conv.WINO4_R4_MIN_W = 32                   # (the round-4 kernel is the reference on the narrow maps too: 64-wide tiles, half empty)
                 launched = conv.PROFILE = []
@@ -392,6 +392,8 @@ def test_wino4_position_split_kernel_bit_identical_to_round4_kernel(cin, cout, h
                 assert [q[4] for q in launched] == ['l2i_conv2d_wino4_f32'] and fused[0]
                 out[mode], sums[mode] = y, sq_acc.double().sum()
             assert torch.equal(out['r4'], out['all']), float((out['r4'] - out['all']).abs().max())
+            assert torch.equal(out['r4'], out['tall']), float((out['r4'] - out['tall']).abs().max())
+            assert abs(float(sums['tall']) - float(sums['all'])) <= 1e-5 * abs(float(sums['all']))
             want_sq = float(((out['all'].double() - g(rmk).double()) ** 2).sum())
             assert abs(float(sums['all']) - want_sq) <= 1e-5 * want_sq and abs(float(sums['r4']) - want_sq) <= 1e-5 * want_sq
     finally:
