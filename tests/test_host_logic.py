@@ -180,3 +180,43 @@ def test_ops_fail_loudly_without_gpu_or_library(monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libl2i_hip.so')
     with pytest.raises(_lib.L2IError):
         _lib.load()
+
+
+def test_image_conv_weight_pack_follows_the_kernels_contraction_index():
+    """[r5] conv.pack_weight_img_h8 (include/l2i.h: l2i_conv_img_h8): element (s, half, co, e) of the 16-bit planes is w[co, c, ky, kx = e] with
+    (c, ky) = divmod(2 s + half, K), zero for e >= K and for rows past Cin K — for the three image-side convs of the 16-bit path (1x1, 3x3, 7x7)."""
+    import torch
+    from latent2im_amd import conv
+    for cout, cin, k in ((32, 3, 1), (64, 3, 3), (64, 3, 7), (40, 1, 3), (96, 4, 3)):
+        w = torch.randn(cout, cin, k, k)
+        for dt in (torch.float16, torch.bfloat16):
+            planes = conv.pack_weight_img_h8(w, dtype=dt)
+            ns, coutp = (cin * k + 1) // 2, (cout + 31) // 32 * 32
+            assert tuple(planes.shape) == (ns, 1, 2, coutp, 8) and planes.dtype == torch.int16
+            got = planes.view(dt).float()
+            want = torch.zeros(ns, 1, 2, coutp, 8)
+            for p in range(cin * k):
+                c, ky = divmod(p, k)
+                want[p // 2, 0, p % 2, :cout, :k] = w[:, c, ky, :].to(dt).float()
+            assert torch.equal(got, want)
+
+
+def test_modulate_plan_table_rows():
+    """[r5] kernels16.ModulatePlan: the device-side table of l2i_modulate_planes_multi_h8 (eight int64 per layer: weight / scale / output offsets, slots
+    per sample, taps, CoutP, Cs, first block) is consistent with the per-layer views it hands out."""
+    import torch
+    from latent2im_amd import conv, kernels16 as K16
+    shapes = [(64, 32, 3), (32, 96, 3), (128, 64, 1)]                              # cin, cout, k
+    w32s = [conv.pack_weight_h8_f32(torch.randn(co, ci, k, k)) for ci, co, k in shapes]
+    offs = [0, 64, 96]
+    plan = K16.ModulatePlan(w32s, offs, 'cpu')
+    B = 3
+    table, slots, nblocks = plan._table(B)
+    rows = table.tolist()
+    assert len(rows) == 3 and rows[0][7] == 0 and all(rows[i][7] < rows[i + 1][7] for i in range(2)) and nblocks > rows[2][7]
+    out_off = 0
+    for (ci, co, k), w32, off, r in zip(shapes, w32s, offs, rows):
+        sps = w32.numel() // 8
+        assert r[:7] == [plan.w_off[rows.index(r)], off * B, out_off, sps, k * k, (co + 31) // 32 * 32, (ci + 31) // 32 * 32]
+        out_off += sps * B
+    assert slots == out_off
