@@ -99,6 +99,10 @@ typedef struct l2i_conv_params {
     const float* rgb_w;     /* l2i_conv2d_h8 with the h8 output and every output channel in one block (Cout <= 64): not NULL = the launch also writes the   */
     const float* rgb_bias;  /* ToRGB image of its output, rgb_out[b, o, oy, ox] = rgb_bias[o] + sum_c rgb_w[b, o, c] * epi(.)[b, c, oy, ox] (o < 3; fp32     */
     float* rgb_out;         /* NCHW [B, 3, OHf, OWf]; networks.py:349-358 on the 512^2 / 1024^2 StyledConv outputs), instead of a pass that re-reads y        */
+    float* pool_out;        /* l2i_conv2d_wino4_f32 (position-split kernel, dense output with even OHf, OWf % 4 == 0, zero output offsets): not NULL = the launch    */
+    uint8_t* pool_idx;      /* also writes MaxPool2d(2, 2) of its output y, pool_out [B, Cout, OHf/2, OWf/2] fp32 and the window-local arg-max pool_idx (same     */
+                            /* shape, bytes; taps in (ky, kx) order, first maximum, NaN propagates: l2i_maxpool2d_fwd_f32's rule) — VGG-19's pool after conv1_2   */
+                            /* (transform_base.py:426-454) from the 4x4 output tile a lane holds anyway, instead of a pass that reads the 2 GB map again          */
 } l2i_conv_params;
 #define L2I_SQ_SLOTS 1024
 

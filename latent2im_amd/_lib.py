@@ -36,7 +36,7 @@ class ConvParams(ctypes.Structure):
         ('ws', c_p), ('ksplit', c_i), ('res_sub', c_p), ('res_coef', c_f), ('res_coef_dev', c_p),
         ('sq_ref', c_p), ('sq_out', c_p),
         ('w_bstride', c_l), ('out_f32', c_i),
-        ('in_h8', c_i), ('rgb_w', c_p), ('rgb_bias', c_p), ('rgb_out', c_p),
+        ('in_h8', c_i), ('rgb_w', c_p), ('rgb_bias', c_p), ('rgb_out', c_p), ('pool_out', c_p), ('pool_idx', c_p),
     ]
 
 

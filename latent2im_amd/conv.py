@@ -374,8 +374,10 @@ def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), 
 
 def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0), out_scale=None, noise=None,
                noise_w=0.0, bias=None, residual=None, res_mask=None, out_mask=None, act=ACT_NONE, slope=0.2, gain=1.0,
-               out_gain=1.0, accumulate=False, tile_hint=0, res_sub=None, res_coef=1.0, res_coef_dev=None, sq=None):
-    """Enqueue one kernel call on the current stream.  ``y`` is the full output tensor [B, Cout, OHf, OWf]."""
+               out_gain=1.0, accumulate=False, tile_hint=0, res_sub=None, res_coef=1.0, res_coef_dev=None, sq=None, pool=None):
+    """Enqueue one kernel call on the current stream.  ``y`` is the full output tensor [B, Cout, OHf, OWf].  ``pool`` ([r5]) = (pooled [B, Cout, OHf/2, OWf/2]
+    fp32, arg-max bytes of the same shape, [fused flag]): where the launch takes the position-split F(4x4) kernel it also writes MaxPool2d(2, 2) of y
+    (l2i.h: pool_out / pool_idx) and sets the flag; otherwise the caller runs the pool kernel."""
     lib = _lib.load()
     B, cin, H, W = x.shape
     assert cin == L.cin, (cin, L.cin)
@@ -431,6 +433,11 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
             pk = L.wino4_pack()
             p.w, p.CoutP = _lib.fptr(pk), pk.shape[1] * 16
             p.tile_hint = 1 if WINO4 == 'r4' else (2 if WINO4 == 'tall' else 0)          # (A/B: the round-4 kernel / the eight-wave tile on the same pack)
+            if (pool is not None and WINO4 != 'r4' and L.step == 1 and OHf % 2 == 0 and OWf % 4 == 0 and OH == OHf and OW == OWf and not accumulate
+                    and pool[0].data_ptr() % 8 == 0):
+                assert tuple(pool[0].shape) == (B, L.cout, OHf // 2, OWf // 2) and pool[1].shape == pool[0].shape and pool[1].dtype == torch.uint8
+                p.pool_out, p.pool_idx = _lib.fptr(pool[0]), _lib.ptr(pool[1])
+                pool[2][0] = True
             entry, name = lib.l2i_conv2d_wino4_f32, 'l2i_conv2d_wino4_f32'
         else:
             p.w = _lib.fptr(L.wino_pack())

@@ -870,6 +870,8 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
             scv[q] = (p.out_scale && co < p.Cout) ? p.out_scale[(size_t)b * p.Cout + co] : 1.f;
             bv[q] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
         }
+        float4 prow[2];                                // pool_out: the even row of the current window pair, per channel of the register pair
+        bool pvalid[2] = {false, false};
 #pragma unroll
         for (int ry = 0; ry < 4; ++ry) {
             const f32x2* m = yv[ry];
@@ -887,7 +889,7 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int co = co0 + q;
-                if (!(pok && co < p.Cout)) continue;
+                if (!(pok && co < p.Cout)) { pvalid[q] = false; continue; }
                 float4 v = q ? make_float4(y0.y, y1.y, y2.y, y3.y) : make_float4(y0.x, y1.x, y2.x, y3.x);
                 if constexpr (RELU) { v.x *= W4_RELU_UNSCALE; v.y *= W4_RELU_UNSCALE; v.z *= W4_RELU_UNSCALE; v.w *= W4_RELU_UNSCALE; }
                 const size_t oidx = ((size_t)b * p.Cout + co) * plane_o + poff;
@@ -921,6 +923,23 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
                 if (!W4_NOEPI || v.x == 123.456f) *reinterpret_cast<float4*>(p.y + oidx) = v;
+                if (p.pool_out) {                                  // [r5] MaxPool2d(2, 2) of y from the tile in registers (l2i.h: pool_out / pool_idx)
+                    if ((ry & 1) == 0) { prow[q] = v; pvalid[q] = true; }
+                    else if (pvalid[q]) {
+                        const float4 u = prow[q];
+                        float b0 = u.x, b1 = u.z;
+                        unsigned i0 = 0u, i1 = 0u;
+                        if (u.y > b0 || u.y != u.y) { b0 = u.y; i0 = 1u; }
+                        if (v.x > b0 || v.x != v.x) { b0 = v.x; i0 = 2u; }
+                        if (v.y > b0 || v.y != v.y) { b0 = v.y; i0 = 3u; }
+                        if (u.w > b1 || u.w != u.w) { b1 = u.w; i1 = 1u; }
+                        if (v.z > b1 || v.z != v.z) { b1 = v.z; i1 = 2u; }
+                        if (v.w > b1 || v.w != v.w) { b1 = v.w; i1 = 3u; }
+                        const size_t pidx = (((size_t)b * p.Cout + co) * (size_t)(p.OHf >> 1) + (size_t)(oy >> 1)) * (size_t)(p.OWf >> 1) + (size_t)(ox >> 1);
+                        *reinterpret_cast<float2*>(p.pool_out + pidx) = make_float2(b0, b1);
+                        *reinterpret_cast<unsigned short*>(p.pool_idx + pidx) = (unsigned short)(i0 | (i1 << 8));
+                    }
+                }
                 if (p.sq_ref) {                                    // ContentLoss value of a VGG tap: sum (y - reference)^2 while y is in registers
                     const float4 rf = *reinterpret_cast<const float4*>(p.sq_ref + oidx);
                     const float d0 = v.x - rf.x, d1 = v.y - rf.y, d2 = v.z - rf.z, d3 = v.w - rf.w;
@@ -1043,6 +1062,10 @@ extern "C" int l2i_conv2d_wino4_f32(const l2i_conv_params* pp, void* stream) {
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: one sample must stay below 2 GiB, the weight pack below 4 GiB (32-bit buffer offsets)");
     if (p.tile_hint < 0 || p.tile_hint > 2) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: tile_hint must be 0 (position-split kernel), 1 (the round-4 kernel) or 2 (position-split, 64 x 16 tile on eight waves)");
     if ((p.sq_ref != nullptr) != (p.sq_out != nullptr) || (((uintptr_t)p.sq_ref) % 16) != 0) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: sq_ref (16-byte aligned) and sq_out go together");
+    if ((p.pool_out != nullptr) != (p.pool_idx != nullptr)) return l2i_set_error(L2I_E_ARG, "conv2d_wino4: pool_out and pool_idx go together");
+    if (p.pool_out && (p.tile_hint == 1 || (p.OHf % 2) != 0 || (p.OWf % 4) != 0 || p.oy_off != 0 || p.ox_off != 0 || p.OH != p.OHf || p.OW != p.OWf || (((uintptr_t)p.pool_out) % 8) != 0 ||
+                       (((uintptr_t)p.pool_idx) % 2) != 0))
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: pool_out needs the position-split kernel, a dense output with even height and OWf % 4 == 0, an 8-byte aligned pool_out");
     if (p.tile_hint == 1) return launch_wino4(p, (hipStream_t)stream);
     if (p.pad_x != 1 || (p.W % 4) != 0)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_wino4: the position-split kernel needs pad_x == 1 and W % 4 == 0 (16-byte groups of the halo window aligned with the image)");

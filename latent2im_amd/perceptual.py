@@ -8,6 +8,8 @@ the prologue of the next conv, and as an output mask in the epilogue of the grad
 Normalisation (x - mean)/std: the per-channel 1/std is folded into the first conv's weights, x - mean is one
 ``fused_bias_act`` call (zero padding of the normalised image is preserved exactly).
 """
+import os as _os
+
 import numpy as np
 import torch
 
@@ -16,6 +18,8 @@ from . import kernels as K
 
 VGG_MEAN = (0.485, 0.456, 0.406)
 VGG_STD = (0.229, 0.224, 0.225)
+
+POOL_FUSED = _os.environ.get('L2I_POOL_FUSED', '1') != '0'     # [r5] VGG pool1 inside conv1_2's F(4x4) epilogue (0: its own launch; A/B)
 
 
 class VGG19Prefix:
@@ -41,8 +45,17 @@ class VGG19Prefix:
             acc = torch.zeros(4, C._lib.SQ_SLOTS, device=img.device, dtype=torch.float32)
             sq = [(org[k], acc[k], [False]) for k in range(4)]
         c1 = self.convs[0].forward(xc, bias=self.biases[0], sq=sq[0])
-        c2 = self.convs[1].forward(c1, in_mask=c1, mask=(1.0, 0.0), bias=self.biases[1], sq=sq[1])
-        p, idx = K.maxpool2d_fwd(c2, 2, 2, 0)                     # relu(maxpool(.)) == maxpool(relu(.))
+        # [r5] the 2x2 pool rides on conv1_2's F(4x4) epilogue (a lane holds a 4x4 output tile: lane-local) where that kernel runs: no pass over the 2 GB map
+        pool = None
+        if POOL_FUSED and c1.shape[2] % 2 == 0 and c1.shape[3] % 4 == 0:
+            oc = self.convs[1].cout
+            pool = (torch.empty(c1.shape[0], oc, c1.shape[2] // 2, c1.shape[3] // 2, device=c1.device, dtype=torch.float32),
+                    torch.empty(c1.shape[0], oc, c1.shape[2] // 2, c1.shape[3] // 2, device=c1.device, dtype=torch.uint8), [False])
+        c2 = self.convs[1].forward(c1, in_mask=c1, mask=(1.0, 0.0), bias=self.biases[1], sq=sq[1], pool=pool)
+        if pool is not None and pool[2][0]:
+            p, idx = pool[0], pool[1]
+        else:
+            p, idx = K.maxpool2d_fwd(c2, 2, 2, 0)                 # relu(maxpool(.)) == maxpool(relu(.))
         c3 = self.convs[2].forward(p, in_mask=p, mask=(1.0, 0.0), bias=self.biases[2], sq=sq[2])
         c4 = self.convs[3].forward(c3, in_mask=c3, mask=(1.0, 0.0), bias=self.biases[3], sq=sq[3])
         if org is None:

@@ -892,3 +892,38 @@ def test_segmented_matvec_kernel_vs_table_emulation(size, batch):
     close(d_all, d_c, 1e-5, 1e-6)
     close(w_all, w_c, 1e-5, 1e-5)
     assert float((g.cpu() - g_c).abs().max()) < 1e-5 * float(g_c.abs().max())
+
+
+@pytest.mark.parametrize('cin,cout,h,w,b,mode', [(64, 64, 64, 64, 2, 'all'), (16, 40, 18, 72, 1, 'all'), (32, 64, 32, 40, 2, 'all'), (64, 64, 48, 128, 1, 'tall')])
+def test_wino4_fused_maxpool_output(cin, cout, h, w, b, mode):
+    """[r5] l2i_conv_params::pool_out / pool_idx: the position-split F(4x4) kernel also writes MaxPool2d(2, 2) of its output (VGG-19 pool1 after
+    conv1_2, transform_base.py:426-454) from the 4x4 tile a lane holds: values and arg-max bytes BIT-IDENTICAL to l2i_maxpool2d_fwd_f32 on the
+    stored map (ReLU-on-load launch with bias and the ContentLoss sum, as the product issues it; ties through a ReLU'd input included)."""
+    from latent2im_amd import kernels
+    rs = np.random.RandomState(cin + cout + h)
+    wt = T(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    x = T(np.round(rs.randn(b, cin, h, w) * 2) / 2).to(DEV)                 # coarse values: exact ties in the windows
+    bias = T(rs.randn(cout)).to(DEV)
+    fc = conv.FrozenConv2d(wt, 1, 1, device=DEV)
+    prev = conv.WINO4
+    conv.WINO4 = mode
+    try:
+        y0 = fc.forward(x, in_mask=x, mask=(1.0, 0.0), bias=bias)
+        pool = (torch.full((b, cout, h // 2, w // 2), float('nan'), device=DEV), torch.full((b, cout, h // 2, w // 2), 255, device=DEV, dtype=torch.uint8), [False])
+        ref = T(rs.randn(b, cout, h, w)).to(DEV)
+        sq = (ref, torch.zeros(_lib.SQ_SLOTS, device=DEV), [False])
+        y1 = fc.forward(x, in_mask=x, mask=(1.0, 0.0), bias=bias, sq=sq, pool=pool)
+    finally:
+        conv.WINO4 = prev
+    torch.cuda.synchronize()
+    assert pool[2][0] and sq[2][0] and torch.equal(y0, y1)
+    want_p, want_i = kernels.maxpool2d_fwd(y1, 2, 2, 0)
+    assert torch.equal(pool[0], want_p) and torch.equal(pool[1], want_i)
+    # a constant map: every window is a four-way tie -> arg-max 0 everywhere
+    z = torch.zeros(b, cin, h, w, device=DEV)
+    conv.WINO4 = mode
+    try:
+        fc.forward(z, pool=pool)
+    finally:
+        conv.WINO4 = prev
+    assert int(pool[1].max()) == 0 and float(pool[0].abs().max()) == 0.0
