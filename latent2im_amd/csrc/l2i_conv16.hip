@@ -478,6 +478,7 @@ extern "C" int l2i_conv_transpose2d_bf16x3_f32(const l2i_conv_params* pp, void* 
     if (!pp) return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: null params");
     const l2i_conv_params& p = *pp;
     if (!p.x || !p.w_hi || !p.w_lo || !p.y) return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: null tensor");
+    if (const char* m = l2i_unsupported_v5_fields(p, false, false, false)) return l2i_set_error(L2I_E_UNSUPPORTED, m);
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OHf <= 0 || p.OWf <= 0)
         return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: non-positive dimension");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d_bf16x3: CoutP must be Cout rounded up to 32");
@@ -516,6 +517,7 @@ extern "C" int l2i_conv2d_bf16x3_f32(const l2i_conv_params* pp, void* stream) {
     if (!pp) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: null params");
     const l2i_conv_params& p = *pp;
     if (!p.x || !p.w_hi || !p.w_lo || !p.y) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: null tensor");
+    if (const char* m = l2i_unsupported_v5_fields(p, false, false, false)) return l2i_set_error(L2I_E_UNSUPPORTED, m);
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0)
         return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: non-positive dimension");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv2d_bf16x3: CoutP must be Cout rounded up to 32");

@@ -636,6 +636,7 @@ static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
 
 static int h8_common_checks(const l2i_conv_params& p, const char* who) {
     if (!p.x || !p.w_hi || !p.y) return l2i_set_error(L2I_E_ARG, "conv h8: null tensor");
+    if (const char* m = l2i_unsupported_v5_fields(p, true, false, false)) return l2i_set_error(L2I_E_UNSUPPORTED, m);
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0) return l2i_set_error(L2I_E_ARG, "conv h8: non-positive dimension");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0) return l2i_set_error(L2I_E_ARG, "conv h8: CoutP must be Cout rounded up to 32");
     const bool relu_in = p.in_mask && (const void*)p.in_mask == (const void*)p.x && p.mask_pos == 1.f && p.mask_neg == 0.f && !p.out_mask;

@@ -552,6 +552,7 @@ extern "C" int l2i_conv_transpose2d_f32(const l2i_conv_params* pp, void* stream)
     if (!pp) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: null params");
     const l2i_conv_params& p = *pp;
     if (!p.x || !p.w || !p.y) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: null tensor");
+    if (const char* m = l2i_unsupported_v5_fields(p, false, false, true)) return l2i_set_error(L2I_E_UNSUPPORTED, m);
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: non-positive dimension");
     if (p.KH != p.KW || p.pad_y != p.pad_x) return l2i_set_error(L2I_E_ARG, "conv_transpose2d: square kernels / symmetric padding only");
     if (p.sq_ref || p.sq_out) return l2i_set_error(L2I_E_UNSUPPORTED, "conv_transpose2d: sq_ref / sq_out are fused in l2i_conv2d_wino_f32 only");

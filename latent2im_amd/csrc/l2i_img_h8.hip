@@ -226,6 +226,7 @@ static int conv_img_h8(const l2i_conv_params* pp, void* stream) {
     if (!pp) return l2i_set_error(L2I_E_ARG, "conv_img_h8: null params");
     const l2i_conv_params& p = *pp;
     if (!p.x || !p.w_hi || !p.y) return l2i_set_error(L2I_E_ARG, "conv_img_h8: null tensor");
+    if (const char* m = l2i_unsupported_v5_fields(p, false, false, false)) return l2i_set_error(L2I_E_UNSUPPORTED, m);
     if (p.B <= 0 || p.Cin <= 0 || p.Cin > 4 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0) return l2i_set_error(L2I_E_ARG, "conv_img_h8: bad dimension (1 .. 4 input channels)");
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0 || (p.Cout % 8) != 0) return l2i_set_error(L2I_E_ARG, "conv_img_h8: CoutP = Cout rounded up to 32, Cout % 8 == 0");
     if (p.KH != p.KW || p.pad_y != p.pad_x || p.oy_step != 1 || p.ox_step != 1 || p.oy_off < 0 || p.ox_off < 0 || p.OH + p.oy_off > p.OHf || p.OW + p.ox_off > p.OWf)

@@ -18,6 +18,15 @@ bool l2i_conv3x3s2_eligible(const l2i_conv_params& p);            // l2i_conv_s2
 int l2i_launch_conv3x3s2(const l2i_conv_params& p, hipStream_t st);
 int l2i_launch_splitk_epilogue(const l2i_conv_params& q, hipStream_t st);     // l2i_conv.hip: y = epilogue(sum of q.ksplit partials in q.ws)
 
+// [r5] The ABI-5 fields of l2i_conv_params belong to single entry points (rgb_*: l2i_conv2d_h8; pool_*: l2i_conv2d_wino4_f32; in_h8: the 7x7 kernel inside
+// l2i_conv_transpose2d_f32).  Every other conv entry refuses a struct that carries them instead of silently not doing what was asked.
+static inline const char* l2i_unsupported_v5_fields(const l2i_conv_params& p, bool allow_rgb, bool allow_pool, bool allow_in_h8) {
+    if (!allow_rgb && (p.rgb_w || p.rgb_bias || p.rgb_out)) return "rgb_w / rgb_bias / rgb_out are fused in l2i_conv2d_h8 only";
+    if (!allow_pool && (p.pool_out || p.pool_idx)) return "pool_out / pool_idx are fused in l2i_conv2d_wino4_f32 only";
+    if (!allow_in_h8 && p.in_h8) return "in_h8 is read by the 7x7 kernel of l2i_conv_transpose2d_f32 only";
+    return nullptr;
+}
+
 #define L2I_CHECK_LAUNCH()                                                      \
     do {                                                                        \
         hipError_t e_ = hipGetLastError();                                      \

@@ -458,6 +458,7 @@ extern "C" int l2i_conv2d_wino_f32(const l2i_conv_params* pp, void* stream) {
     if (!pp) return l2i_set_error(L2I_E_ARG, "conv2d_wino: null params");
     const l2i_conv_params& p = *pp;
     if (!p.x || !p.w || !p.y) return l2i_set_error(L2I_E_ARG, "conv2d_wino: null tensor");
+    if (const char* m = l2i_unsupported_v5_fields(p, false, false, false)) return l2i_set_error(L2I_E_UNSUPPORTED, m);
     if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.H <= 0 || p.W <= 0 || p.OH <= 0 || p.OW <= 0)
         return l2i_set_error(L2I_E_ARG, "conv2d_wino: non-positive dimension");
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.oy_step != 1 || p.ox_step != 1 || (p.Cin % 8) != 0)

@@ -927,3 +927,34 @@ def test_wino4_fused_maxpool_output(cin, cout, h, w, b, mode):
     finally:
         conv.WINO4 = prev
     assert int(pool[1].max()) == 0 and float(pool[0].abs().max()) == 0.0
+
+
+def test_abi5_fields_are_refused_by_the_entries_that_do_not_implement_them():
+    """[r5] rgb_* belong to l2i_conv2d_h8, pool_* to l2i_conv2d_wino4_f32, in_h8 to the 7x7 kernel of l2i_conv_transpose2d_f32: every other conv entry
+    returns L2I_E_UNSUPPORTED for a struct that carries them instead of silently ignoring the request."""
+    lib = _lib.load()
+    x = torch.randn(1, 8, 16, 64, device=DEV)
+    fc = conv.FrozenConv2d(torch.randn(8, 8, 3, 3), 1, 1, device=DEV)
+    L = fc.fwd[0]
+    y = torch.empty(1, 8, 16, 64, device=DEV)
+    buf = torch.zeros(1, 8, 8, 32, device=DEV)
+    idx = torch.zeros(1, 8, 8, 32, device=DEV, dtype=torch.uint8)
+
+    def params():
+        p = _lib.ConvParams()
+        p.x, p.w, p.y = _lib.fptr(x), _lib.fptr(L.w), _lib.fptr(y)
+        p.B, p.Cin, p.H, p.W, p.Cout, p.CoutP = 1, 8, 16, 64, 8, L.w.shape[2]
+        p.KH = p.KW = 3
+        p.stride, p.pad_y, p.pad_x = 1, 1, 1
+        p.OH, p.OW, p.OHf, p.OWf = 16, 64, 16, 64
+        p.oy_step = p.ox_step = 1
+        p.act_gain = p.out_gain = 1.0
+        return p
+    p = params()
+    assert lib.l2i_conv2d_f32(p, _lib.stream_ptr()) == 0
+    for field, val in (('rgb_w', _lib.fptr(buf)), ('pool_out', _lib.fptr(buf)), ('pool_idx', _lib.ptr(idx)), ('in_h8', 1)):
+        p = params()
+        setattr(p, field, val)
+        assert lib.l2i_conv2d_f32(p, _lib.stream_ptr()) < 0, field
+        assert lib.l2i_conv2d_wino_f32(p, _lib.stream_ptr()) < 0, field
+    torch.cuda.synchronize()
