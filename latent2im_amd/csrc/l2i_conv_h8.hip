@@ -231,8 +231,11 @@ __device__ __forceinline__ void h8_gather(const f32x16& a, int pr, int half, flo
 // nothing.  What moves it is less energy per output: fewer bytes (this path), fewer VALU instructions (the lean epilogue), fewer MFMA passes.
 // [r5] Measured again with a 128-channel block (WM = 4, two blocks per CU: half the B-fragment reads and half the L2 -> LDS input traffic per MFMA): 256 -> 256
 // @128^2 0.1301 against 0.1306 ms, 512 -> 512 @64^2 0.1286 / 0.1291, 128 -> 128 @512^2 0.636 / 0.617, 512 -> 512 @32^2 0.0735 / 0.0461 (too few blocks): not kept.
-template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false, int KS = 2>
-__global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
+// EXTRA [r5]: the lean epilogue's optional outputs (ToRGB image, ContentLoss sum) live in their own instantiations of the 3x3 stride-1
+// kernel (a fused 2x2 max-pool of the output was built here too, bit-identical to the pool kernel, and measured: c5 223.4 - 223.9 images/s with, 225.2 - 225.8
+// without — the pooled values' registers slow the two big VGG launches by more than the pool pass costs: removed): their registers (24 weights + 6 sums) otherwise cost the plain launches — 58 of the c5 step's — spills at four blocks per CU
+template <int WM, int WN, int K, int S, int TR, bool OUT32, bool RELU_IN = false, int KS = 2, bool EXTRA = false>
+__global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? (EXTRA ? 3 : 4) : 2) void conv_h8_kernel(const l2i_conv_params p, const H8Launch L) {
     using G = g8::Geo<WN, K, S, TR, KS>;
     constexpr int NACC = TR ? 4 : 1;
     constexpr int DMIN = (TR == 1) ? -1 : 0;
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
         for (int n = 0; n < WN; ++n)
 #pragma unroll
             for (int a = 0; a < NACC; ++a) racc[n][a][0] = racc[n][a][1] = racc[n][a][2] = 0.f;
+        float sq_lean = 0.f;
         const float gpos = (p.act == L2I_ACT_LRELU ? p.act_gain : 1.f) * p.out_gain;
         const float gneg = p.act == L2I_ACT_LRELU ? p.act_slope * p.act_gain * p.out_gain : (p.act == L2I_ACT_RELU ? 0.f : p.out_gain);
         const bool plain_relu = p.act == L2I_ACT_RELU && p.out_gain == 1.f, identity = p.act == L2I_ACT_NONE && p.out_gain == 1.f;
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
             }
             u32x4* const yq = yb + (size_t)(4 * m + 2 * pr) * plane;
             float rw[3][8];
-            if (L.rgb) {
+            if (EXTRA && L.rgb) {
 #pragma unroll
                 for (int o = 0; o < 3; ++o) {
                     const float* wp = p.rgb_w + ((size_t)b * 3 + o) * p.Cout + cc;
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
                         }
                     }
                     g[0] = v[0].x; g[1] = v[0].y; g[2] = v[1].x; g[3] = v[1].y; g[4] = v[2].x; g[5] = v[2].y; g[6] = v[3].x; g[7] = v[3].y;
-                    if (L.rgb) {
+                    if (EXTRA && L.rgb) {
 #pragma unroll
                         for (int o = 0; o < 3; ++o)
 #pragma unroll
@@ -546,10 +550,27 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? 4 : 2) void
                     if (out.x == 0x12345678u && out.y == 0x9abcdef0u)
 #endif
                     if (ok && gok) yq[off] = out;
+                    if (EXTRA && p.sq_ref && ok && gok) {          // [r5] ContentLoss value of a VGG tap on the ROUNDED output, as in the general epilogue
+                        float rf[8], w[8];
+                        h8_unpack(reinterpret_cast<const u32x4*>(p.sq_ref)[((size_t)b * cg_out + g0 + 4 * m + 2 * pr) * plane + off], rf);
+                        h8_unpack(out, w);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float d = w[e] - rf[e]; sq_lean += d * d; }
+                    }
                 }
             }
         }
-        if (L.rgb) {
+        if (EXTRA && p.sq_ref) {                                   // one atomic per block into L2I_SQ_SLOTS slots (as below)
+            float sq = sq_lean;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem4);
+            if (lane == 0) red[wave] = sq;
+            __syncthreads();
+            if (tid == 0) atomicAdd(p.sq_out + (blockIdx.x & (L2I_SQ_SLOTS - 1)), (red[0] + red[1]) + (red[2] + red[3]));
+        }
+        if (EXTRA && L.rgb) {
             // the two lane halves hold the partial sums of different channel groups of the SAME pixel: exchange, add, lanes 0-31 store three fp32 rows
 #pragma unroll
             for (int n = 0; n < WN; ++n)
@@ -607,6 +628,7 @@ static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
     using G = g8::Geo<WN, K, S, TR, KS>;
     constexpr int BM = WM * 32;
     constexpr int WSLOTS = K * G::KS * 2 * BM;
+    constexpr bool CAN_EXTRA = (K == 3 && S == 1 && TR == 0 && !OUT32);       // the instantiations that exist with the lean epilogue's optional outputs
     H8Launch L;
     L.tiles_x = (p.OW + 31) / 32;
     L.tiles_y = (p.OH + G::TH - 1) / G::TH;
@@ -619,16 +641,28 @@ static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
     static const int lean_env = getenv("L2I_H8_LEAN") ? atoi(getenv("L2I_H8_LEAN")) : 1;
     // identity / ReLU / leaky ReLU as max(g * gpos, g * gneg) needs 0 <= gneg <= gpos
     const bool gains_ok = p.out_gain > 0.f && (p.act != L2I_ACT_LRELU || (p.act_gain > 0.f && p.act_slope >= 0.f && p.act_slope <= 1.f));
-    L.lean_epi = (!OUT32 && lean_env && !p.out_mask && !p.residual && !p.accumulate && !p.sq_ref && gains_ok && (size_t)p.OHf * p.OWf < 0xFFFFFFFFull) ? 1 : 0;
+    bool lean = !OUT32 && lean_env && !p.out_mask && !p.residual && !p.accumulate && gains_ok && (size_t)p.OHf * p.OWf < 0xFFFFFFFFull;
+    if (p.sq_ref && !CAN_EXTRA) lean = false;              // the ContentLoss sum rides on the lean epilogue of the EXTRA instantiations only; elsewhere: the general epilogue
+    L.lean_epi = lean ? 1 : 0;
+    const bool extra = CAN_EXTRA && lean && (p.rgb_w || p.sq_ref);
     L.rgb = p.rgb_w ? 1 : 0;
-    if (L.rgb && !(L.lean_epi && L.mblocks == 1 && TR == 0 && p.rgb_bias && p.rgb_out && (p.Cout % 8) == 0 && (((uintptr_t)p.rgb_w) % 16) == 0))
-        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: rgb_w needs the lean h8 epilogue (no per-pixel operand maps), every output channel in one block (Cout <= 64), rgb_bias / rgb_out, a 16-byte aligned rgb_w");
+    if (L.rgb && !(extra && L.mblocks == 1 && p.rgb_bias && p.rgb_out && (p.Cout % 8) == 0 && (((uintptr_t)p.rgb_w) % 16) == 0))
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: rgb_w needs a 3x3 stride-1 launch on the lean h8 epilogue (no per-pixel operand maps), every output channel in one block (Cout <= 64), rgb_bias / rgb_out, a 16-byte aligned rgb_w");
     size_t lds = (size_t)(2 * G::IN_STAGE + 2 * WSLOTS) * 16;
     if (OUT32 && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: tile does not fit the LDS");
+    const unsigned grid = (unsigned)((total + 7) & ~7L);
+    if constexpr (CAN_EXTRA) {
+        if (extra) {
+            L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN, KS, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL((conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN, KS, true>), dim3(grid), dim3(256), lds, st, p, L);
+            L2I_CHECK_LAUNCH();
+            return L2I_OK;
+        }
+    }
     L2I_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN, KS>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const unsigned grid = (unsigned)((total + 7) & ~7L);
     hipLaunchKernelGGL((conv_h8_kernel<WM, WN, K, S, TR, OUT32, RELU_IN, KS>), dim3(grid), dim3(256), lds, st, p, L);
     L2I_CHECK_LAUNCH();
     return L2I_OK;
