@@ -375,10 +375,30 @@ typedef struct l2i_segmv_seg {
 int l2i_segmented_matvec_f32(float* out, const float* in, const float* in2, const float* w, const float* bias, const float* e1, const float* e2,
                              float* wmod, const float* wrgb, const l2i_segmv_seg* segs, const int32_t* block_seg, int nblocks, int B, void* stream);
 
+/* ---- ABI version 6: the optimiser tail of the walk step on the fp16 path (l2i_optim.hip) ------------------------------------------------------
+ * The reference ends a step with torch.optim.Adam on the walk tensor (transform_base.py:329-331, 487-488); under autocast it would do so through
+ * a GradScaler.  These two entry points are that pair without a host synchronisation: all state lives on the device.
+ *   state  int32[4]:  [L2I_LS_FOUND] 1 = a gradient of this step held an inf / NaN, [L2I_LS_TRACKER] clean steps since the last scale change,
+ *                     [L2I_LS_SKIPPED] updates skipped so far, [L2I_LS_STEPS] steps seen so far
+ *   scale  float[2]:  [0] the dynamic loss-scale factor (a power of two; multiplies every loss branch's incoming gradient), [1] its inverse */
+#define L2I_LS_FOUND 0
+#define L2I_LS_TRACKER 1
+#define L2I_LS_SKIPPED 2
+#define L2I_LS_STEPS 3
+/* state[L2I_LS_FOUND] |= any(!isfinite(g[0..n))).  For walks with several parameter tensors: one call per gradient before the first update. */
+int l2i_nonfinite_flag_f32(const float* g, int64_t n, int32_t* state, void* stream);
+/* One Adam update of p (moments m, v; step = float step counter on the device) with torch.optim.Adam's arithmetic (no weight decay, no amsgrad),
+ * SKIPPED — p, m, v, step untouched — when state[L2I_LS_FOUND] is set or (check_self) g itself holds an inf / NaN.  last != 0: afterwards the
+ * scale state advances as torch._amp_update_scale_ does (found: scale[0] *= backoff, tracker = 0, skipped += 1; clean: ++tracker == interval ->
+ * scale[0] = min(scale[0] * growth, max_scale) and tracker = 0), scale[1] = 1 / scale[0], steps += 1, and the flag is cleared.  scale may be NULL. */
+int l2i_adam_guarded_f32(float* p, const float* g, float* m, float* v, float* step, int64_t n, float lr, float beta1, float beta2, float eps,
+                         int32_t check_self, int32_t* state, float* scale, float growth, float backoff, int32_t interval, float max_scale,
+                         int32_t last, void* stream);
+
 const char* l2i_last_error(void);
 /* Bumped whenever a struct of this header grows or an entry point changes meaning (1: round 1-2; 2: round 3, l2i_conv_params gained w_bstride /
- * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
-#define L2I_ABI_VERSION 5
+ * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
+#define L2I_ABI_VERSION 6
 int l2i_abi_version(void);
 int l2i_sizeof_conv_params(void);       /* sizeof(struct l2i_conv_params) of THIS build */
 

@@ -105,6 +105,8 @@ _SIGNATURES = {
     'l2i_modulate_planes_h8': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'l2i_modulate_planes_multi_h8': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     'l2i_segmented_matvec_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    'l2i_nonfinite_flag_f32': (c_i, [c_p, c_l, c_p, c_p]),
+    'l2i_adam_guarded_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_i, c_p, c_p, c_f, c_f, c_i, c_f, c_i, c_p]),
     'l2i_last_error': (ctypes.c_char_p, []),
     'l2i_abi_version': (c_i, []),
     'l2i_sizeof_conv_params': (c_i, []),
@@ -114,7 +116,7 @@ _SIGNATURES = {
 for _n in [k for k in _SIGNATURES if k.endswith('_h8') or k in ('l2i_cast_f32_to_h8', 'l2i_cast_h8_to_f32')]:
     _SIGNATURES[_n + '_f16'] = _SIGNATURES[_n]
 
-ABI_VERSION = 5          # L2I_ABI_VERSION of include/l2i.h this binding mirrors
+ABI_VERSION = 6          # L2I_ABI_VERSION of include/l2i.h this binding mirrors
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -30,3 +30,6 @@ CONCURRENT_LOSS_BRANCHES = True
 
 # transform_base.py:290 hard-codes ``is_mlp = False`` ("TODO: Hard code"); True builds WalkMlpMultiW instead of WalkLinearMultiW
 WALK_IS_MLP = False
+
+# fp16 elements (--precision f16): clean steps before the dynamic loss-scale factor doubles again (torch.cuda.amp.GradScaler's growth_interval)
+LOSS_SCALE_GROWTH_INTERVAL = 2000

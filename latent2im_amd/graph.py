@@ -176,9 +176,6 @@ def load_networks(resolution, device, need_vgg=True, need_d=True):
     if conv.PRECISION in conv.H8_PRECISIONS:                           # the 16-bit path (BASELINE config 5): bf16 h8 feature maps, one bf16 MFMA per MAC (nets16.py)
         from . import nets16
         GenCls, RegCls, VggCls, DCls = nets16.Generator, nets16.ResNet50, nets16.VGG19Prefix, nets16.Discriminator
-        if conv.PRECISION == 'f16':                                    # static power-of-two gradient scales of the fp16 path for this resolution / batch
-            from . import constants as _c
-            nets16.LOSS_SCALE_LOG2.update(nets16.loss_scale_for(resolution, _c.BATCH_SIZE))
     else:
         GenCls, RegCls, VggCls, DCls = Generator, ResNet50, VGG19Prefix, Discriminator
     src['precision'] = conv.PRECISION
@@ -198,6 +195,14 @@ def load_networks(resolution, device, need_vgg=True, need_d=True):
         # the reference's netD is ALWAYS freshly initialised (never loaded): seeded here for reproducibility
         netD = DCls(synth.discriminator_state(resolution, seed=constants.SYNTH_SEED_D), resolution, device=device)
         src['D'] = 'random-init(seed=%d)' % constants.SYNTH_SEED_D
+    if conv.PRECISION == 'f16':
+        # gradient scales of the fp16 path (nets16.loss_scale_for): static exponents for this resolution and the PER-RANK batch — every rank's losses
+        # are means over its own shard — times one dynamic factor on the device; one scaler per graph, carried by its four networks
+        from . import optim
+        per_rank = max(constants.BATCH_SIZE // dist.world_size(), 1)
+        scaler = optim.LossScaler(nets16.loss_scale_for(resolution, per_rank), device, growth_interval=constants.LOSS_SCALE_GROWTH_INTERVAL)
+        nets16.attach_scaler((netG, netD, reg, vgg), scaler)
+        src['loss_scale_log2'] = dict(scaler.log2)
     return netG, netD, reg, vgg, src
 
 
@@ -262,7 +267,14 @@ class TransformGraph:
         else:
             raise NotImplementedError('unknown walk_type %r' % (walk_type,))
 
-        self.optimizers = torch.optim.Adam(self.walk.parameters(), lr=self.lr, betas=(0.5, 0.99))
+        # fp16 elements: the same Adam with GradScaler semantics on the device — a step whose gradient holds an inf / NaN is skipped and the dynamic
+        # loss scale halves (optim.py); every other precision: torch's own, as in the reference (transform_base.py:329-331)
+        self.loss_scaler = getattr(netG, 'scaler', None)
+        if self.loss_scaler is not None:
+            from . import optim
+            self.optimizers = optim.GuardedAdam(self.walk.parameters(), lr=self.lr, betas=(0.5, 0.99), scaler=self.loss_scaler)
+        else:
+            self.optimizers = torch.optim.Adam(self.walk.parameters(), lr=self.lr, betas=(0.5, 0.99))
         self.walk_type = walk_type
         self.last_terms = None
 

@@ -37,8 +37,10 @@ LRELU_MASK = (SQRT2, 0.2 * SQRT2)
 # the GRADIENT maps do not (a ContentLoss gradient at 1024^2 is ~1e-11 per element).  Each loss branch therefore multiplies the gradient it receives by
 # a power of two on the way in and its fp32 result (the 3-channel image gradient; the latent gradient of the generator) by the inverse on the way
 # out: exact in every fp32 quantity, and inside a branch all maps are linear in the incoming gradient.  The exponents are STATIC per (branch,
-# resolution, batch): `loss_scale` below — measured with tools/bf16_study.py --probe (max / median magnitude of every gradient map), chosen to put the
-# largest map of a branch near 2^8 .. 2^11; nothing is checked at run time.  bf16 elements: every scale is 1 (not applied).
+# resolution, per-GPU batch): `loss_scale_for` below — measured with tools/bf16_study.py --probe (max / median magnitude of every gradient map), chosen
+# to put the largest map of a branch near 2^5.  [r6] On top of them ONE dynamic power of two with torch GradScaler's semantics, kept on the device
+# (optim.LossScaler / optim.GuardedAdam, csrc/l2i_optim.hip): a step whose walk gradient holds an inf / NaN is skipped and the factor halves, it doubles
+# again after `constants.LOSS_SCALE_GROWTH_INTERVAL` clean steps.  bf16 elements: every scale is 1 (not applied).
 # [r5] the three image-side convs (VGG conv1_1, the discriminator's from-RGB 1x1, ResNet-50's 7x7 stem) read the fp32 3-channel image and STORE h8
 # (l2i_conv_img_h8, csrc/l2i_img_h8.hip), the stem's input gradient READS h8 (l2i_conv_params::in_h8): no padded 16 / 32-channel 16-bit copy of the
 # image, no fp32 stem map, no cast passes (-6 GB of the step's HBM traffic at 1024^2 batch 8).  L2I_H8_IMG_CONVS=0: the round-4 form (A/B).
@@ -60,13 +62,12 @@ def _probe(tag, t):
         PROBE.append((tag, tuple(t.shape), float(a.max()), float(nz.median()) if nz.numel() else 0.0, float((a == 0).float().mean())))
 
 
-LOSS_SCALE_LOG2 = dict(R=0, V=0, D=0, G=0)      # set by loss_scale_for(); an override for experiments: L2I_F16_SCALES="R,V,D,G" (log2 values)
-
-
 def loss_scale_for(resolution, batch):
-    """log2 of the per-branch gradient scales of the fp16 path at `resolution`^2, per-GPU `batch` (see above).  The magnitudes follow the loss
-    normalisations: the ContentLoss is a mean over B * C * H * W elements (gradient ~ 1 / (B H W)), the regressor's BCE a mean over B * attrs through
-    an average pool (1 / B), the discriminator's BCE a mean over B through learned-scale convs, and the generator receives their sum."""
+    """log2 of the per-branch STATIC gradient scales of the fp16 path at `resolution`^2 and PER-GPU `batch` (each rank's losses are means over its own
+    shard, dist.shard: its gradients scale with 1 / B_local, not with the global batch).  The magnitudes follow the loss normalisations: the
+    ContentLoss is a mean over B * C * H * W elements (gradient ~ 1 / (B H W)), the regressor's BCE a mean over B * attrs through an average pool
+    (1 / B), the discriminator's BCE a mean over B through learned-scale convs, and the generator receives their sum.  An override for experiments
+    and for the overflow-guard tests: L2I_F16_SCALES="R,V,D,G" (log2 values)."""
     env = os.environ.get('L2I_F16_SCALES')
     if env:
         r, v, d, g = (int(x) for x in env.split(','))
@@ -89,11 +90,32 @@ F16_SCALE_RES = dict(R=2, V=2, D=0, G=0)
 F16_D_BLOCK_GAIN = 2.0
 
 
+# [r6] The scales live on the NETWORK objects (`net.scaler`, an optim.LossScaler shared by the four networks of one graph; None = unscaled: bf16
+# elements, or an fp16 network driven directly by a test) — round 5 kept them in a module-global dict that every load_networks() call overwrote, so two
+# live graphs of different resolution or batch shared whichever was built last.  On top of the static exponents the scaler carries ONE dynamic power
+# of two on the device (GradScaler semantics without a host read: optim.py, csrc/l2i_optim.hip): every branch multiplies its incoming gradient by
+# static * dynamic, the generator's latent gradient leaves multiplied by 1 / (static_G * dynamic).
+def attach_scaler(nets, scaler):
+    for n in nets:
+        if n is not None:
+            n.scaler = scaler
+    return scaler
+
+
 def _gs(net, key):
-    """The branch's gradient scale (a float power of two; 1.0 on the bf16 path)."""
-    if net.dtype != torch.float16:
+    """The branch's STATIC gradient scale (a float power of two; 1.0 without a scaler: bf16 elements / stand-alone networks)."""
+    sc = getattr(net, 'scaler', None)
+    if sc is None or net.dtype != torch.float16:
         return 1.0
-    return float(2.0 ** LOSS_SCALE_LOG2[key])
+    return sc.static(key)
+
+
+def _dyn(net, inverse=False):
+    """The dynamic factor (or its inverse) as a one-element device tensor, or None."""
+    sc = getattr(net, 'scaler', None)
+    if sc is None or net.dtype != torch.float16:
+        return None
+    return sc.inv_dyn if inverse else sc.dyn
 
 
 # =====================================================================================================================================
@@ -156,8 +178,9 @@ class _Content16Fn(torch.autograd.Function):
     def backward(ctx, g_losses):
         net, (o1, o2, o3, o4) = ctx.net, ctx.org
         c1, c2, p, c3, c4, idx = ctx.acts
-        S = _gs(net, 'V')
-        gl = [(g_losses[k:k + 1] * S).contiguous() if S != 1.0 else g_losses[k:k + 1].contiguous() for k in range(4)]
+        S, dyn = _gs(net, 'V'), _dyn(net)
+        gs = g_losses if dyn is None else g_losses * (dyn * S)           # static * dynamic scale (fp16 elements; exact: powers of two)
+        gl = [gs[k:k + 1].contiguous() for k in range(4)]
         hw = lambda t: (t.shape[2], t.shape[3])
         d4 = K16.sqdiff(o4, c4, coef=2.0 / c4.numel(), coef_dev=gl[3], want_grad=True, want_sum=False)[1]
         d4_probe = d4 if PROBE is not None else None
@@ -253,7 +276,9 @@ class _ResNet16Fn(torch.autograd.Function):
         # epilogue — and MEASURED: input-gradient cosine against the exact oracle 0.9715 / 0.9526 at 64^2 / 256^2 with either trunk, identical to four
         # digits (profiles/r04_bf16_trunk_f32_vs_bf16.txt; the cause is the forward's storage rounding), while its two extra
         # epilogue branches cost the 16-bit conv kernel 3 - 17 % on launches with a residual (c5 209.5 -> 213.1 images/s without them): removed.
-        S = _gs(net, 'R')
+        S, dyn = _gs(net, 'R'), _dyn(net)
+        if dyn is not None:
+            g_feat = g_feat * dyn
         g = (g_feat * (S / (h * w))).reshape(b, g8, 1, 1, 8).expand(b, g8, h, w, 8).contiguous().to(net.dtype)
         G = K16.mask_mul(g, last)                                                        # gradient w.r.t. the pre-ReLU sum of the last block
         n = len(net.blocks)
@@ -363,8 +388,10 @@ class _DBody16Fn(torch.autograd.Function):
         net, saved = ctx.net, ctx.saved
         if saved is None:
             raise RuntimeError('discriminator was run without a differentiable input')
-        S = _gs(net, 'D')
-        bg = F16_D_BLOCK_GAIN if S != 1.0 else 1.0        # fp16: the gradient is doubled once per block on both branches (undone with S at the image)
+        S, dyn = _gs(net, 'D'), _dyn(net)
+        if dyn is not None:
+            g32 = g32 * dyn
+        bg = F16_D_BLOCK_GAIN if dyn is not None else 1.0        # fp16: the gradient is doubled once per block on both branches (undone with S at the image)
         g = K16.cast_to_h8(g32.contiguous() * S if S != 1.0 else g32.contiguous(), dtype=net.dtype)
         for blk, (y1, y2, in_hw) in zip(reversed(net.blocks), reversed(saved[1:])):
             _probe('D.g@%d' % in_hw[0], g)
@@ -539,4 +566,6 @@ class _Synthesis16Fn(torch.autograd.Function):
         g_lat = plan.backward(B, s_all, d_all, red_dz, q_all, red_rgb)
         if S != 1.0:
             g_lat = g_lat * (1.0 / S)
+        if _dyn(gen) is not None:
+            g_lat = g_lat * _dyn(gen, inverse=True)
         return g_lat, None, None

@@ -37,6 +37,10 @@ CASES = {
                  bounded=True, f64=True),
     's1024': dict(size=1024, batch=1, attrs=SCENE5, scene=True, z_seed=21, alpha=lambda: np.ones((1, 5)) * np.random.RandomState(22).uniform(-1, 1, 5), clamp=True,
                   bounded=True, f64=True),
+    # [r6] config 5 exactly as bench.py times it: 1024^2, per-GPU batch 8, five scene attributes, clamp flow (float32 evaluation, like c3 / c4: the
+    # float64 autograd graph of a four-sample stddev subgroup at 1024^2 does not fit the build container's 64 GB)
+    's1024b8': dict(size=1024, batch=8, attrs=SCENE5, scene=True, z_seed=21, alpha=lambda: np.ones((8, 5)) * np.random.RandomState(22).uniform(-1, 1, 5), clamp=True,
+                    bounded=True, f64=False),
 }
 ATTR_IDX = {'Smiling': 31, 'Young': 39, 'Male': 20, 'Eyeglasses': 15, 'Bangs': 5}
 

@@ -370,20 +370,25 @@ def test_bf16_networks_vs_float64_oracle(size):
     assert max(r['V_loss_rel']) < 4e-3 and r['V_grad_cos'] > 0.99 and r['V_grad_l2'] < 0.13      # (content terms: 3e-4 at 64^2, 1.9e-3 at 256^2)
 
 
-def _cached_step(precision, size, batch):
+def _cached_step(precision, size, batch, hipgraph=False):
     """tools/bf16_study.py:step for BASELINE config 5's flow against the float64 oracle evaluation of tests/golden/oracle_1024.npz (cases s64 / s256 /
-    s1024: the same seeds; [r5] the oracle used to be re-evaluated on every run, 8 - 36 s per case)."""
+    s1024: the same seeds; [r5] the oracle used to be re-evaluated on every run, 8 - 36 s per case; [r6] s1024b8: the per-GPU batch bench.py runs,
+    float32 oracle — 1e-3 of the float64 one in relative L2 on the cases that hold both)."""
+    import gc
     from latent2im_amd import conv
     from tests import oracle_cache
     from tests.conftest import GOLDEN
     st = _study()
-    case = oracle_cache.CASES['s%d' % size]
+    name = 's%d' % size + ('b%d' % batch if batch == 8 else '')
+    case = oracle_cache.CASES[name]
     assert (case['batch'], case['z_seed']) == (batch, 21)
     old, st.PRECISION = conv.PRECISION, precision
     try:
-        return st.step(size, batch, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], True, 'scene', cached=oracle_cache.load(GOLDEN, 's%d' % size))
+        return st.step(size, batch, ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk'], True, 'scene', cached=oracle_cache.load(GOLDEN, name), hipgraph=hipgraph)
     finally:
         conv.PRECISION = old
+        gc.collect()
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize('size,batch', [(64, 4), (256, 2), (1024, 1)])
@@ -412,6 +417,60 @@ def test_fp16_training_step_vs_float64_oracle(size, batch):
     assert r["loss_rel"] < 5e-4 and r["reg_rel"] < 5e-4 and r["gan_rel"] < 4e-3
     assert max(r['per_attr_reg_loss_delta']) < 2e-4
     assert r['grad_cos'] > 0.998 and r['grad_l2'] < 0.06, (r['grad_cos'], r['grad_l2'])
+
+
+@pytest.mark.parametrize('hipgraph', [False, True], ids=['eager', 'hipgraph'])
+def test_fp16_config5_as_benched_1024_batch8_vs_oracle(hipgraph):
+    """[r6] BASELINE config 5 EXACTLY as `bench.py --config c5` times it — SceneGraph, five scene attributes, clamp flow, IEEE fp16 h8 maps with the
+    gradient scales of nets16.loss_scale_for(1024, 8), 1024^2, per-GPU batch 8, launched eagerly and REPLAYED from the hipGraph — against the oracle
+    (cached case s1024b8).  The exponents depend on batch and resolution, so this is the leg that checks the batch-8 values for range; same contract as
+    test_fp16_training_step_vs_float64_oracle (the oracle here is its float32 evaluation: within 1e-3 relative L2 of float64 on every case that holds
+    both, against a bound of 0.06)."""
+    r = _cached_step('f16', 1024, 8, hipgraph=hipgraph)
+    print(r)
+    assert r['finite'] and r['hipgraph'] == hipgraph
+    assert r['x0_relmax'] < 6e-3 and r['x1_relmax'] < 6e-3
+    assert r['a0_absmax'] < 2e-4 and r['eps_absmax'] < 2e-4
+    assert r["loss_rel"] < 5e-4 and r["reg_rel"] < 5e-4 and r["gan_rel"] < 4e-3
+    assert max(r['per_attr_reg_loss_delta']) < 2e-4
+    assert r['grad_cos'] > 0.998 and r['grad_l2'] < 0.06, (r['grad_cos'], r['grad_l2'])
+
+
+def test_fp16_hipgraph_captured_steps_follow_eager_steps():
+    """[r6] tests/test_networks_gpu.py::test_hipgraph_captured_step_matches_eager on fp16 elements: three optimiser steps (GuardedAdam, dynamic loss
+    scale) replayed from the graph against the same steps launched eagerly.  Same kernels on the same inputs: only the fp32 atomics of the reductions
+    reorder, and 16-bit rounding may turn that into a one-step difference of an activation."""
+    from latent2im_amd import capture, constants, selfcheck, synth
+    old = conv.PRECISION
+    try:
+        conv.PRECISION = 'f16'
+        attrs = ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk']
+        size, batch = 64, 4
+        rs = np.random.RandomState(3)
+        zs = [synth.z_sample(batch, seed=40 + i) for i in range(3)]
+        al = [np.ones((batch, 5)) * rs.uniform(-1, 1, 5) for _ in range(3)]
+        ge = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform='scene')
+        assert type(ge.optimizers).__name__ == 'GuardedAdam' and ge.loss_scaler is not None
+        eager = [selfcheck.run_step(ge, zs[i], al[i], clamp=True) for i in range(3)]
+        gc_ = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform='scene')
+        step = capture.CapturedStep(gc_, batch, 5, clamp=True)
+        for i in range(3):
+            r = step(zs[i], al[i])
+            torch.cuda.synchronize()
+            e = eager[i]
+            assert float((r['x1'].float() - e['x1'].float()).abs().max()) <= 2.0 ** -8 * float(e['x1'].abs().max())
+            assert abs(float(r['loss']) - float(e['loss'])) <= 1e-4 * abs(float(e['loss']))
+            g, ge_ = r['grad'].float(), e['grad'].float()
+            cos = float((g * ge_).sum() / (g.norm() * ge_.norm()))
+            assert cos > 0.9995, (i, cos)
+        w0 = torch.from_numpy(synth.walk_init(5, 10, seed=7))
+        assert not torch.equal(gc_.walk.w.detach().cpu(), w0)
+        assert float((gc_.walk.w - ge.walk.w).abs().max()) <= 2.5e-3          # three Adam steps of lr 1e-3: entries whose gradient is rounding noise may step apart
+        st = gc_.loss_scaler.stats()
+        assert st['steps'] == 3 and st['skipped'] == 0 and st['scale'] == 1.0, st
+    finally:
+        conv.PRECISION = old
+        constants.resolution, constants.BATCH_SIZE = 256, 4
 
 
 def test_bf16_hipgraph_replay_matches_eager_1024_batch8():
@@ -456,7 +515,8 @@ def test_bf16_hipgraph_replay_matches_eager_1024_batch8():
         constants.resolution, constants.BATCH_SIZE = 256, 4
 
 
-def test_bf16_data_parallel_matches_single_process(tmp_path):
+@pytest.mark.parametrize('prec', ['bf16', 'f16'])
+def test_bf16_data_parallel_matches_single_process(tmp_path, prec):
     """SURVEY 8(e) on the 16-bit path: two rank processes (one GPU here, process group over gloo; RCCL on a node) run the product graph with
     L2I_PRECISION=bf16 for two optimizeParametersAll steps on strided shards of a global batch of 8, full loss; a single process runs the
     global batch.  Sharding changes which samples share a launch, not a sample's arithmetic (bf16 rounding is per element, the discriminator's
@@ -468,7 +528,7 @@ def test_bf16_data_parallel_matches_single_process(tmp_path):
     from latent2im_amd import dist
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dp_worker.py')
     args = ['64', '8', '2', '0']
-    env = dict(os.environ, L2I_DIST_BACKEND='gloo', L2I_PRECISION='bf16')
+    env = dict(os.environ, L2I_DIST_BACKEND='gloo', L2I_PRECISION=prec)       # [r6] f16: per-RANK batch in the loss scales, GuardedAdam after the all-reduce
     env.pop('WORLD_SIZE', None)
     single, multi = str(tmp_path / 'single.npz'), str(tmp_path / 'dp2.npz')
     # (one after the other: three processes time-slicing the box's one GPU at once were measured 2x SLOWER than the two runs in sequence)
@@ -478,7 +538,7 @@ def test_bf16_data_parallel_matches_single_process(tmp_path):
     assert codes == [0, 0], codes
     a, b = np.load(single), np.load(multi)
     assert int(a['world']) == 1 and int(b['world']) == 2
-    assert str(a['precision']) == 'bf16' and str(b['precision']) == 'bf16'
+    assert str(a['precision']) == prec and str(b['precision']) == prec
     la, lb = a['losses'][0], b['losses'][0]                            # total, regressor, content, GAN
     print('bf16 DP losses: single', la, 'two ranks', lb)
     np.testing.assert_allclose(lb[[0, 1, 3]], la[[0, 1, 3]], rtol=1e-3, atol=1e-5)
@@ -536,3 +596,112 @@ def test_modulate_planes_multi_matches_per_layer():
     for w32, off, ci, v in zip(w32s, offs, rows, views):
         want = K16.modulate_planes(w32, s_all[B * off:B * (off + ci)].view(B, ci).contiguous())
         assert v.shape == want.shape and torch.equal(v, want)
+
+
+# ---- [r6] the optimiser tail of the fp16 path: guarded Adam + dynamic loss scale on the device (csrc/l2i_optim.hip, latent2im_amd/optim.py) ---------
+def test_fp16_guarded_adam_matches_torch_adam_and_skips_nonfinite_steps():
+    """l2i_adam_guarded_f32 against torch.optim.Adam(lr, betas=(0.5, 0.99)) (transform_base.py:329-331) over six steps of random gradients on a
+    walk-shaped tensor: parameter and both moments to float32 rounding.  Then GradScaler semantics: a gradient with one inf (and one with a NaN) leaves
+    parameter, moments and step counter bit-identical, halves the dynamic scale, resets the growth tracker, counts the skip; `interval` clean steps
+    double the scale again, never past its cap."""
+    from latent2im_amd import optim
+    rs = np.random.RandomState(0)
+    w0 = T(rs.randn(5, 18, 512) * 0.02)
+    pa, pb = torch.nn.Parameter(w0.clone().to(DEV)), torch.nn.Parameter(w0.clone().to(DEV))
+    ref = torch.optim.Adam([pa], lr=1e-3, betas=(0.5, 0.99))
+    sc = optim.LossScaler(dict(R=0, V=0, D=0, G=0), DEV, growth_interval=3, max_log2=1)
+    opt = optim.GuardedAdam([pb], lr=1e-3, betas=(0.5, 0.99), scaler=sc)
+    for i in range(6):
+        g = T(rs.randn(5, 18, 512) * 10.0 ** rs.uniform(-6, 0)).to(DEV)
+        pa.grad, pb.grad = g.clone(), g.clone()
+        ref.step()
+        opt.step()
+    torch.cuda.synchronize()
+    assert float((pa - pb).abs().max()) < 2e-7, float((pa - pb).abs().max())
+    for key in ('exp_avg', 'exp_avg_sq'):                                            # (m + (g - m) / 2 cancels: absolute bound at the moment's own scale)
+        got, want = opt.state[pb][key].cpu().numpy(), ref.state[pa][key].cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6 * float(np.abs(want).max()))
+    st = sc.stats()
+    assert st == dict(scale=2.0, tracker=0, skipped=0, steps=6), st                 # grew once after 3 clean steps; the cap 2^1 stopped the second doubling
+    before = [pb.detach().clone(), opt.state[pb]['exp_avg'].clone(), opt.state[pb]['exp_avg_sq'].clone(), opt.state[pb]['step'].clone()]
+    for bad in (float('inf'), float('nan')):
+        g = T(rs.randn(5, 18, 512)).to(DEV)
+        g[3, 7, 100] = bad
+        pb.grad = g
+        opt.step()
+    torch.cuda.synchronize()
+    after = [pb.detach(), opt.state[pb]['exp_avg'], opt.state[pb]['exp_avg_sq'], opt.state[pb]['step']]
+    assert all(torch.equal(a, b) for a, b in zip(before, after))
+    st = sc.stats()
+    assert st == dict(scale=0.5, tracker=0, skipped=2, steps=8), st
+    assert float(sc.inv_dyn) == 2.0
+    pb.grad = T(rs.randn(5, 18, 512)).to(DEV)
+    opt.step()
+    assert not torch.equal(pb.detach(), before[0]) and float(opt.state[pb]['step']) == 7.0
+    # several parameter tensors (the MLP walks): one inf in ANY of them skips ALL of them
+    ps = [torch.nn.Parameter(T(rs.randn(64, 32)).to(DEV)), torch.nn.Parameter(T(rs.randn(32)).to(DEV))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref2, opt2 = torch.optim.Adam(qs, lr=1e-2, betas=(0.5, 0.99)), optim.GuardedAdam(ps, lr=1e-2, betas=(0.5, 0.99))
+    for i in range(3):
+        gs = [T(rs.randn(*p.shape)).to(DEV) for p in ps]
+        for p, q, g in zip(ps, qs, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        if i == 1:
+            ps[1].grad[5] = float('inf')                        # the SECOND tensor: the first one's update must be skipped too
+            keep = [p.detach().clone() for p in ps]
+            opt2.step()
+            assert all(torch.equal(p.detach(), k) for p, k in zip(ps, keep))
+            continue
+        ref2.step()
+        opt2.step()
+    for p, q in zip(ps, qs):
+        assert float((p - q).abs().max()) < 1e-6
+
+
+def test_fp16_overflow_guard_skips_steps_and_backs_the_scale_off(monkeypatch):
+    """The whole fp16 training step with the static exponents forced 13 octaves too high (L2I_F16_SCALES; the calibrated ones leave eleven octaves of
+    headroom): the scaled gradient maps overflow fp16, the walk gradient comes back non-finite, and — instead of inf / NaN going straight into Adam as in
+    round 5 — the step is skipped (walk and moments untouched), the dynamic factor halves step by step until the maps fit, and from then on the walk
+    trains on gradients that agree with a run at the calibrated exponents.  No host read anywhere in the step (the same code path replays from the
+    hipGraph: test_fp16_hipgraph_captured_steps_follow_eager_steps)."""
+    from latent2im_amd import constants, nets16, selfcheck, synth
+    old = conv.PRECISION
+    attrs = ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk']
+    size, batch = 64, 4
+    zs = synth.z_sample(batch, seed=21)
+    alpha = np.ones((batch, 5)) * np.random.RandomState(22).uniform(-1, 1, 5)
+    try:
+        conv.PRECISION = 'f16'
+        good = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform='scene')
+        base = nets16.loss_scale_for(size, batch)
+        assert good.loss_scaler.log2 == base
+        rg = selfcheck.run_step(good, zs, alpha, clamp=True, optimize=False)
+        assert bool(torch.isfinite(rg['grad']).all())
+        monkeypatch.setenv('L2I_F16_SCALES', ','.join(str(base[k] + 13) for k in 'RVDG'))
+        hot = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform='scene')
+        monkeypatch.delenv('L2I_F16_SCALES')
+        assert hot.loss_scaler.log2 == {k: v + 13 for k, v in base.items()}
+        w0 = hot.walk.w.detach().clone()
+        skipped, first_clean = 0, None
+        for i in range(16):
+            r = selfcheck.run_step(hot, zs, alpha, clamp=True)
+            finite = bool(torch.isfinite(r['grad']).all())
+            assert bool(torch.isfinite(hot.walk.w).all())                           # whatever the gradient held, the walk never sees it
+            if not finite:
+                assert first_clean is None, 'a non-finite step after a clean one at a smaller scale'
+                assert torch.equal(hot.walk.w.detach(), w0)
+                skipped += 1
+            elif first_clean is None:
+                first_clean = r
+                break
+        st = hot.loss_scaler.stats()
+        print('skipped %d steps; scaler %s' % (skipped, st))
+        assert 1 <= skipped <= 14 and first_clean is not None
+        assert st['skipped'] == skipped and st['scale'] == 2.0 ** -skipped and st['steps'] == skipped + 1
+        assert not torch.equal(hot.walk.w.detach(), w0)                              # the first finite step trained
+        g, gg = first_clean['grad'].float(), rg['grad'].float()
+        cos = float((g * gg).sum() / (g.norm() * gg.norm()))
+        assert cos > 0.999 and abs(float(g.norm() / gg.norm()) - 1) < 0.03, (cos, float(g.norm() / gg.norm()))
+    finally:
+        conv.PRECISION = old
+        constants.resolution, constants.BATCH_SIZE = 256, 4

@@ -37,8 +37,7 @@ def l2rel(a, b):
 def networks(size, batch):
     from latent2im_amd import nets16
     conv.PRECISION = PRECISION
-    if PRECISION == 'f16':                                  # the networks are driven by unit-scale random upstream gradients here, not by the loss: no scaling
-        nets16.LOSS_SCALE_LOG2.update(dict(R=0, V=0, D=0, G=0))
+    # (fp16: the networks are driven by unit-scale random upstream gradients here, not by the loss — built stand-alone they carry no scaler: no scaling)
     out = dict(case='networks', precision=PRECISION, size=size, batch=batch)
     dt = torch.float64
     rs = np.random.RandomState(size)
@@ -115,23 +114,29 @@ def probe(size, batch, attrs, clamp, transform='face'):
         rows, nets16.PROBE = nets16.PROBE, None
     print('== %s %d^2 batch %d, %d attrs: loss %.6f, walk-gradient max %.3e, finite %s; scales (log2) %s' % (
         PRECISION, size, batch, len(attrs), float(r['loss']), float(r['grad'].abs().max()), bool(torch.isfinite(r['grad']).all() and torch.isfinite(r['x1']).all()),
-        nets16.LOSS_SCALE_LOG2 if PRECISION == 'f16' else '-'))
+        gr.loss_scaler.log2 if gr.loss_scaler is not None else '-'))
     for tag, shape, mx, med, zf in rows:
         print('  %-16s %-24s max %.3e (2^%6.1f)  median %.3e (2^%6.1f)  zeros %.3f' % (tag, 'x'.join(str(v) for v in shape), mx, np.log2(mx) if mx > 0 else -999,
                                                                                     med, np.log2(med) if med > 0 else -999, zf))
     constants.resolution, constants.BATCH_SIZE = 256, 4
 
 
-def step(size, batch, attrs, clamp, transform='face', cached=None):
+def step(size, batch, attrs, clamp, transform='face', cached=None, hipgraph=False):
     """One training step on the 16-bit path against the float64 oracle.  ``cached``: a tests.oracle_cache.Cached case holding that oracle evaluation
-    (the GPU tests pass the committed one instead of spending 8 - 36 s of CPU per case; image errors are then taken at its 4096 probe pixels)."""
-    from latent2im_amd import constants
+    (the GPU tests pass the committed one instead of spending 8 - 36 s of CPU per case; image errors are then taken at its 4096 probe pixels).
+    ``hipgraph``: forward + backward REPLAYED from one hipGraph (capture.CapturedStep), the way bench.py --config c5 runs the step."""
+    from latent2im_amd import capture, constants
     conv.PRECISION = PRECISION
     gr = selfcheck.build_graph(size, attrs, batch, lr=1e-3, transform=transform)
     zs = synth.z_sample(batch, seed=21)
     rs = np.random.RandomState(22)
     alpha = np.ones((batch, len(attrs))) * (rs.uniform(-1, 1, len(attrs)) if clamp else rs.uniform(0, 1, len(attrs)))
-    r = selfcheck.run_step(gr, zs, alpha, clamp=clamp, optimize=False)
+    if hipgraph:
+        cs = capture.CapturedStep(gr, batch, len(attrs), clamp=clamp)
+        r = cs(zs, alpha, optimize=False)
+        r = cs(zs, alpha, optimize=False)                   # the second replay: the graph holds no state of its own
+    else:
+        r = selfcheck.run_step(gr, zs, alpha, clamp=clamp, optimize=False)
     torch.cuda.synchronize()
     dt = torch.float64
     idx = gr.attrIdx
@@ -148,7 +153,7 @@ def step(size, batch, attrs, clamp, transform='face', cached=None):
         img = dict(x0_relmax=rel(r['x0'], o['x0']), x1_relmax=rel(r['x1'], o['x1']), x1_l2=l2rel(r['x1'], o['x1']))
     tgt = o['target'].double()
     per_attr = lambda p: -(tgt * p.clamp(min=1e-12).log() + (1 - tgt) * (1 - p).clamp(min=1e-12).log()).mean(0)
-    out = dict(case='step', precision=PRECISION, size=size, batch=batch, attrs=len(attrs), clamp=clamp, finite=bool(torch.isfinite(r['grad']).all() and torch.isfinite(r['x1']).all()),
+    out = dict(case='step', precision=PRECISION, size=size, batch=batch, attrs=len(attrs), clamp=clamp, hipgraph=bool(hipgraph), finite=bool(torch.isfinite(r['grad']).all() and torch.isfinite(r['x1']).all()),
                **img,
                a0_absmax=float((r['a0'].double().cpu() - o['alpha_org']).abs().max()), eps_absmax=float((r['eps'].double().cpu() - o['eps']).abs().max()),
                reg_rel=abs(float(r['terms']['reg']) - float(o['reg'])) / abs(float(o['reg'])), cont_rel=abs(float(r['terms']['cont']) - float(o['cont'])) / abs(float(o['cont'])),

@@ -9,7 +9,7 @@ size, batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1024, int(sys.argv[4]) 
 attrs = ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk']
 np.random.seed(1234)
 g = selfcheck.build_graph(size, attrs, batch, lr=1e-4, transform='scene')
-print('scales', nets16.LOSS_SCALE_LOG2)
+print('scales', g.loss_scaler.log2 if g.loss_scaler is not None else None)
 zs = synth.z_sample(batch * 6, seed=0)
 for i in range(6):
     alpha = np.ones((batch, 5)) * np.random.uniform(-1, 1, 5)
