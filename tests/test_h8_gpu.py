@@ -705,3 +705,58 @@ def test_fp16_overflow_guard_skips_steps_and_backs_the_scale_off(monkeypatch):
     finally:
         conv.PRECISION = old
         constants.resolution, constants.BATCH_SIZE = 256, 4
+
+
+@pytest.mark.parametrize('name,up', [('same512', False), ('up512', True)])
+def test_modulated_conv_layer_fixture_h8(name, up):
+    """[r6] The reference's ModulatedConv2d layer fixtures (tests/golden/modconv.npz; networks.py:231-272; 48 -> 40 and 40 -> 24 channels: ragged channel
+    groups on both sides) through the 16-bit path's call sequence — style folded into per-sample weight planes (l2i_modulate_planes_h8), demodulation as
+    out_scale, the separable blur, the gradient conv on planes carrying the demodulation, the style gradient from dot_reduce — under the 16-bit
+    contract (outputs and gradients to 2^-7 of their largest entry: three roundings on the way)."""
+    import math
+    from latent2im_amd import kernels16 as K16
+    from latent2im_amd.generator import _Mod
+    from tests.conftest import GOLDEN
+    import os
+    g = np.load(os.path.join(GOLDEN, 'modconv.npz'))
+    P = {'m.' + k[len(name) + 3:]: g[k] for k in g.files if k.startswith(name + '.P.')}
+    W = T(P['m.weight'])[0]
+    cout, cin, k, _ = W.shape
+    ws = W * (1.0 / math.sqrt(cin * k * k))
+    mod = _Mod(P, 'm', DEV)
+    x, w, gy = (T(g['%s.%s' % (name, n)]).to(DEV) for n in ('x', 'w', 'gy'))
+    B = x.shape[0]
+    s = mod(w)
+    Tm = (ws * ws).sum((2, 3)).to(DEV)
+    demod = torch.rsqrt((s * s) @ Tm.t() + 1e-8)
+    pad32 = lambda v: torch.cat([v, v.new_zeros(B, (v.shape[1] + 31) // 32 * 32 - v.shape[1])], 1).contiguous()
+    hc = conv.H8Conv(ws, stride=2 if up else 1, padding=0 if up else 1, transposed=up, device=DEV)
+    wt = ws.transpose(0, 1).contiguous()
+    w32_fwd = conv.pack_weight_h8_f32(ws).to(DEV)
+    w32_bwd = conv.pack_weight_h8_f32(wt if up else torch.flip(wt, [2, 3])).to(DEV)
+    planes = K16.modulate_planes(w32_fwd, pad32(s))
+    xh = conv.to_h8(x, 32)
+    t = hc.forward(xh, planes=planes, w_bstride=planes[0].numel() * 2, out_scale=demod.contiguous())
+    bk = None
+    if up:
+        bk = T(P['m.blur.kernel']).to(DEV)
+        yh = K16.upfirdn2d(t, bk, pad=(1, 1, 1, 1), sep=K16.separable(P['m.blur.kernel']))
+    else:
+        yh = t
+    torch.cuda.synchronize()
+    want = T(g[name + '.y']).double()
+    y = conv.from_h8(yh, cout)
+    assert float((y.double().cpu() - want).abs().max()) < 2.0 ** -7 * float(want.abs().max())
+    gyh = conv.to_h8(gy, 32)
+    dt = K16.upfirdn2d(gyh, torch.flip(bk, [0, 1]).contiguous(), pad=(2, 2, 2, 2), sep=K16.separable(np.asarray(P['m.blur.kernel'])[::-1, ::-1])) if up else gyh
+    planes_b = K16.modulate_planes(w32_bwd, pad32(demod))
+    dxmod = hc.dgrad(dt, (x.shape[2], x.shape[3]), planes=planes_b, w_bstride=planes_b[0].numel() * 2)
+    gx = conv.from_h8(dxmod, cin) * s[:, :, None, None]
+    want = T(g[name + '.gx']).double()
+    assert float((gx.double().cpu() - want).abs().max()) < 2.0 ** -7 * float(want.abs().max())
+    q = K16.dot_reduce(dxmod, conv.to_h8(x, 8))[:, :cin]               # (maps of equal channel-group count)
+    red = K16.dot_reduce(conv.to_h8(gy, 8), yh)[:, :cout]
+    ds = q - s * ((red * demod * demod) @ Tm)
+    gw = (ds @ mod.A).double().cpu()
+    want = T(g[name + '.gw']).double()
+    assert float((gw - want).abs().max()) < 2.0 ** -6 * float(want.abs().max()), float((gw - want).abs().max()) / float(want.abs().max())

@@ -1089,3 +1089,91 @@ def test_hipgraph_replays_back_to_back_without_host_sync():
     finally:
         constants.resolution, constants.BATCH_SIZE = 256, 4
 
+
+
+# ---- [r6] the reference's ModulatedConv2d / StyledConv / ToRGB layer fixtures (tests/golden/modconv.npz, networks.py:176-358) on the HIP kernels ------
+# The generator tests above pin whole images; these pin ONE layer each, with the call sequence generator._SynthesisFn uses for it (style-scaled input,
+# demodulation as the conv's out_scale, blur + noise + bias + leaky ReLU in the FIR epilogue, the input gradient with the demodulation as in_scale, the
+# style gradient from the pixel reductions), so a kernel regression is localised to a layer instead of showing up as a wrong 1024^2 image.
+def _modconv_case(g, name):
+    import math
+    from latent2im_amd.generator import _Mod
+    P = {'m.' + k[len(name) + 3:]: g[k] for k in g.files if k.startswith(name + '.P.')}
+    W = T(P['m.weight'])[0]
+    cout, cin, k, _ = W.shape
+    ws = W * (1.0 / math.sqrt(cin * k * k))
+    mod = _Mod(P, 'm', DEV)
+    x, w, gy = (T(g['%s.%s' % (name, n)]).float().to(DEV) for n in ('x', 'w', 'gy'))
+    return P, ws, mod, x, w, gy
+
+
+@pytest.mark.parametrize('name,up', [('same', False), ('up', True), ('same512', False), ('up512', True)])
+def test_modulated_conv_layer_fixture(golden, precision, name, up):
+    """ModulatedConv2d with demodulation (networks.py:231-272), plain and upsampling: y, d y / d x and d y / d style against the reference's own
+    autograd on its own module, through FrozenConv2d.forward(in_scale, out_scale) / the blur FIR / FrozenConv2d.dgrad(in_scale) / dot_reduce."""
+    from latent2im_amd import conv as C, kernels as K
+    g = golden('modconv')
+    P, ws, mod, x, w, gy = _modconv_case(g, name)
+    s = mod(w)                                                                          # [B, Cin]
+    Tm = (ws * ws).sum((2, 3)).to(DEV)                                                  # [Cout, Cin]
+    demod = torch.rsqrt((s * s) @ Tm.t() + 1e-8)
+    cv = C.FrozenConv2d(ws, stride=2 if up else 1, padding=0 if up else 1, transposed=up, device=DEV)
+    t = cv.forward(x, in_scale=s.contiguous(), out_scale=demod.contiguous())
+    if up:
+        bk = T(P['m.blur.kernel']).to(DEV)
+        y = K.upfirdn2d(t, bk, pad=(1, 1, 1, 1))
+    else:
+        y = t
+    close(y, g[name + '.y'], 2e-4, 2e-5)
+    # backward, in the order generator._SynthesisFn.backward runs it
+    dt = K.upfirdn2d(gy, torch.flip(bk, [0, 1]).contiguous(), pad=(2, 2, 2, 2)) if up else gy
+    dxmod = cv.dgrad(dt.contiguous(), (x.shape[2], x.shape[3]), in_scale=demod.contiguous())        # gradient w.r.t. x * s
+    close(dxmod * s[:, :, None, None], g[name + '.gx'], 2e-4, 2e-5)
+    q = K.dot_reduce(dxmod, x)                                                          # sum_p dxmod * x: the style gradient through the modulated input
+    red = K.dot_reduce(gy, y)                                                           # sum_p gy * y = demod * d demod
+    ds = q - s * ((red * demod * demod) @ Tm)                                           # (+ through demod = rsqrt(s^2 T + eps))
+    close(ds @ mod.A, g[name + '.gw'], 2e-4, 2e-4)
+
+
+def test_to_rgb_and_styled_conv_layer_fixtures(golden, precision):
+    """ToRGB (1x1 modulated conv without demodulation + bias + up-sampled skip, networks.py:339-358) forward and backward, the bare 1x1 modulated conv
+    fixture ('rgb'), and StyledConv (networks.py:302-336: up-sampling modulated conv, blur, explicit noise with weight 0.7, bias, fused leaky ReLU) forward,
+    through l2i_torgb_fwd / the up-2 FIR with the addend / l2i_sg2_act_bwd's ToRGB branch and the FIR epilogue."""
+    import math
+    from latent2im_amd import conv as C, kernels as K
+    from latent2im_amd.generator import _Mod, _StyledLayer, _ToRGB
+    g = golden('modconv')
+    # (1) bare 1x1 modulated conv, demodulate=False
+    P, ws, mod, x, w, gy = _modconv_case(g, 'rgb')
+    s = mod(w)
+    # (a 9 x 9 map: l2i_torgb_fwd / l2i_sg2_act_bwd take whole 4-pixel groups — every map of the generator is a power of two — so this fixture runs
+    # on the generic conv kernels: 1x1, style as in_scale, three output channels)
+    cv = C.FrozenConv2d(ws, stride=1, padding=0, device=DEV)
+    close(cv.forward(x, in_scale=s.contiguous()), g['rgb.y'], 2e-4, 2e-5)
+    dxmod = cv.dgrad(gy.contiguous(), (x.shape[2], x.shape[3]))
+    close(dxmod * s[:, :, None, None], g['rgb.gx'], 2e-4, 2e-5)
+    close(K.dot_reduce(dxmod, x) @ mod.A, g['rgb.gw'], 2e-4, 2e-4)
+    SQ2 = math.sqrt(2.0)
+    # (2) ToRGB with skip
+    Pt = {'t.' + k[len('torgb.P.'):]: g[k] for k in g.files if k.startswith('torgb.P.')}
+    R = _ToRGB(Pt, 't', 8, True, DEV)
+    x, w, skip, gy = (T(g['torgb.' + n]).float().to(DEV) for n in ('x', 'w', 'skip', 'gy'))
+    s = R.mod(w)
+    wmod = (R.W[None] * s[:, None, :]).contiguous()
+    rgb = K.torgb_fwd(x, wmod, R.bias)
+    y = K.upfirdn2d(skip, R.up_k, up=(2, 2), pad=(2, 1, 2, 1), addend=rgb)
+    close(y, g['torgb.y'], 2e-4, 2e-5)
+    close(K.upfirdn2d(gy, R.up_k_flip, up=(1, 1), down=(2, 2), pad=(1, 1, 1, 1)), g['torgb.gskip'], 2e-4, 2e-5)
+    dz, _, red = K.sg2_act_bwd(x, None, None, gy, wmod, torch.zeros(8, device=DEV), None, 0.0, 0.2, SQ2)
+    close(dz / torch.where(x > 0, SQ2, 0.2 * SQ2), g['torgb.gx'], 2e-4, 2e-5)
+    close(((red * R.W.t()[None]).sum(2)) @ R.mod.A, g['torgb.gw'], 2e-4, 2e-4)
+    # (3) StyledConv, upsample=True, explicit noise
+    Ps = {'s.' + k[len('styled.P.'):]: g[k] for k in g.files if k.startswith('styled.P.')}
+    L = _StyledLayer(Ps, 's', 8, 6, True, DEV)
+    x, w, nz = (T(g['styled.' + n]).float().to(DEV) for n in ('x', 'w', 'noise'))
+    s = L.mod(w)
+    demod = torch.rsqrt((s * s) @ L.T.t() + 1e-8)
+    t = L.conv.forward(x, in_scale=s.contiguous(), out_scale=demod.contiguous())
+    y = K.upfirdn2d(t, L.blur_k, pad=(1, 1, 1, 1), noise=nz.contiguous(), noise_w=L.noise_w, bias=L.bias, act=K.ACT_LRELU, slope=0.2, gain=SQ2)
+    assert abs(L.noise_w - 0.7) < 1e-6
+    close(y, g['styled.y'], 2e-4, 2e-5)
