@@ -465,8 +465,10 @@ def main():
     ap.add_argument('--no_kernel_events', action='store_true', help='do not bracket conv launches with events')
     ap.add_argument('--event_steps', type=int, default=5, help='steps of the per-launch event pass (roofline)')
     ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16', 'f16'],
-                    help="f32: exact fp32 MFMA, fp32 storage (c3 default); bf16: the 16-bit path — bf16 h8 storage, one bf16 MFMA per MAC, fp32 accumulation (c5 "
-                         "default); bf16x3: fp32 storage, 3-term bf16 split on the matrix cores (fp32-class results)")
+                    help="f32: exact fp32 MFMA, fp32 storage (c3 default); f16: the 16-bit path with IEEE fp16 h8 storage, one fp16 MFMA per MAC, fp32 accumulation, "
+                         "scaled gradients with a device-side overflow guard (c5 default since round 5); bf16: the same path with bfloat16 elements (c5 default of "
+                         "rounds 3-4: profiles/r03_*, r04_* `config5` / `reg_only.bf16` keys are bf16 numbers); bf16x3: fp32 storage, 3-term bf16 split on the "
+                         "matrix cores (fp32-class results)")
     ap.add_argument('--hip_graph', type=int, default=None, help='1: replay forward+backward from one hipGraph (c5 default), 0: eager launches')
     ap.add_argument('--no_config5', action='store_true', help='skip the `config5` block (c5 workload, 16-bit path, hipGraph) of a c3 run')
     ap.add_argument('--config5_steps', type=int, default=10)
@@ -506,6 +508,7 @@ def main():
     rk, world, local = dist.init_from_env()
     if a.gpus != world:
         raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    ranks = dist.assert_distinct_devices()          # N ranks over RCCL = N distinct physical GPUs (host + PCI address), checked before any work; reported as ranks_seen
     assert torch.cuda.is_available(), 'bench.py needs the MI355X'
     dev = torch.device('cuda', torch.cuda.current_device())
     sens_idx = local
@@ -532,7 +535,6 @@ def main():
     per_rank_ms = [round(t / a.steps * 1e3, 3) for t in dist.gather_floats(elapsed)]
     elapsed = dist.max_over_ranks(elapsed, dev)
     loss_value = float(r['loss'])
-    ranks = dist.ranks_seen()
     wgrad = next(iter(wl.g.walk.parameters()))
     allreduce_us = dist.time_allreduce(wgrad.detach())
     allreduce_note = ('median of 100 synchronised all-reduces of a walk-gradient-shaped tensor (%d bytes) over the %s process group'

@@ -96,7 +96,7 @@ typedef struct l2i_conv_params {
     /* ---- ABI version 5: fp32 <-> 16-bit boundaries of the 16-bit path without a cast pass (see also l2i_conv_img_h8) ------------------------- */
     int32_t in_h8;          /* l2i_conv_transpose2d_f32, 7x7 / pad 3 onto <= 3 channels (the ResNet stem's input gradient): 1 / 2 = x and in_mask are      */
                             /* bf16 / fp16 h8 tensors [B, Cin/8, H, W, 8] (Cin % 8 == 0)                                                                  */
-    const float* rgb_w;     /* l2i_conv2d_h8 with the h8 output and every output channel in one block (Cout <= 64): not NULL = the launch also writes the   */
+    const float* rgb_w;     /* l2i_conv2d_h8 with the h8 output and every output channel in one block (Cout = 32 or 64): not NULL = the launch also writes the   */
     const float* rgb_bias;  /* ToRGB image of its output, rgb_out[b, o, oy, ox] = rgb_bias[o] + sum_c rgb_w[b, o, c] * epi(.)[b, c, oy, ox] (o < 3; fp32     */
     float* rgb_out;         /* NCHW [B, 3, OHf, OWf]; networks.py:349-358 on the 512^2 / 1024^2 StyledConv outputs), instead of a pass that re-reads y        */
     float* pool_out;        /* l2i_conv2d_wino4_f32 (position-split kernel, dense output with even OHf, OWf % 4 == 0, zero output offsets): not NULL = the launch    */

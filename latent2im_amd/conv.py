@@ -780,7 +780,7 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
         p.sq_ref, p.sq_out = _lib.ptr(sq[0]), _lib.fptr(sq[1])
         sq[2][0] = True
     if rgb is not None:                                           # [r5] (wmod [B, 3, Cout], bias [3], out [B, 3, OHf, OWf]) fp32: ToRGB of the output in the epilogue (l2i.h: rgb_w)
-        assert not transposed and not out_f32 and cout <= 64 and tuple(rgb[0].shape) == (B, 3, cout) and tuple(rgb[2].shape) == (B, 3, OHf, OWf)
+        assert not transposed and not out_f32 and cout in (32, 64) and tuple(rgb[0].shape) == (B, 3, cout) and tuple(rgb[2].shape) == (B, 3, OHf, OWf)
         p.rgb_w, p.rgb_bias, p.rgb_out = _lib.fptr(rgb[0]), _lib.fptr(rgb[1]), _lib.fptr(rgb[2])
     name = ('l2i_conv_transpose2d_h8' if transposed else 'l2i_conv2d_h8') + ('_f16' if f16 else '')
     entry = getattr(lib, name)

@@ -222,6 +222,12 @@ __device__ __forceinline__ void h8_gather(const f32x16& a, int pr, int half, flo
 // blocks hide more of that than a deeper pipeline in two.  Also measured, no effect (inside +-1 %): the same wave roles at four blocks per CU (two tile
 // stages: a tile wave waits for its tile only at the chunk's first phase, a weight wave never behind a tile), starting the four first-generation
 // blocks of a CU a quarter of a block time apart (s_sleep sweep 0 ... 12 x 2048 cycles per slot), and removing every barrier (timing only).
+// [r6] Measured, not kept (profiles/r06_h8_deep_ring_ab.txt): a DEEP ring for the mid-size launches (<= 2048 blocks: ResNet-50's layers at batch 8, the <= 64^2
+// layers of G / D: 35 - 80 us per launch whatever their work) — four weight stages requested three phases ahead, three tile stages two chunks ahead, one counted
+// vmcnt per head, null-descriptor tail, two blocks per CU.  Element-exact, and 0 - 15 % SLOWER on the 3x3 shapes, up to 1.8x slower on the >= 1024-block 1x1s; only the
+// 256-block 1x1s gain (38 -> 31 us).  The ablations of the same shapes say why: with no DMA at all 256 -> 256 @64^2 still takes 31 of 38 us (15 us of matrix time),
+// with no MFMA 28 — at one to two waves per SIMD the parts of a block add, and prefetch depth removes none of them.
+// Also measured on those shapes, no gain: 4-row tiles (WN = 1: twice the blocks; 128 -> 128 @128^2 41.0 -> 44.6 us, 256 -> 256 @64^2 42.5 -> 42.9) and 32-channel chunks.
 // Finer ablations of the no-DMA / no-MFMA / no-store skeleton (profiles/r03_h8_conv3x3_timing_ablations.txt): the epilogue is 0.25 ms of the
 // 0.83 ms launch (0.12 of it the stores), the fragment reads + barriers of the K loop another 0.2.
 // What all of these have in common (tools/probes/h8_clocks.sh, profiles/r03_h8_power_clocks.txt): while this kernel runs the package sits AT its
@@ -646,8 +652,11 @@ static int launch_h8(const l2i_conv_params& p, hipStream_t st) {
     L.lean_epi = lean ? 1 : 0;
     const bool extra = CAN_EXTRA && lean && (p.rgb_w || p.sq_ref);
     L.rgb = p.rgb_w ? 1 : 0;
-    if (L.rgb && !(extra && L.mblocks == 1 && p.rgb_bias && p.rgb_out && (p.Cout % 8) == 0 && (((uintptr_t)p.rgb_w) % 16) == 0))
-        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: rgb_w needs a 3x3 stride-1 launch on the lean h8 epilogue (no per-pixel operand maps), every output channel in one block (Cout <= 64), rgb_bias / rgb_out, a 16-byte aligned rgb_w");
+    // (Cout % 32: the epilogue fetches the eight rgb_w values of EVERY channel group of the block's 32- / 64-channel tile before it masks the groups
+    //  past Cout — with Cout = 40 or 48 those loads would run past the sample's row, and past the buffer for the last sample; the generator's layers
+    //  have 32 and 64 channels)
+    if (L.rgb && !(extra && L.mblocks == 1 && p.rgb_bias && p.rgb_out && (p.Cout % 32) == 0 && (((uintptr_t)p.rgb_w) % 16) == 0))
+        return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: rgb_w needs a 3x3 stride-1 launch on the lean h8 epilogue (no per-pixel operand maps), every output channel in one block (Cout = 32 or 64), rgb_bias / rgb_out, a 16-byte aligned rgb_w");
     size_t lds = (size_t)(2 * G::IN_STAGE + 2 * WSLOTS) * 16;
     if (OUT32 && lds < 4 * 32 * 64 * sizeof(float)) lds = 4 * 32 * 64 * sizeof(float);
     if (lds > 160 * 1024) return l2i_set_error(L2I_E_UNSUPPORTED, "conv2d_h8: tile does not fit the LDS");

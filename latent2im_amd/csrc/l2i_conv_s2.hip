@@ -66,7 +66,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3s2_dma_kernel(const l2i_conv_pa
     const unsigned plane_b = (unsigned)((size_t)p.H * p.W * sizeof(float));
     const size_t smp = (size_t)b * p.Cin * ((size_t)p.H * p.W);
     const unsigned wrow_b = (unsigned)p.CoutP * 4u;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + smp), 0, (unsigned)p.Cin * plane_b, 0x00020000);
+    // [r6] The second input slot rides on the first one's M0 with an instruction immediate of 2048, which moves the LDS target AND the global address:
+    // its register offset must carry -2048.  Round 5 subtracted it from the byte offset itself, so a pixel in the first 2 KB of a sample had a
+    // "negative" (wrapped) voffset and relied on the hardware adding voffset + immediate modulo 2^32 before its range check.  Now the descriptor
+    // starts 2048 bytes BEFORE the sample (never dereferenced there: every offset is built from an in-image pixel) and is 2048 bytes longer; every
+    // register offset is byte + 2048 - immediate >= 0.
+    constexpr unsigned XSHIFT = 2048u;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(p.x + smp) - XSHIFT), 0, (unsigned)p.Cin * plane_b + XSHIFT, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.Cin * 9u * wrow_b, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0u, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3s2_dma_kernel(const l2i_conv_pa
         const int iy = e / IWG, ig = e - iy * IWG;
         const int gy = iy0 + iy, gx = gx0 + 4 * ig;
         const bool ok = (e < NGRP) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
-        voff[u] = ok ? (unsigned)(gy * p.W + gx) * 4u - (u == 1 ? 2048u : 0u) : OOB;        // (slot u = 1 rides on slot 0's M0 with an immediate of 2048)
+        voff[u] = ok ? (unsigned)(gy * p.W + gx) * 4u + (u == 1 ? 0u : XSHIFT) : OOB;        // (slot u = 1 rides on slot 0's M0 with an immediate of 2048)
     }
     // weights: 288 16-byte pieces [c][tap][16] of the chunk: wave w takes pieces 64 w .., wave 0 also 256 .. 287
     unsigned wvoff[2];

@@ -122,6 +122,11 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
     // DMAIN: element e = 64 s + lane of a dense [IH][IW] channel plane -> byte offset inside the plane (minus the slot's immediate), or out of range
     constexpr int NSL = 6;
     unsigned dvoff[DMAIN ? NSL : 1];
+    // [r6] slot s of a plane rides on the plane's M0 with an immediate of 256 s (LDS target and global address alike), so its register offset carries
+    // -256 s.  To keep every register offset non-negative (round 5 let the first pixels of a sample wrap below zero and relied on voffset + immediate
+    // being added modulo 2^32 before the range check) the DMA's descriptor starts DSHIFT bytes before the sample group and is DSHIFT bytes longer.
+    constexpr unsigned DSHIFT = (NSL - 1) * 256u;
+    const __amdgpu_buffer_rsrc_t rs_xd = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(p.x + grp_off) - DSHIFT), 0, in_bytes + DSHIFT, 0x00020000);
     if constexpr (DMAIN) {
 #pragma unroll
         for (int s_ = 0; s_ < NSL; ++s_) {
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
             const unsigned row = fast_div_t(e, L.magic_iw), ixu = e - row * L.IW;
             const int gy = iy0 + (int)row, gx = ix0 + (int)ixu;
             const bool ok = (s_ < L.nslots) & ((int)row < L.IH) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
-            dvoff[s_] = ok ? (unsigned)(gy * p.W + gx) * 4u - (unsigned)s_ * 256u : 0x80000000u;
+            dvoff[s_] = ok ? (unsigned)(gy * p.W + gx) * 4u + (DSHIFT - (unsigned)s_ * 256u) : 0x80000000u;      // >= 0: rs_xd starts DSHIFT bytes early
         }
     }
 #pragma unroll
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
         }
     };
     // DMAIN: the input tile of a chunk: wave w takes channel planes w, w + 4, ...; one M0 per plane, its slots by immediate offsets (the immediate
-    // moves the LDS target and the global address alike: dvoff carries -256 s).  Idle lanes / slots past the plane write zeros into its padding.
+    // moves the LDS target and the global address alike: dvoff carries DSHIFT - 256 s against a descriptor that starts DSHIFT bytes early).  Idle lanes / slots past the plane write zeros into its padding.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto dma_in = [&](int c0, int st) {
         if constexpr (DMAIN) {
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256, WN == 1 ? 3 : 2) void convt_mfma_kernel(const 
                              "buffer_load_dword %3, %7, %8 offen offset:768 lds\n\t"
                              "buffer_load_dword %4, %7, %8 offen offset:1024 lds\n\t"
                              "buffer_load_dword %5, %7, %8 offen offset:1280 lds"
-                             :: "v"(dvoff[0]), "v"(dvoff[1]), "v"(dvoff[2]), "v"(dvoff[3]), "v"(dvoff[4]), "v"(dvoff[DMAIN ? 5 : 0]), "s"(base), "s"(rs_x), "s"(so) : "memory");
+                             :: "v"(dvoff[0]), "v"(dvoff[1]), "v"(dvoff[2]), "v"(dvoff[3]), "v"(dvoff[4]), "v"(dvoff[DMAIN ? 5 : 0]), "s"(base), "s"(rs_xd), "s"(so) : "memory");
             }
         }
     };

@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256, (MASK || NOPS > 0) ? 2 : 3) void gemm1x1_kerne
         }
     } else {
         // operand slots in canonical order; the host guarantees that at most NOPS exist
-        const float* cand[5] = {p.out_mask, p.residual, p.res_sub, p.res_mask, p.accumulate ? p.y : nullptr};
+        // ([r6] res_mask == out_mask — the ReLU mask of a bottleneck's input on both terms of its input gradient, regressor.py — is ONE operand: one fetch)
+        const bool rm_is_om = p.res_mask && p.res_mask == p.out_mask;
+        const float* cand[5] = {p.out_mask, p.residual, p.res_sub, rm_is_om ? nullptr : p.res_mask, p.accumulate ? p.y : nullptr};
         int slot[5];
         const float* sp0 = nullptr;
         const float* sp1 = nullptr;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256, (MASK || NOPS > 0) ? 2 : 3) void gemm1x1_kerne
             if (slot[c] == 0) sp0 = cand[c];
             if (slot[c] == 1) sp1 = cand[c];
         }
-        const int s_om = slot[0], s_rv = slot[1], s_sb = slot[2], s_rm = slot[3], s_yo = slot[4];
+        const int s_om = slot[0], s_rv = slot[1], s_sb = slot[2], s_rm = rm_is_om ? slot[0] : slot[3], s_yo = slot[4];
         struct Ops { float4 s[NOPS][4]; };
         auto fetch = [&](int g, Ops& o) {                  // group g = channel rows ((g & 1) * 4 + i) * 4 + ch_l of channel block g >> 1
 #pragma unroll
@@ -260,8 +262,8 @@ int l2i_launch_gemm1x1(const l2i_conv_params& p, hipStream_t st) {
     const bool mask = p.in_mask != nullptr;
     const size_t lds = (size_t)2 * (gm::CK * gm::BN * (mask ? 2 : 1) + gm::CK * BM) * sizeof(float);
     // epilogue operands that are read from global memory: up to two are prefetched (NOPS), otherwise the plain loop
-    int nops = (p.out_mask ? 1 : 0) + (p.residual ? 1 : 0) + (p.res_sub ? 1 : 0) + (p.res_mask ? 1 : 0) + (p.accumulate ? 1 : 0);
-    if (nops > 2 || (!mask && nops > 1)) nops = 0;
+    int nops = (p.out_mask ? 1 : 0) + (p.residual ? 1 : 0) + (p.res_sub ? 1 : 0) + ((p.res_mask && p.res_mask != p.out_mask) ? 1 : 0) + (p.accumulate ? 1 : 0);
+    if (nops > 2) nops = 0;
     const dim3 g(grid), t(256);
 #define L2I_GEMM_LAUNCH(WM_, MASK_, NOPS_)                                                                                              \
     do {                                                                                                                                \
@@ -272,10 +274,10 @@ int l2i_launch_gemm1x1(const l2i_conv_params& p, hipStream_t st) {
     } while (0)
     if (wide) {
         if (mask) { if (nops == 2) L2I_GEMM_LAUNCH(4, true, 2); else if (nops == 1) L2I_GEMM_LAUNCH(4, true, 1); else L2I_GEMM_LAUNCH(4, true, 0); }
-        else { if (nops == 1) L2I_GEMM_LAUNCH(4, false, 1); else L2I_GEMM_LAUNCH(4, false, 0); }
+        else { if (nops == 2) L2I_GEMM_LAUNCH(4, false, 2); else if (nops == 1) L2I_GEMM_LAUNCH(4, false, 1); else L2I_GEMM_LAUNCH(4, false, 0); }
     } else {
         if (mask) { if (nops == 2) L2I_GEMM_LAUNCH(2, true, 2); else if (nops == 1) L2I_GEMM_LAUNCH(2, true, 1); else L2I_GEMM_LAUNCH(2, true, 0); }
-        else { if (nops == 1) L2I_GEMM_LAUNCH(2, false, 1); else L2I_GEMM_LAUNCH(2, false, 0); }
+        else { if (nops == 2) L2I_GEMM_LAUNCH(2, false, 2); else if (nops == 1) L2I_GEMM_LAUNCH(2, false, 1); else L2I_GEMM_LAUNCH(2, false, 0); }
     }
 #undef L2I_GEMM_LAUNCH
     L2I_CHECK_LAUNCH();

@@ -199,11 +199,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const l2i_conv_param
     const unsigned in_bytes = (unsigned)p.Cin * plane_b;
     const size_t smp = (size_t)b * p.Cin * ((size_t)p.H * p.W);
     const unsigned uchunk_b = (unsigned)(p.CoutP / BM) * (unsigned)(UST * sizeof(float));            // bytes of one 4-channel chunk of the weight pack
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + smp), 0, in_bytes, 0x00020000);
+    constexpr unsigned XSHIFT = (NSL - 2) * 1024u;     // [r6] the descriptor starts this far before the sample: every register offset below stays >= 0
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(p.x + smp) - XSHIFT), 0, in_bytes + XSHIFT, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)(p.Cin / CK) * uchunk_b, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0u, 0x00020000);
     // element e = u * 256 + tid of the [18][66] plane -> byte offset in the channel plane.  Slots 0..3 of a channel go out in ONE statement with
-    // immediate offsets u * 1024 (the immediate moves the LDS target AND the global address: voff carries -u * 1024); out-of-image / past-the-plane
+    // immediate offsets u * 1024 (the immediate moves the LDS target AND the global address: voff carries XSHIFT - u * 1024 against a descriptor that
+    // starts XSHIFT bytes early); out-of-image / past-the-plane
     // elements use an offset that is out of range whatever is added to it (one sample stays below 2 GiB: checked at launch) = zeros.
     constexpr unsigned OOB = 0x80000000u;
     unsigned voff[NSL];
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const l2i_conv_param
         const int iy = e / IW, ix = e - iy * IW;
         const int gy = iy0 + iy, gx = ix0 + ix;
         const bool ok = (e < PLANE_E) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
-        voff[u] = ok ? (unsigned)(gy * p.W + gx) * 4u - (u < NSL - 1 ? (unsigned)u * 1024u : 0u) : OOB;
+        voff[u] = ok ? (unsigned)(gy * p.W + gx) * 4u + (XSHIFT - (u < NSL - 1 ? (unsigned)u * 1024u : 0u)) : OOB;
     }
     const unsigned wvoff = (unsigned)tid * 16u;        // U: the chunk image is copied linearly, 16 bytes per lane and slot
     const unsigned lds_raw = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)rawbuf;
@@ -601,18 +603,22 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     const unsigned in_bytes = (unsigned)p.Cin * plane_b;
     const size_t smp = (size_t)b * p.Cin * ((size_t)p.H * p.W);
     const unsigned uchunk_b = (unsigned)(p.CoutP / 16) * (unsigned)(UG * sizeof(float));
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + smp), 0, in_bytes, 0x00020000);
+    // [r6] raw slot u rides on slot 0's M0 with an immediate of 1024 u (LDS target and global address alike): its register offset carries -1024 u.  The
+    // descriptor starts XSHIFT bytes before the sample and is XSHIFT bytes longer, so that every register offset (byte + XSHIFT - 1024 u) is >= 0 — round 5
+    // let the first pixels of a sample wrap below zero and relied on voffset + immediate being added modulo 2^32 before the range check (round-5 advice).
+    constexpr unsigned XSHIFT = (NRS - 1) * 1024u;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(p.x + smp) - XSHIFT), 0, in_bytes + XSHIFT, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)(p.Cin / CK) * uchunk_b, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0u, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    unsigned voff[NRS];                                // group 64 u + lane of the [10][18] plane -> byte offset in the channel plane (minus the immediate)
+    unsigned voff[NRS];                                // group 64 u + lane of the [10][18] plane -> byte offset in the channel plane (+ XSHIFT - the immediate)
 #pragma unroll
     for (int u = 0; u < NRS; ++u) {
         const int e = (rsl + u) * 64 + lane;
         const int iy = e / IWG, ig = e - iy * IWG;
         const int gy = iy0 + iy, gx = ox0 - 4 + 4 * ig;
         const bool ok = (e < NGRP) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
-        voff[u] = ok ? (unsigned)(gy * p.W + gx) * 4u - (unsigned)u * 1024u : OOB;
+        voff[u] = ok ? (unsigned)(gy * p.W + gx) * 4u + (XSHIFT - (unsigned)u * 1024u) : OOB;
     }
     const unsigned wvoff = (unsigned)lane * 16u;
     const unsigned lds_raw = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)rawbuf;

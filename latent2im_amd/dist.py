@@ -173,16 +173,43 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def _device_identity():
+    """(device index, 'domain:bus:device' PCI address or None) of this rank's current GPU: the address is what tells two ranks on ONE physical GPU
+    apart from two ranks on two GPUs when each process sees its own device as index 0 (HIP_VISIBLE_DEVICES per rank)."""
+    if not torch.cuda.is_available():
+        return None, None
+    i = torch.cuda.current_device()
+    pr = torch.cuda.get_device_properties(i)
+    try:
+        pci = '%04x:%02x:%02x' % (int(getattr(pr, 'pci_domain_id', 0)), int(pr.pci_bus_id), int(pr.pci_device_id))
+    except (AttributeError, TypeError, ValueError):
+        pci = None
+    return i, pci
+
+
 def ranks_seen():
-    """[{rank, device, host}] of every rank (all_gather_object; one entry without a process group): self-reporting evidence of which
+    """[{rank, device, pci, host}] of every rank (all_gather_object; one entry without a process group): self-reporting evidence of which
     GPUs a multi-rank run really used."""
     import socket
-    me = dict(rank=rank(), device=torch.cuda.current_device() if torch.cuda.is_available() else None, host=socket.gethostname())
+    i, pci = _device_identity()
+    me = dict(rank=rank(), device=i, pci=pci, host=socket.gethostname())
     if not is_initialized():
         return [me]
     out = [None] * world_size()
     td.all_gather_object(out, me)
     return out
+
+
+def assert_distinct_devices(seen=None):
+    """Start-up check of a multi-rank run over RCCL: the N ranks sit on N DISTINCT physical GPUs (host + PCI address, falling back to the device
+    index) — two ranks time-slicing one GPU would still produce a line, with half the throughput and no hint why.  Rehearsals over gloo
+    (L2I_DIST_BACKEND=gloo: N ranks on a single-GPU box) are exempt.  Returns the gathered list."""
+    seen = ranks_seen() if seen is None else seen
+    if is_initialized() and td.get_backend() == 'nccl' and len(seen) > 1:
+        ids = [(r['host'], r['pci'] if r.get('pci') else r['device']) for r in seen]
+        if len(set(ids)) != len(ids):
+            raise RuntimeError('data-parallel run over RCCL with %d ranks on %d distinct GPUs: %s' % (len(ids), len(set(ids)), seen))
+    return seen
 
 
 def gather_floats(value):

@@ -180,8 +180,11 @@ class ModulatePlan:
     [B, Cin/16, KK, 2, CoutP, 8] per layer of one buffer."""
     BLOCK_SLOTS = 256 * 8                      # slots a block handles at most per pass of its grid-stride loop
 
-    def __init__(self, w32s, s_offsets, device):
+    def __init__(self, w32s, s_offsets, device, widths=None):
         self.shapes = [tuple(w.shape) for w in w32s]
+        if widths is not None:                   # rows of the scale buffer per layer: the kernel reads c16 * 16 scales per sample, like modulate_planes asserts
+            for w, n in zip(w32s, widths):
+                assert n == w.shape[0] * 16, 'scale row of %d entries for a weight plane set of %d padded input channels' % (n, w.shape[0] * 16)
         self.w32 = torch.cat([w.reshape(-1) for w in w32s]).contiguous().to(device)
         self.w_off = [0]
         for w in w32s[:-1]:

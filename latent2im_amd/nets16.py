@@ -459,8 +459,8 @@ class Generator(_Generator32):
         self.modplan = _ModPlan(self, device)
         self.mod_fwd = self.mod_bwd = None
         if MOD_MULTI:
-            self.mod_fwd = K16.ModulatePlan([L.w32_fwd for L in self.layers], self.modplan.s_off[:len(self.layers)], device)
-            self.mod_bwd = K16.ModulatePlan([L.w32_bwd for L in self.layers], self.modplan.d_off, device)
+            self.mod_fwd = K16.ModulatePlan([L.w32_fwd for L in self.layers], self.modplan.s_off[:len(self.layers)], device, widths=self.modplan.cin)
+            self.mod_bwd = K16.ModulatePlan([L.w32_bwd for L in self.layers], self.modplan.d_off, device, widths=self.modplan.cout)
 
     def synthesis(self, latent, noise=None):
         return _Synthesis16Fn.apply(latent, self, noise)
@@ -495,7 +495,7 @@ class _Synthesis16Fn(torch.autograd.Function):
             else:
                 has_rgb = li == 0 or li % 2 == 0
                 rgb = None
-                if has_rgb and RGB_FUSED and L.cout <= 64:                     # ToRGB in this conv's epilogue (the block holds every channel of its pixels)
+                if has_rgb and RGB_FUSED and L.cout in (32, 64):                     # ToRGB in this conv's epilogue (the block holds every channel of its pixels)
                     rgb = torch.empty(B, 3, res, res, device=dev, dtype=torch.float32)
                 y = L.conv.forward(x, planes=planes, w_bstride=bstride, out_scale=demod, noise=nz, noise_w=L.noise_w, bias=L.bias,
                                    rgb=None if rgb is None else (plan.wmod(w_all, B, li // 2), gen.rgbs[li // 2].bias, rgb), **lr)
@@ -506,7 +506,7 @@ class _Synthesis16Fn(torch.autograd.Function):
             if li == 0 or (li % 2 == 0):
                 R = gen.rgbs[li // 2]
                 wmod = plan.wmod(w_all, B, li // 2)
-                if L.up or not (RGB_FUSED and L.cout <= 64):
+                if L.up or not (RGB_FUSED and L.cout in (32, 64)):
                     rgb = K16.torgb_fwd(y, wmod, R.bias)                       # fp32 [B,3,H,W]: the skip image stays fp32
                 skip = K.upfirdn2d(skip, R.up_k, up=(2, 2), pad=(2, 1, 2, 1), addend=rgb) if R.up else rgb
                 rec['wmod'] = wmod

@@ -3,8 +3,8 @@
 Reference call sites: transform_base.py:522-528 (construction / checkpoint ``ckpt['model']``), :396-403 and :416-424
 (``regressor(img)[:, attrIdx]`` on the raw [-1,1] generator output, eval mode :267).  Eval-mode BatchNorm is an affine
 map, so it is folded into the preceding conv at construction; ReLU and the residual add live in the conv epilogue;
-the backward is input-gradient only, with every ReLU mask applied in the *prologue* of the next gradient conv
-(no standalone elementwise passes).
+the backward is input-gradient only, with every ReLU mask applied in the epilogue of the launch that produces the masked
+gradient or in the prologue of the one that consumes it (no standalone elementwise passes but the first mask).
 """
 
 import numpy as np
@@ -58,6 +58,31 @@ class ResNet50:
         return torch.addmm(self.fc_b, feat, self.fc_w.t())
 
 
+PREMASK = __import__('os').environ.get('L2I_R_PREMASK', '1') != '0'      # 0: the round-5 mask plumbing of the backward (A/B)
+
+
+def _backward_r5(net, saved, g):
+    """The round-5 form (L2I_R_PREMASK=0): g = the gradient w.r.t. a block's ReLU output; its mask rides on BOTH consumers of g."""
+    for blk, (y1, y2, out, in_hw) in zip(reversed(net.blocks), reversed(saved['blocks'])):
+        pre = blk['c2'].conv.stride == 1
+        g_y2 = blk['c3'].conv.dgrad(g, (y2.shape[2], y2.shape[3]), in_mask=out, mask=(1.0, 0.0), **(dict(out_mask=y2) if pre else {}))
+        if pre:
+            g_y1 = blk['c2'].conv.dgrad(g_y2, (y1.shape[2], y1.shape[3]), out_mask=y1)
+            m1 = {}
+        else:
+            g_y1 = blk['c2'].conv.dgrad(g_y2, (y1.shape[2], y1.shape[3]), in_mask=y2, mask=(1.0, 0.0))
+            m1 = dict(in_mask=y1, mask=(1.0, 0.0))
+        if blk['down'] is None:
+            g_in = blk['c1'].conv.dgrad(g_y1, in_hw, residual=g, res_mask=out, **m1)
+        else:
+            g_in = blk['c1'].conv.dgrad(g_y1, in_hw, **m1)
+            blk['down'].conv.dgrad(g, in_hw, out=g_in, in_mask=out, mask=(1.0, 0.0), accumulate=True)
+        g = g_in
+    a0 = saved['a0']
+    g_a0 = K.maxpool2d_bwd(g, saved['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1)
+    return net.stem.conv.dgrad(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0))
+
+
 class _ResNetFeatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, net):
@@ -90,26 +115,45 @@ class _ResNetFeatFn(torch.autograd.Function):
             raise RuntimeError('regressor was run without a differentiable input')
         b, c, h, w = ctx.last_shape
         g = (g_feat * (1.0 / (h * w))).reshape(b, c, 1, 1).expand(b, c, h, w).contiguous()
-        for blk, (y1, y2, out, in_hw) in zip(reversed(net.blocks), reversed(saved['blocks'])):
-            # out = relu(c3(y2) + idt): the relu mask of `out` rides on every consumer of g.  [r4] The masks of y2 / y1 are applied by the PRODUCING
-            # launch's epilogue (out_mask: a select on values it holds in registers) instead of the consuming launch's prologue (in_mask): the
-            # same numbers, and the 3x3 gradient conv becomes an unmasked launch — the F(4x4,3x3) Winograd kernel (csrc/l2i_wino4.hip) and the
-            # unmasked transposed instantiation take those
+        blocks = saved['blocks']
+        # [r6] G = the gradient w.r.t. the PRE-ReLU sum of a block (out = relu(c3(y2) + idt)): the ReLU mask of the block input (the previous block's
+        # `out`, the 4x-wide map) is applied ONCE, by the launch that produces the block-input gradient (out_mask / res_mask = the same tensor: one
+        # operand fetch in the 1x1 GEMM's epilogue), instead of twice by the two consumers of g (round 5: in_mask = out on c3's gradient GEMM — a
+        # second DMA stream and 3 VALU per fragment in its K loop — and res_mask = out on c1's): one read of every wide map less per block (3.7 GB per
+        # 1024^2 batch-8 step) and c3's gradient conv becomes the unmasked GEMM.  The 16-bit path has always done this (nets16._ResNet16Fn).
+        if not PREMASK:
+            return _backward_r5(net, saved, g), None
+        G = K.relu_mask(g, blocks[-1][2])
+        del g
+        for bi in range(len(net.blocks) - 1, -1, -1):
+            blk, (y1, y2, out, in_hw) = net.blocks[bi], blocks[bi]
+            m = blocks[bi - 1][2] if bi > 0 else None          # the block input is the previous block's ReLU output (the pooled stem map is not)
+            mk = dict(out_mask=m) if m is not None else {}
+            # [r4] The masks of y2 / y1 are applied by the PRODUCING launch's epilogue (out_mask: a select on values it holds in registers) instead
+            # of the consuming launch's prologue (in_mask): the same numbers, and the 3x3 gradient conv becomes an unmasked launch — the F(4x4,3x3)
+            # Winograd kernel (csrc/l2i_wino4.hip) and the unmasked transposed instantiation take those
             # (the three stride-2 blocks keep the prologue masks: their c2 gradient is the one-launch transposed kernel, which fuses in_mask only)
             pre = blk['c2'].conv.stride == 1
-            g_y2 = blk['c3'].conv.dgrad(g, (y2.shape[2], y2.shape[3]), in_mask=out, mask=(1.0, 0.0), **(dict(out_mask=y2) if pre else {}))
+            g_y2 = blk['c3'].conv.dgrad(G, (y2.shape[2], y2.shape[3]), **(dict(out_mask=y2) if pre else {}))
             if pre:
                 g_y1 = blk['c2'].conv.dgrad(g_y2, (y1.shape[2], y1.shape[3]), out_mask=y1)
                 m1 = {}
             else:
                 g_y1 = blk['c2'].conv.dgrad(g_y2, (y1.shape[2], y1.shape[3]), in_mask=y2, mask=(1.0, 0.0))
                 m1 = dict(in_mask=y1, mask=(1.0, 0.0))
+            del g_y2
             if blk['down'] is None:
-                g_in = blk['c1'].conv.dgrad(g_y1, in_hw, residual=g, res_mask=out, **m1)
+                Gp = blk['c1'].conv.dgrad(g_y1, in_hw, residual=G, **(dict(out_mask=m, res_mask=m) if m is not None else {}), **m1)
+            elif blk['down'].conv.stride == 1:
+                t = blk['c1'].conv.dgrad(g_y1, in_hw, **m1)
+                Gp = blk['down'].conv.dgrad(G, in_hw, residual=t, **(dict(out_mask=m, res_mask=m) if m is not None else {}))
+                del t
             else:
-                g_in = blk['c1'].conv.dgrad(g_y1, in_hw, **m1)
-                blk['down'].conv.dgrad(g, in_hw, out=g_in, in_mask=out, mask=(1.0, 0.0), accumulate=True)
-            g = g_in
+                Gp = blk['c1'].conv.dgrad(g_y1, in_hw, **mk, **m1)
+                blk['down'].conv.dgrad(G, in_hw, out=Gp, accumulate=True, **mk)      # strided 1x1: lands on every second pixel, masked there
+            del g_y1
+            G = Gp
+        g = G
         a0 = saved['a0']
         g_a0 = K.maxpool2d_bwd(g, saved['idx0'], (a0.shape[2], a0.shape[3]), 3, 2, 1)
         g_img = net.stem.conv.dgrad(g_a0, saved['in_hw'], in_mask=a0, mask=(1.0, 0.0))

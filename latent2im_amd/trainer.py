@@ -148,6 +148,7 @@ def main(multi_attr=False, argv=None):
     opt = TrainOptions().parse(print_opt=(int(os.environ.get('RANK', '0')) == 0), argv=argv)
     dist.select_gpu(opt.gpu)                         # train.py:150 — before the first torch.cuda call (init_from_env makes it)
     rk, world, local = dist.init_from_env()
+    dist.assert_distinct_devices()                   # N ranks over RCCL must sit on N distinct physical GPUs
     if opt.synthetic_weights:
         constants.ALLOW_SYNTHETIC_WEIGHTS = True
     if opt.precision:

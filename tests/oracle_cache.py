@@ -45,6 +45,29 @@ CASES = {
 ATTR_IDX = {'Smiling': 31, 'Young': 39, 'Male': 20, 'Eyeglasses': 15, 'Bangs': 5}
 
 
+ORACLE_SOURCES = ('oracle/__init__.py', 'oracle/step.py', 'oracle/sg2.py', 'oracle/nets.py', 'latent2im_amd/synth.py', 'latent2im_amd/specs.py')
+
+
+def case_fingerprint(name):
+    """sha256[:16] over everything a cached case is a function of: the oracle sources `evaluate` runs (ORACLE_SOURCES), the case's spec (size, batch,
+    attributes, seeds, flow, dtype) and its alpha values.  Stored per case as `<name>.meta_sha` when the cache is written; tests/test_oracle_cache_cpu.py
+    fails when a committed entry no longer matches — a change to the oracle that only moves the float64 / scene / clamp cases would otherwise leave the
+    GPU tests comparing against stale constants (round-5 advice)."""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for rel in ORACLE_SOURCES:
+        h.update(rel.encode())
+        with open(os.path.join(root, rel), 'rb') as f:
+            h.update(f.read())
+    c = CASES[name]
+    h.update(repr(sorted((k, v) for k, v in c.items() if k != 'alpha')).encode())
+    h.update(np.ascontiguousarray(c['alpha'](), dtype=np.float64).tobytes())
+    h.update(repr((NPROBE, sorted(ATTR_IDX.items()))).encode())
+    return h.hexdigest()[:16]
+
+
 def probe_positions(size):
     """4096 distinct flat pixel positions of a size x size image (the same for every sample and channel)."""
     return np.sort(np.random.RandomState(size).choice(size * size, NPROBE, replace=False))
@@ -110,6 +133,7 @@ class Cached:
     def __init__(self, npz, name):
         self.d = {k[len(name) + 1:]: npz[k] for k in npz.files if k.startswith(name + '.')}
         assert self.d, 'no cached oracle case %r' % name
+        self.sha = str(self.d.pop('meta_sha')) if 'meta_sha' in self.d else None       # case_fingerprint(name) when the entry was written
 
     def __getitem__(self, k):
         return torch.from_numpy(np.asarray(self.d[k]))

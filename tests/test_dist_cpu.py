@@ -146,3 +146,22 @@ def test_spawn_local_ends_the_group_when_a_rank_dies_early(tmp_path):
     codes, _ = dist.spawn_local(2, [sys.executable, str(script)], env=env, timeout=2)
     assert time.monotonic() - t0 < 30 and all(c not in (0, None) for c in codes)      # the finite timeout bench.py passes
 
+
+
+def test_assert_distinct_devices_logic():
+    """[r6] The start-up check of a multi-rank RCCL run (bench.py, trainer.main): N ranks must report N distinct (host, PCI address) pairs — the device
+    INDEX cannot tell (with one visible device per process every rank says 0).  Pure logic on hand-made rank lists; the backend test is patched."""
+    from unittest import mock
+    from latent2im_amd import dist
+    good = [dict(rank=r, device=0, pci='0000:%02x:00' % (5 + r), host='node') for r in range(4)]
+    two_hosts = [dict(rank=r, device=0, pci='0000:05:00', host='node%d' % r) for r in range(2)]
+    shared = [dict(rank=r, device=0, pci='0000:05:00', host='node') for r in range(2)]
+    no_pci = [dict(rank=r, device=r, pci=None, host='node') for r in range(2)]
+    with mock.patch.object(dist, 'is_initialized', lambda: True), mock.patch.object(dist.td, 'get_backend', lambda: 'nccl'):
+        assert dist.assert_distinct_devices(good) is good
+        assert dist.assert_distinct_devices(two_hosts) is two_hosts
+        assert dist.assert_distinct_devices(no_pci) is no_pci
+        with pytest.raises(RuntimeError, match='2 ranks on 1 distinct'):
+            dist.assert_distinct_devices(shared)
+    with mock.patch.object(dist, 'is_initialized', lambda: True), mock.patch.object(dist.td, 'get_backend', lambda: 'gloo'):
+        assert dist.assert_distinct_devices(shared) is shared           # the one-GPU rehearsal over gloo is allowed to share

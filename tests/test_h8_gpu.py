@@ -145,6 +145,15 @@ def test_conv_h8_fused_torgb(cout, cin, h, w):
     assert float((rgb.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
     with pytest.raises(_lib.L2IError):                       # the lean epilogue only: a per-pixel operand map is refused, not silently dropped
         hc.forward(xh, rgb=(g(wmod), g(rb), rgb), out_mask=y0, **kw)
+    # [r6] Two things this test pins on purpose.  (1) The fused image is formed from the fp32 epilogue values BEFORE the 16-bit store, while the unfused
+    # l2i_torgb_fwd_h8 and the backward (l2i_sg2_act_bwd_h8: sum_o wmod * grgb against the stored y) see the rounded map: forward and backward of the
+    # ToRGB branch differ by one 16-bit rounding of y, inside the 16-bit step contract (2^-9 / 2^-12 relative per element), which is why `want` above is
+    # built from the unrounded reference.  (2) Cout must be a whole number of 32-channel tiles: the epilogue fetches rgb_w rows for every channel group
+    # of the tile before masking (a 40-channel layer would read past its row).
+    if cout == 32:
+        hc40 = conv.H8Conv(T(rs.randn(40, cin, 3, 3)), 1, 1, device=DEV)
+        with pytest.raises((AssertionError, _lib.L2IError)):
+            hc40.forward(xh, rgb=(g(T(rs.randn(b, 3, 40))), g(rb), rgb))
 
 
 def test_conv_h8_epilogue_fusions_and_fp32_output():

@@ -830,8 +830,11 @@ def test_data_parallel_product_graph_matches_single_process(tmp_path, no_gan):
     for s in range(2):
         # same samples, different launch shapes: at 64^2 most maps are <= 16 x 16, where a batch-4 and a batch-8 launch pack different samples
         # into a tile and sum in a different order, so ReLU / max-pool masks within rounding of zero flip between the two runs (they do not
-        # between either run and the oracle's bar at the bench shapes): 1 % of the entries may be off by more than 2e-3 of the largest, none by 10 %
-        grad_ok(T(b['grads'][s]), T(a['grads'][s]), frac_tol=1e-2)
+        # between either run and the oracle's bar at the bench shapes): 2.5 % of the entries may be off by more than 2e-3 of the largest, none by 10 %
+        # ([r6] measured 1.9 % / largest deviation 0.5 % of max with the pre-masked ResNet trunk, 0.9 % with the round-5 plumbing — two forms that agree to
+        #  2e-5 on equal launch shapes, test_resnet_backward_premasked_trunk_equals_round5_plumbing: which masks flip between a batch-4 and a batch-8
+        #  launch is chaotic in the summation order, the size of what a flip moves is what the second bound holds)
+        grad_ok(T(b['grads'][s]), T(a['grads'][s]), frac_tol=2.5e-2)
         assert relmax(T(b['grads'][s]), T(a['grads'][s])) < 2e-2
     step = np.abs(a['walk'] - synth.walk_init(2, 10, seed=7).reshape(-1)).max()
     assert step > 1e-4                                                # Adam moved the walk ...
@@ -1177,3 +1180,28 @@ def test_to_rgb_and_styled_conv_layer_fixtures(golden, precision):
     y = K.upfirdn2d(t, L.blur_k, pad=(1, 1, 1, 1), noise=nz.contiguous(), noise_w=L.noise_w, bias=L.bias, act=K.ACT_LRELU, slope=0.2, gain=SQ2)
     assert abs(L.noise_w - 0.7) < 1e-6
     close(y, g['styled.y'], 2e-4, 2e-5)
+
+
+@pytest.mark.parametrize('size,batch', [(64, 8), (64, 4), (256, 2)])
+def test_resnet_backward_premasked_trunk_equals_round5_plumbing(size, batch):
+    """[r6] regressor._ResNetFeatFn.backward carries the gradient w.r.t. each block's PRE-ReLU sum (the block-input mask applied once, in the epilogue of
+    the launch that produces it) where round 5 carried the gradient w.r.t. the ReLU output and masked it in both consumers.  Same masks (the stored
+    activations), same products, another order of the two fp32 additions per element: the image gradients of the two forms must agree to fp32
+    rounding — far below the mask-flip bar the gradient tests need against the oracle."""
+    from latent2im_amd import regressor as R
+    net = ResNet50(synth.resnet50_state(seed=300), device=DEV)
+    rs = np.random.RandomState(size + batch)
+    x = T(rs.randn(batch, 3, size, size) * 0.5).float().to(DEV)
+    gy = T(rs.randn(batch, 40)).float().to(DEV)
+    grads = []
+    old = R.PREMASK
+    try:
+        for flag in (True, False):
+            R.PREMASK = flag
+            xg = x.clone().requires_grad_(True)
+            net(xg).backward(gy)
+            grads.append(xg.grad.detach().double().cpu())
+    finally:
+        R.PREMASK = old
+    err = float((grads[0] - grads[1]).abs().max() / grads[1].abs().max())
+    assert err < 2e-5, err

@@ -23,6 +23,28 @@ def test_cached_256_entry_equals_a_live_oracle_evaluation():
         np.testing.assert_allclose(v, c.d[k], rtol=2e-4, atol=2e-5 * scale, err_msg=k)
 
 
+def test_cached_entries_carry_the_fingerprint_of_the_current_oracle():
+    """[r6] Every committed entry was written by THIS oracle on THIS case spec: `<name>.meta_sha` = sha256 over the oracle sources `evaluate` runs, the
+    synthetic-weight generator, the case's spec and alpha values (oracle_cache.case_fingerprint).  A change to any of them fails here until
+    `python tests/golden/make_oracle_cache.py <case>` has re-evaluated the entry — the GPU tests never compare against stale constants silently."""
+    z = np.load(os.path.join(GOLDEN, 'oracle_1024.npz'), allow_pickle=False)
+    for name in oracle_cache.CASES:
+        c = oracle_cache.Cached(z, name)
+        assert c.sha == oracle_cache.case_fingerprint(name), 'cached oracle case %r is stale: re-run tests/golden/make_oracle_cache.py %s' % (name, name)
+
+
+def test_cached_float64_scene_entry_equals_a_live_oracle_evaluation():
+    """[r6] The second honesty entry: `s64` — SceneGraph attribute indices, clamp flow, FLOAT64 evaluation plus the float32 gradient beside it — the code
+    paths the float32 face-attribute entry above does not walk, re-derived live (64^2, batch 4: seconds)."""
+    c = oracle_cache.load(GOLDEN, 's64')
+    live = oracle_cache.evaluate_and_summarize('s64')
+    assert set(live) == set(c.d)
+    for k, v in live.items():
+        scale = float(np.abs(c.d[k]).max()) + 1e-30
+        tol = (2e-4, 2e-5) if k in ('grad32', 'x0.probes', 'x1.probes') else (1e-7, 1e-9)        # float32 quantities / float64 quantities
+        np.testing.assert_allclose(v, c.d[k], rtol=tol[0], atol=tol[1] * scale, err_msg=k)
+
+
 def test_cached_1024_entries_are_complete_and_self_consistent():
     z = np.load(os.path.join(GOLDEN, 'oracle_1024.npz'), allow_pickle=False)
     for name, case in oracle_cache.CASES.items():
