@@ -590,6 +590,13 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     const int tcol_n = NARROW ? (n & 7) : n;
 
     const int G = gridDim.x;
+#ifdef L2I_W4_STAMP                                     // timing instrumentation (tools/probes/w4_stamp.py): thread 0 of every block writes the cycle counter at six points into p.ws
+    unsigned long long stamp[6];
+#define W4_STAMP(i) stamp[i] = __builtin_readcyclecounter()
+#else
+#define W4_STAMP(i)
+#endif
+    W4_STAMP(0);
     int w = (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
     if (w >= L.total) return;
     const int mblk = w % L.mblocks; w /= L.mblocks;
@@ -726,6 +733,7 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     if (W4_UPF) { issue_pf(1, 1 < L.nchunks); issue_pf(2, 2 < L.nchunks); }
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NRS + 2 * W4_UPF) : "memory");   // U(0), raw(0) landed
     __syncthreads();                                                          // (also: the style-scale table)
+    W4_STAMP(1);
     {
         const f32x2 sc = scale_of(0);
 #pragma unroll
@@ -809,6 +817,7 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
     };
     auto nxt = [](int v, int m) { return v + 1 == m ? 0 : v + 1; };
 
+    W4_STAMP(2);
     top();
     chunk(std::true_type(), 0, 0, 1 % RS, Ta, Tb);
     int ch = 1, rnext = 2 % RS, ucur = 1;
@@ -824,9 +833,39 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
         top();
         chunk(std::false_type(), ch, ucur, rnext, Tb, Ta);
     }
+    W4_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // no DMA may outlive the block's LDS
     __syncthreads();                                                           // every wave is past its last LDS read and its last DMA: the rings are dead
 
+    // [r6] epilogue operands that do not depend on the accumulators — the demodulation / bias of this lane's four channels and the four noise rows of its
+    // tile — are requested HERE, so that they travel during the half exchange below (36 LDS instructions and a barrier) instead of after it: inside the
+    // row loop the noise row of ry + 1 could not even be requested before row ry's stores (they may alias as far as the compiler knows).  Same values,
+    // same arithmetic: bit-identical; -11 % / -8 % on the generator's 1024^2 / 512^2 launches (profiles/r06_wino4s_strip_ab.txt).
+    // -DL2I_W4_EPI_HOIST=0: the round-5 placement (A/B).
+#ifndef L2I_W4_EPI_HOIST
+#define L2I_W4_EPI_HOIST 1
+#endif
+    const size_t plane_o = (size_t)p.OHf * p.OWf;
+    const int oyb = oy0 + 4 * trow_n, ox = ox0 + 4 * tcol_n;
+    const bool xok = ox < p.OW;
+    float scv_h[2][2], bv_h[2][2];
+    float4 nz_h[4];
+    if (L2I_W4_EPI_HOIST) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int co = m0 + 16 * H + 4 * kq + 2 * h + q;
+                scv_h[h][q] = (p.out_scale && co < p.Cout) ? p.out_scale[(size_t)b * p.Cout + co] : 1.f;
+                bv_h[h][q] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+            }
+#pragma unroll
+        for (int ry = 0; ry < 4; ++ry) {
+            const int oy = oyb + ry;
+            nz_h[ry] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xok && oy < p.OH && p.noise) nz_h[ry] = *reinterpret_cast<const float4*>(p.noise + (size_t)b * plane_o + (size_t)(oy + p.oy_off) * p.OWf + ox + p.ox_off);
+        }
+    }
     // ---- the two position halves of a tile row meet: wave (H, t) hands over its rows of group 1 - H and finishes group H ----
     {
         float4* xw = reinterpret_cast<float4*>(smem + wave_u * XCH) + lane;
@@ -847,11 +886,9 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
         }
     }
     auto M = [&](int r, int j) -> const f32x4& { return (r / 3 == H) ? acc[H][6 * (r - 3 * H) + j] : oth[6 * (r - 3 * (1 - H)) + j]; };
+    W4_STAMP(4);
 
     // ---- epilogue: lane-local inverse transform Y = A^T M A, then 16-byte row stores (lane (g, n): channels m0 + 16 H + 4 g + 0..3, tile (trow, n)) ----
-    const size_t plane_o = (size_t)p.OHf * p.OWf;
-    const int oyb = oy0 + 4 * trow_n, ox = ox0 + 4 * tcol_n;
-    const bool xok = ox < p.OW;
     float sq = 0.f;
     const float rc = p.res_sub ? p.res_coef * (p.res_coef_dev ? p.res_coef_dev[0] : 1.f) : 0.f;
 #pragma unroll
@@ -873,6 +910,7 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int co = co0 + q;
+            if (L2I_W4_EPI_HOIST) { scv[q] = scv_h[h][q]; bv[q] = bv_h[h][q]; continue; }
             scv[q] = (p.out_scale && co < p.Cout) ? p.out_scale[(size_t)b * p.Cout + co] : 1.f;
             bv[q] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
         }
@@ -889,7 +927,7 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
             const size_t poff = (size_t)(oy + p.oy_off) * p.OWf + ox + p.ox_off;
             float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
             if (pok && p.noise) {
-                nz = *reinterpret_cast<const float4*>(p.noise + (size_t)b * plane_o + poff);
+                nz = L2I_W4_EPI_HOIST ? nz_h[ry] : *reinterpret_cast<const float4*>(p.noise + (size_t)b * plane_o + poff);
                 nz.x *= p.noise_w; nz.y *= p.noise_w; nz.z *= p.noise_w; nz.w *= p.noise_w;
             }
 #pragma unroll
@@ -966,6 +1004,13 @@ __device__ __forceinline__ void wino4s_body(const l2i_conv_params& p, const Wino
             atomicAdd(p.sq_out + (blockIdx.x & (L2I_SQ_SLOTS - 1)), t);
         }
     }
+#ifdef L2I_W4_STAMP
+    W4_STAMP(5);
+    if (p.ws && tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 6; ++i) o[i] = stamp[i];
+    }
+#endif
 }
 
 template <bool SCALE, bool RELU, int VAR = 0>
