@@ -33,11 +33,14 @@ def freeze_host_objects():
     gc.freeze()
 
 
-def forward(g, z, alpha_for_graph, clamp=False, layers=None):
+def forward(g, z, alpha_for_graph, clamp=False, layers=None, content=False):
     """train.py:56-101 on DEVICE inputs: both generator passes, the regressor on the original, epsilon and the walk; no host
-    synchronisation.  Returns (feed_dict for optimizeParametersAll, dict of device tensors)."""
+    synchronisation.  Returns (feed_dict for optimizeParametersAll, dict of device tensors).  ``content``: the step will take the content
+    loss: the VGG taps of the original image start now, beside the regressor and the second generator pass (graph.prefetch_content_taps)."""
     w = g.get_w(z)
     x0 = g.get_logits({'w': w})
+    if content:
+        g.prefetch_content_taps(x0)
     a0 = g.get_reg_preds(x0)
     if clamp:
         target, eps = g.get_alphas_clamped(a0, alpha_for_graph)
@@ -51,7 +54,7 @@ def forward(g, z, alpha_for_graph, clamp=False, layers=None):
 def forward_backward(g, z, alpha_for_graph, no_content_loss=False, no_gan_loss=False, clamp=False, layers=None):
     """``forward`` + the loss and backward of optimizeParametersAll (transform_base.py:459-488), without its all-reduce / Adam tail.
     Leaves d loss / d walk in ``walk.grad``."""
-    feed, r = forward(g, z, alpha_for_graph, clamp=clamp, layers=layers)
+    feed, r = forward(g, z, alpha_for_graph, clamp=clamp, layers=layers, content=not no_content_loss)
     g.optimizers.zero_grad()
     loss = g.get_w_loss(feed, no_content_loss, no_gan_loss)
     loss.backward()

@@ -27,6 +27,8 @@ SYNTH_NOISE_STRENGTH = 0.0
 
 # run the discriminator / VGG / regressor loss branches on separate HIP streams (see graph.TransformGraph.get_w_loss)
 CONCURRENT_LOSS_BRANCHES = True
+# [r6] start the VGG prefix of the ORIGINAL image on the content branch's stream as soon as that image exists (graph.prefetch_content_taps); L2I_PREFETCH_TAPS=1 / 0: force on / off (A/B)
+PREFETCH_CONTENT_TAPS = {'1': True, '0': False}.get(_os.environ.get('L2I_PREFETCH_TAPS', ''))      # None: on for the 16-bit path only (measured: graph.prefetch_content_taps)
 
 # transform_base.py:290 hard-codes ``is_mlp = False`` ("TODO: Hard code"); True builds WalkMlpMultiW instead of WalkLinearMultiW
 WALK_IS_MLP = False

@@ -336,9 +336,31 @@ class TransformGraph:
         preds = self.regressor(logit).index_select(1, self._attr_columns())
         return self.get_bce_loss(preds, alpha_gt).mean()
 
+    def prefetch_content_taps(self, org_img):
+        """[r6] Start the VGG-19 prefix of the ORIGINAL image (transform_base.py:444-454: ``target = model(org).detach()``, no gradient) on the content
+        branch's stream as soon as that image exists, i.e. while the regressor reads it and the second generator pass runs: 6 ms (fp32) of large
+        matrix-bound launches that fill the chip where the regressor's tail and the generator's 4^2 .. 64^2 layers do not.  ``get_content_loss`` picks
+        the taps up when it is handed the same tensor; the values are the same launches' outputs, issued earlier.  The drivers call this (capture.forward,
+        trainer.train_step) when the content loss is on; without the call nothing changes."""
+        # Measured (tools/ab/r06_prefetch_taps.sh, alternating runs on one box): the 16-bit path gains 0.8 % (c5 35.43 / 35.24 -> 35.08 / 34.99 ms per step: its
+        # launches are short and the chip has holes to fill); the fp32 path LOSES 0.4 % (c3 99.27 / 99.54 -> 99.82 / 99.94: its launches saturate the chip
+        # and the early taps only lengthen the critical chain) — so: on for the 16-bit path, off for fp32 (L2I_PREFETCH_TAPS=1 / 0 force it).
+        from . import conv
+        on = constants.PREFETCH_CONTENT_TAPS if constants.PREFETCH_CONTENT_TAPS is not None else conv.PRECISION in conv.H8_PRECISIONS
+        if self.vgg19 is None or not constants.CONCURRENT_LOSS_BRANCHES or not on:
+            return
+        cur = torch.cuda.current_stream()
+        side = self._side_streams()[1]
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            self._org_taps = (org_img, self.vgg19.org_taps(org_img.detach()))
+
     def get_content_loss(self, org_img, shifted_img):
         """List of four scalars (transform_base.py:426-454)."""
-        losses = self.vgg19.content_losses(org_img, shifted_img)
+        pre = getattr(self, '_org_taps', None)
+        self._org_taps = None
+        taps = pre[1] if (pre is not None and pre[0] is org_img) else None
+        losses = self.vgg19.content_losses(org_img, shifted_img, org_taps=taps)
         return [losses[i] for i in range(4)]
 
     # -- loss / optimiser ----------------------------------------------------------------------------------------

@@ -158,10 +158,13 @@ class VGG19Prefix:
             return c1, c2, p, c3, c4, idx
         return c1, c2, p, c3, c4, idx, [acc[k].sum().reshape(1) for k in range(4)]
 
-    def content_losses(self, org, shifted):
+    def org_taps(self, org):
         with torch.no_grad():
             o1, o2, _, o3, o4, _ = self.taps(org.detach())
-        return _Content16Fn.apply(shifted, self, (o1, o2, o3, o4))
+        return (o1, o2, o3, o4)
+
+    def content_losses(self, org, shifted, org_taps=None):
+        return _Content16Fn.apply(shifted, self, org_taps if org_taps is not None else self.org_taps(org))
 
 
 class _Content16Fn(torch.autograd.Function):

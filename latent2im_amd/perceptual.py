@@ -64,11 +64,16 @@ class VGG19Prefix:
         sums = [acc[k].sum().reshape(1) if sq[k][2][0] else K.sqdiff(org[k], mine[k])[0] for k in range(4)]
         return c1, c2, p, c3, c4, idx, sums
 
-    def content_losses(self, org, shifted):
-        """Four mse(feat_k(org).detach(), feat_k(shifted)) scalars as one [4] tensor, differentiable w.r.t. shifted."""
+    def org_taps(self, org):
+        """The four taps of the original image (no gradient): what ``content_losses`` compares against."""
         with torch.no_grad():
             o1, o2, _, o3, o4, _ = self.taps(org.detach())
-        return _ContentFn.apply(shifted, self, (o1, o2, o3, o4))
+        return (o1, o2, o3, o4)
+
+    def content_losses(self, org, shifted, org_taps=None):
+        """Four mse(feat_k(org).detach(), feat_k(shifted)) scalars as one [4] tensor, differentiable w.r.t. shifted.  ``org_taps``: the result of
+        ``org_taps(org)`` when the caller has already started it (graph.TransformGraph.prefetch_content_taps)."""
+        return _ContentFn.apply(shifted, self, org_taps if org_taps is not None else self.org_taps(org))
 
 
 class _ContentFn(torch.autograd.Function):

@@ -37,7 +37,7 @@ def run_step(g, zs, alpha, no_content_loss=False, no_gan_loss=False, clamp=False
     z = torch.Tensor(zs).to(dev)
     ag = torch.tensor(alpha).float().to(dev)
     if optimize:
-        feed, r = capture.forward(g, z, ag, clamp=clamp, layers=layers)
+        feed, r = capture.forward(g, z, ag, clamp=clamp, layers=layers, content=not no_content_loss)
         loss = g.optimizeParametersAll(feed, False, False, no_content_loss=no_content_loss, no_gan_loss=no_gan_loss)
         r.update(loss=loss.detach(), terms=g.last_terms)
     else:

@@ -53,6 +53,8 @@ def train_step(graphs, zs_batch, attrList, layers=None, trainEmbed=False, update
     z_global = torch.Tensor(zs_batch).to(graphs.device)                       # train.py:56
     w_global = graphs.get_w(z_global)                                          # :62
     out_zs = graphs.get_logits({'z': z_global, 'w': w_global})                 # :66
+    if not (opt and opt.no_content_loss) and hasattr(graphs, 'prefetch_content_taps'):
+        graphs.prefetch_content_taps(out_zs)                                   # the VGG taps of the original start beside the regressor / second generator pass
     alpha_org = graphs.get_reg_preds(out_zs)                                   # :69
     alpha_for_graph, alpha_for_target, _ = graphs.get_train_alpha(zs_batch, N_attr=len(attrList), trainEmbed=trainEmbed)
     ag = torch.tensor(alpha_for_graph).float().to(graphs.device)               # :84-85
