@@ -103,6 +103,12 @@ typedef struct l2i_conv_params {
     uint8_t* pool_idx;      /* also writes MaxPool2d(2, 2) of its output y, pool_out [B, Cout, OHf/2, OWf/2] fp32 and the window-local arg-max pool_idx (same     */
                             /* shape, bytes; taps in (ky, kx) order, first maximum, NaN propagates: l2i_maxpool2d_fwd_f32's rule) — VGG-19's pool after conv1_2   */
                             /* (transform_base.py:426-454) from the 4x4 output tile a lane holds anyway, instead of a pass that reads the 2 GB map again          */
+    /* ---- ABI version 6: one-bit activation masks on the 16-bit path (l2i_conv2d_h8 / l2i_conv_transpose2d_h8) ------------------------------------------- */
+    uint8_t* mask_out;      /* h8 output: not NULL = the launch also writes the SIGN PLANE of its output, one byte per 16-byte pixel slot:                              */
+                            /* mask_out[((b * Cout/8 + g) * OHf + oy) * OWf + ox] bit e = (the stored 16-bit y[b, 8 g + e, oy, ox] > 0).  The input-gradient launches of   */
+                            /* a frozen ReLU network need exactly this bit of every saved activation (torchvision's bottleneck relu(bn(conv)) called at                   */
+                            /* transform_base.py:396-403,416-424), and read it at 1/16 of the map's bytes                                                                 */
+    int32_t mask_bits;      /* 1 = out_mask / res_mask point to such sign planes ([B, Cout/8, OHf, OWf] bytes) instead of h8 maps shaped like y                           */
 } l2i_conv_params;
 #define L2I_SQ_SLOTS 1024
 
@@ -397,7 +403,7 @@ int l2i_adam_guarded_f32(float* p, const float* g, float* m, float* v, float* st
 
 const char* l2i_last_error(void);
 /* Bumped whenever a struct of this header grows or an entry point changes meaning (1: round 1-2; 2: round 3, l2i_conv_params gained w_bstride /
- * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
+ * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32, mask_out / mask_bits fields).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
 #define L2I_ABI_VERSION 6
 int l2i_abi_version(void);
 int l2i_sizeof_conv_params(void);       /* sizeof(struct l2i_conv_params) of THIS build */

@@ -37,6 +37,7 @@ class ConvParams(ctypes.Structure):
         ('sq_ref', c_p), ('sq_out', c_p),
         ('w_bstride', c_l), ('out_f32', c_i),
         ('in_h8', c_i), ('rgb_w', c_p), ('rgb_bias', c_p), ('rgb_out', c_p), ('pool_out', c_p), ('pool_idx', c_p),
+        ('mask_out', c_p), ('mask_bits', c_i),
     ]
 
 

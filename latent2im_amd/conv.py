@@ -736,7 +736,7 @@ H8Conv.dgrad_compact = _h8_dgrad_compact
 
 def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=0, out_f32=False, out_scale=None, noise=None, noise_w=0.0, bias=None,
            residual=None, res_mask=None, out_mask=None, mask=(1.0, 0.0), act=ACT_NONE, slope=0.2, gain=1.0, out_gain=1.0, accumulate=False, res_sub=None, res_coef=1.0,
-           res_coef_dev=None, sq=None, relu_in=False, rgb=None):
+           res_coef_dev=None, sq=None, relu_in=False, rgb=None, mask_out=None, mask_bits=False):
     """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels."""
     lib = _lib.load()
     B, cg, H, W, _ = x.shape
@@ -763,8 +763,13 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
         p.OH, p.OW = min(OHf, (H + 2 * pad - k) // stride + 1), min(OWf, (W + 2 * pad - k) // stride + 1)
         p.oy_step = p.ox_step = 1
     p.out_scale, p.noise, p.noise_w, p.bias = _lib.fptr(out_scale), _lib.fptr(noise), float(noise_w), _lib.fptr(bias)
-    for t in (residual, res_mask, out_mask, res_sub):
+    for t in (residual, res_sub) + (() if mask_bits else (res_mask, out_mask)):
         assert t is None or (t.shape == y.shape and t.dtype == y.dtype)
+    if mask_bits or mask_out is not None:             # [r6] sign planes (l2i.h: mask_out / mask_bits): one byte per 16-byte pixel slot, [B, Cout/8, OHf, OWf] uint8
+        assert not out_f32
+        for t in (mask_out,) + ((res_mask, out_mask) if mask_bits else ()):
+            assert t is None or (t.dtype == torch.uint8 and tuple(t.shape) == tuple(y.shape[:4]) and t.is_contiguous()), (None if t is None else (t.dtype, t.shape), y.shape)
+        p.mask_out, p.mask_bits = _lib.ptr(mask_out), int(bool(mask_bits))
     p.residual, p.res_mask, p.out_mask = _lib.ptr(residual), _lib.ptr(res_mask), _lib.ptr(out_mask)
     p.mask_pos, p.mask_neg = mask                                 # of the OUTPUT mask here: * (out_mask > 0 ? mask[0] : mask[1])
     if relu_in:                                                   # ReLU-on-load (VGG-19 reads pre-ReLU taps): in_mask == x, mask (1, 0)

@@ -110,6 +110,19 @@ __device__ __forceinline__ void h8_unpack(const u32x4& u, float (&v)[8]) {
     v[4] = bf16_lo(u.z); v[5] = bf16_hi(u.z); v[6] = bf16_lo(u.w); v[7] = bf16_hi(u.w);
 }
 
+// [r6] sign plane: bit e of the byte = (16-bit element e of the slot > 0).  Per dword (two elements): max with 0 as signed 16-bit integers (a negative
+// fp16 / bf16, and -0, is a negative int16) then min with 1 as unsigned -> 0 / 1 in bits 0 and 16; the four dwords shifted by 0, 2, 4, 6 and folded.
+__device__ __forceinline__ unsigned h8_sign_byte(const u32x4& o) {
+    unsigned t[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asm("v_pk_max_i16 %0, %0, 0" : "+v"(t[i]));
+        asm("v_pk_min_u16 %0, %0, %1" : "+v"(t[i]) : "v"(0x00010001u));
+    }
+    const unsigned u = t[0] | (t[1] << 2) | (t[2] << 4) | (t[3] << 6);
+    return (u | (u >> 15)) & 0xffu;
+}
+
 struct H8Out {
     const l2i_conv_params& p;
     int b, cg_out;                       // sample, 8-channel groups of the output tensor
@@ -124,19 +137,28 @@ struct H8Out {
         // dependent memory round trips per slot and eight slots per wave
         u32x4 q_mask, q_res, q_sub, q_rmask, q_old;
         float4 s0, s1, b0, b1;
-        if (p.out_mask) q_mask = reinterpret_cast<const u32x4*>(p.out_mask)[slot];
+        unsigned mb = 0u, rmb = 0u;                                // [r6] mask_bits: the masks are sign planes, one byte per slot
+        if (p.out_mask) { if (p.mask_bits) mb = reinterpret_cast<const uint8_t*>(p.out_mask)[slot]; else q_mask = reinterpret_cast<const u32x4*>(p.out_mask)[slot]; }
         if (p.residual) q_res = reinterpret_cast<const u32x4*>(p.residual)[slot];
         if (p.res_sub) q_sub = reinterpret_cast<const u32x4*>(p.res_sub)[slot];
-        if (p.res_mask) q_rmask = reinterpret_cast<const u32x4*>(p.res_mask)[slot];
+        if (p.res_mask) {
+            if (p.mask_bits) rmb = (p.res_mask == p.out_mask) ? mb : (unsigned)reinterpret_cast<const uint8_t*>(p.res_mask)[slot];
+            else q_rmask = reinterpret_cast<const u32x4*>(p.res_mask)[slot];
+        }
         if (p.accumulate) q_old = y4[slot];
         if (p.out_scale) { s0 = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Cout + co0); s1 = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Cout + co0 + 4); }
         if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + co0); b1 = *reinterpret_cast<const float4*>(p.bias + co0 + 4); }
         if (p.out_scale) { v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w; v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w; }
         if (p.out_mask) {
-            float m[8];
-            h8_unpack(q_mask, m);
+            if (p.mask_bits) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= m[e] > 0.f ? p.mask_pos : p.mask_neg;   // (1, 0): a ReLU mask; (1, 0.2) / (sqrt2, 0.2 sqrt2): leaky ReLU'
+                for (int e = 0; e < 8; ++e) v[e] *= ((mb >> e) & 1u) ? p.mask_pos : p.mask_neg;
+            } else {
+                float m[8];
+                h8_unpack(q_mask, m);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= m[e] > 0.f ? p.mask_pos : p.mask_neg;   // (1, 0): a ReLU mask; (1, 0.2) / (sqrt2, 0.2 sqrt2): leaky ReLU'
+            }
         }
         if (p.bias) { v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w; }
         if (p.noise) {
@@ -153,10 +175,15 @@ struct H8Out {
                 for (int e = 0; e < 8; ++e) r[e] = rc * (r[e] - s[e]);
             }
             if (p.res_mask) {
-                float m[8];
-                h8_unpack(q_rmask, m);
+                if (p.mask_bits) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) r[e] = m[e] > 0.f ? r[e] : 0.f;
+                    for (int e = 0; e < 8; ++e) r[e] = ((rmb >> e) & 1u) ? r[e] : 0.f;
+                } else {
+                    float m[8];
+                    h8_unpack(q_rmask, m);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = m[e] > 0.f ? r[e] : 0.f;
+                }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += r[e];
@@ -183,6 +210,7 @@ struct H8Out {
         if (out.x == 0x12345678u && out.y == 0x9abcdef0u)
 #endif
         reinterpret_cast<u32x4*>(p.y)[slot] = out;
+        if (p.mask_out) p.mask_out[slot] = (uint8_t)h8_sign_byte(out);
         if (p.sq_ref) {                                            // ContentLoss value of a VGG tap on the ROUNDED output (what the next layer reads)
             float rf[8], w[8];
             h8_unpack(reinterpret_cast<const u32x4*>(p.sq_ref)[slot], rf);
@@ -556,6 +584,7 @@ __global__ __launch_bounds__(256, ((KS == 1 || K == 1) && TR == 0) ? (EXTRA ? 3 
                     if (out.x == 0x12345678u && out.y == 0x9abcdef0u)
 #endif
                     if (ok && gok) yq[off] = out;
+                    if (!EXTRA && p.mask_out && ok && gok) p.mask_out[((size_t)b * cg_out + g0 + 4 * m + 2 * pr) * plane + off] = (uint8_t)h8_sign_byte(out);
                     if (EXTRA && p.sq_ref && ok && gok) {          // [r5] ContentLoss value of a VGG tap on the ROUNDED output, as in the general epilogue
                         float rf[8], w[8];
                         h8_unpack(reinterpret_cast<const u32x4*>(p.sq_ref)[((size_t)b * cg_out + g0 + 4 * m + 2 * pr) * plane + off], rf);
@@ -687,12 +716,14 @@ static int h8_common_checks(const l2i_conv_params& p, const char* who) {
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: no prologue fusions (scales live in the weights, masks in the producing epilogue) except ReLU-on-load (in_mask == x)");
     if ((p.Cin % 16) != 0) return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: Cin must be a multiple of 16");
     auto al16 = [](const void* q) { return (((uintptr_t)q) % 16) == 0; };
-    if (!al16(p.x) || !al16(p.w_hi) || !al16(p.y) || !al16(p.residual) || !al16(p.res_mask) || !al16(p.res_sub) || !al16(p.out_mask) || !al16(p.sq_ref) ||
+    if (!al16(p.x) || !al16(p.w_hi) || !al16(p.y) || !al16(p.residual) || (!p.mask_bits && (!al16(p.res_mask) || !al16(p.out_mask))) || !al16(p.res_sub) || !al16(p.sq_ref) ||
         !al16(p.bias) || !al16(p.out_scale) || (p.w_bstride % 16) != 0)
         return l2i_set_error(L2I_E_ARG, "conv h8: tensors must be 16-byte aligned");
     if ((size_t)(p.Cin / 8) * p.H * p.W * 16 >= 0xFFFFFFF0ull || (size_t)(p.Cin / 16) * p.KH * p.KW * 2 * p.CoutP * 16 >= 0xFFFFFFF0ull)
         return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: one sample / the weight planes must stay below 4 GiB (32-bit buffer offsets)");
     if (p.res_sub && !p.residual) return l2i_set_error(L2I_E_ARG, "conv h8: res_sub needs residual");
+    if (p.mask_out && (p.out_f32 || p.rgb_w || p.sq_ref)) return l2i_set_error(L2I_E_UNSUPPORTED, "conv h8: mask_out rides on the plain h8 epilogues (no fp32 output, ToRGB or ContentLoss sum in the same launch)");
+    if (p.mask_bits && (p.out_f32 || !(p.out_mask || p.res_mask))) return l2i_set_error(L2I_E_ARG, "conv h8: mask_bits describes out_mask / res_mask of an h8-output launch");
     if ((p.sq_ref != nullptr) != (p.sq_out != nullptr)) return l2i_set_error(L2I_E_ARG, "conv h8: sq_ref and sq_out go together");
     (void)who;
     return L2I_OK;

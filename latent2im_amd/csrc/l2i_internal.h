@@ -24,6 +24,7 @@ static inline const char* l2i_unsupported_v5_fields(const l2i_conv_params& p, bo
     if (!allow_rgb && (p.rgb_w || p.rgb_bias || p.rgb_out)) return "rgb_w / rgb_bias / rgb_out are fused in l2i_conv2d_h8 only";
     if (!allow_pool && (p.pool_out || p.pool_idx)) return "pool_out / pool_idx are fused in l2i_conv2d_wino4_f32 only";
     if (!allow_in_h8 && p.in_h8) return "in_h8 is read by the 7x7 kernel of l2i_conv_transpose2d_f32 only";
+    if (!allow_rgb && (p.mask_out || p.mask_bits)) return "mask_out / mask_bits (one-bit activation masks) belong to l2i_conv2d_h8 / l2i_conv_transpose2d_h8";      // (allow_rgb = the h8 entries)
     return nullptr;
 }
 

@@ -48,6 +48,9 @@ IMG_CONVS = os.environ.get('L2I_H8_IMG_CONVS', '1') != '0'
 # [r5] ToRGB of the 512^2 / 1024^2 StyledConv outputs (64 / 32 channels: one block of the conv holds them all) in that conv's epilogue
 # (l2i_conv_params::rgb_w) instead of a pass that reads the feature map again.  L2I_H8_RGB_FUSED=0: the separate l2i_torgb_fwd_h8 launch (A/B).
 RGB_FUSED = os.environ.get('L2I_H8_RGB_FUSED', '1') != '0'
+# [r6] ResNet-50's backward reads one-bit sign planes written by the forward convs instead of the activation maps themselves (l2i.h: mask_out / mask_bits).
+# L2I_H8_SIGN_PLANES=0: the maps, as in round 5 (A/B).
+SIGN_PLANES = os.environ.get('L2I_H8_SIGN_PLANES', '1') != '0'
 # [r5] the per-sample weight planes of all modulated convs of a pass in ONE launch (kernels16.ModulatePlan) instead of one 15 us launch per layer and
 # pass (51 per step).  L2I_H8_MOD_MULTI=0: per layer (A/B).
 MOD_MULTI = os.environ.get('L2I_H8_MOD_MULTI', '1') != '0'
@@ -252,12 +255,30 @@ class _ResNet16Fn(torch.autograd.Function):
             p0, idx0 = K16.maxpool2d_fwd(K16.cast_to_h8(a0, dtype=net.dtype), 3, 2, 1)
         saved = dict(in_hw=(x.shape[2], x.shape[3]), a0=a0 if keep else None, idx0=idx0 if keep else None, blocks=[])
         cur = p0
-        for blk in net.blocks:
-            y1 = blk['c1'].conv.forward(cur, bias=blk['c1'].bias, act=C.ACT_RELU)
-            y2 = blk['c2'].conv.forward(y1, bias=blk['c2'].bias, act=C.ACT_RELU)
+        # [r6] SIGN_PLANES: the backward needs ONE BIT of every activation of this net (is the ReLU output positive); the three convs of a bottleneck write it
+        # beside their map (l2i.h: mask_out, one byte per 16-byte pixel slot) and the gradient launches read the byte planes (mask_bits) — 1/16 of the
+        # bytes of the maps they stand for, and y1 / y2 / out need not be kept for the backward at all.  L2I_H8_SIGN_PLANES=0: the round-5 form (A/B).
+        bits = keep and SIGN_PLANES
+        plane = lambda t: torch.empty(t.shape[:4], device=t.device, dtype=torch.uint8)
+        n_blk = len(net.blocks)
+        for bi, blk in enumerate(net.blocks):
+            if bits:
+                hw_in = (cur.shape[2], cur.shape[3])
+                s2 = blk['c2'].conv.stride
+                m1 = torch.empty(cur.shape[0], blk['c1'].conv.cout // 8, hw_in[0], hw_in[1], device=cur.device, dtype=torch.uint8)
+                m2 = torch.empty(cur.shape[0], blk['c2'].conv.cout // 8, hw_in[0] // s2, hw_in[1] // s2, device=cur.device, dtype=torch.uint8)
+                mo = torch.empty(cur.shape[0], blk['c3'].conv.cout // 8, hw_in[0] // s2, hw_in[1] // s2, device=cur.device, dtype=torch.uint8)
+            else:
+                m1 = m2 = mo = None
+            y1 = blk['c1'].conv.forward(cur, bias=blk['c1'].bias, act=C.ACT_RELU, mask_out=m1)
+            y2 = blk['c2'].conv.forward(y1, bias=blk['c2'].bias, act=C.ACT_RELU, mask_out=m2)
             idt = blk['down'].conv.forward(cur, bias=blk['down'].bias) if blk['down'] is not None else cur
-            out = blk['c3'].conv.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU)
-            if keep:
+            out = blk['c3'].conv.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU, mask_out=mo)
+            if bits:
+                # (kept as maps: the input of a stride-2 block — its mask rides on the zero-insertion pass — and the last output, for the first mask)
+                keep_cur = blk['down'] is not None and blk['down'].conv.stride == 2
+                saved['blocks'].append((cur if keep_cur else cur.shape, m1, m2, mo, out if bi == n_blk - 1 else None))
+            elif keep:
                 saved['blocks'].append((cur, y1, y2, out))
             cur = out
             if PROBE is not None and blk['down'] is not None:
@@ -285,21 +306,32 @@ class _ResNet16Fn(torch.autograd.Function):
         g = (g_feat * (S / (h * w))).reshape(b, g8, 1, 1, 8).expand(b, g8, h, w, 8).contiguous().to(net.dtype)
         G = K16.mask_mul(g, last)                                                        # gradient w.r.t. the pre-ReLU sum of the last block
         n = len(net.blocks)
+        bits = len(saved['blocks'][0]) == 5                # sign planes (forward: SIGN_PLANES)
         for bi in range(n - 1, -1, -1):
-            blk, (cur, y1, y2, out) = net.blocks[bi], saved['blocks'][bi]
-            m = cur if bi > 0 else None                    # the block input is the previous block's ReLU output (the pooled stem map is not)
-            g_y2 = blk['c3'].conv.dgrad(G, hw(y2), out_mask=y2)
-            g_y1 = blk['c2'].conv.dgrad(g_y2, hw(y1), out_mask=y1)
+            blk = net.blocks[bi]
+            if bits:
+                cur, y1, y2, out, _ = saved['blocks'][bi]                      # y1 / y2 / out: byte planes; cur: the input map (stride-2 blocks) or its shape
+                cur_hw = (cur[2], cur[3]) if isinstance(cur, torch.Size) else hw(cur)
+                m = saved['blocks'][bi - 1][3] if bi > 0 else None
+                mb = dict(mask_bits=True)
+            else:
+                cur, y1, y2, out = saved['blocks'][bi]
+                cur_hw = hw(cur)
+                m = cur if bi > 0 else None                # the block input is the previous block's ReLU output (the pooled stem map is not)
+                mb = {}
+            mm = dict(out_mask=m, res_mask=m, **mb) if m is not None else {}
+            g_y2 = blk['c3'].conv.dgrad(G, hw(y2), out_mask=y2, **mb)
+            g_y1 = blk['c2'].conv.dgrad(g_y2, hw(y1), out_mask=y1, **mb)
             del g_y2
             if blk['down'] is None:
-                Gp = blk['c1'].conv.dgrad(g_y1, hw(cur), residual=G, out_mask=m, res_mask=m)
+                Gp = blk['c1'].conv.dgrad(g_y1, cur_hw, residual=G, **mm)
             elif blk['down'].conv.stride == 1:
-                t = blk['c1'].conv.dgrad(g_y1, hw(cur))
-                Gp = blk['down'].conv.dgrad(G, hw(cur), residual=t, out_mask=m, res_mask=m)
+                t = blk['c1'].conv.dgrad(g_y1, cur_hw)
+                Gp = blk['down'].conv.dgrad(G, cur_hw, residual=t, **mm)
                 del t
             else:
-                Gp = blk['c1'].conv.dgrad(g_y1, hw(cur), out_mask=m)
-                K16.add_zero_insert(Gp, blk['down'].conv.dgrad_compact(G), mask=m)       # strided 1x1: compact 1x1 conv + zero insertion
+                Gp = blk['c1'].conv.dgrad(g_y1, cur_hw, **(dict(out_mask=m, **mb) if m is not None else {}))
+                K16.add_zero_insert(Gp, blk['down'].conv.dgrad_compact(G), mask=cur if bi > 0 else None)       # strided 1x1: compact 1x1 conv + zero insertion
             del g_y1
             G = Gp
             if PROBE is not None and (bi in (0, n - 1) or net.blocks[bi]['down'] is not None):

@@ -769,3 +769,68 @@ def test_modulated_conv_layer_fixture_h8(name, up):
     gw = (ds @ mod.A).double().cpu()
     want = T(g[name + '.gw']).double()
     assert float((gw - want).abs().max()) < 2.0 ** -6 * float(want.abs().max()), float((gw - want).abs().max()) / float(want.abs().max())
+
+
+def test_conv_h8_sign_planes_written_and_read():
+    """[r6] l2i_conv_params::mask_out / mask_bits: a launch writes the sign plane of its h8 output (one byte per 16-byte pixel slot, bit e = the stored element
+    e > 0) from both epilogues (lean: bias + ReLU / leaky ReLU; general: residual + ReLU), bit-exactly what the stored map says; and a gradient launch
+    that reads its out_mask / res_mask as such planes returns the same bits as the launch that reads the maps."""
+    rs = np.random.RandomState(5)
+    g = lambda t: t.to(DEV)
+    b, cin, cout, h, w = 2, 64, 96, 19, 45
+    x = conv.to_h8(g(T(rs.randn(b, cin, h, w))), 32)
+    bias = g(T(rs.randn(cout)))
+
+    def want_bits(y):                                   # [B, G, H, W, 8] 16-bit -> [B, G, H, W] uint8
+        pos = (y.float() > 0).to(torch.int32)
+        return sum(pos[..., e] << e for e in range(8)).to(torch.uint8)
+
+    for k, kw in ((3, dict(bias=bias, act=conv.ACT_RELU)), (3, dict(bias=bias, act=conv.ACT_LRELU, slope=0.2, gain=2 ** 0.5)), (1, dict(bias=bias, act=conv.ACT_RELU))):
+        hc = conv.H8Conv(T(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)), 1, k // 2, device=DEV)
+        y0 = hc.forward(x, **kw)
+        planes = torch.full((b, cout // 8, h, w), 0xAA, device=DEV, dtype=torch.uint8)
+        y1 = hc.forward(x, mask_out=planes, **kw)                                        # lean epilogue
+        res = conv.to_h8(g(T(rs.randn(b, cout, h, w))), 8)
+        planes_r = torch.full_like(planes, 0x55)
+        y2 = hc.forward(x, residual=res, mask_out=planes_r, **kw)                        # general epilogue
+        torch.cuda.synchronize()
+        assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+        assert torch.equal(planes, want_bits(y1)) and torch.equal(planes_r, want_bits(y2))
+        assert 0.2 < float((planes != 0).float().mean()) and int(planes_r.max()) > 127 and int((planes_r & 1).sum()) > 0
+    # consumers: out_mask / res_mask as maps vs as planes
+    hc = conv.H8Conv(T(rs.randn(cout, cin, 1, 1) / np.sqrt(cin)), 1, 0, device=DEV)
+    gy = conv.to_h8(g(T(rs.randn(b, cout, h, w))), 32)
+    act = conv.to_h8(g(T(rs.randn(b, cin, h, w))), 8)                                    # the activation whose sign masks the gradient
+    res = conv.to_h8(g(T(rs.randn(b, cin, h, w))), 8)
+    bits = want_bits(act)
+    for kw in (dict(out_mask=act), dict(out_mask=act, res_mask=act, residual=res), dict(out_mask=act, mask=(2 ** 0.5, 0.2 * 2 ** 0.5))):
+        a = hc.dgrad(gy, (h, w), **kw)
+        kb = {k_: (bits if k_ in ('out_mask', 'res_mask') else v) for k_, v in kw.items()}
+        bq = hc.dgrad(gy, (h, w), mask_bits=True, **kb)
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int16), bq.view(torch.int16)), list(kw)
+    with pytest.raises((AssertionError, _lib.L2IError)):     # planes are an h8-epilogue feature: refused with the fp32 output
+        hc.dgrad(gy, (h, w), out_f32=True, out_mask=bits, mask_bits=True)
+
+
+def test_resnet16_backward_on_sign_planes_is_bit_identical():
+    """[r6] nets16.ResNet50 with the backward's ReLU masks as one-bit sign planes (written by the forward convs) against the round-5 form that reads the
+    activation maps: same masks, same launches otherwise — the image gradient must be bit-identical, at a shape with and one without stride-2 tails."""
+    from latent2im_amd import nets16, synth
+    net = nets16.ResNet50(synth.resnet50_state(seed=300), device=DEV)
+    rs = np.random.RandomState(11)
+    for size, batch in ((64, 4), (128, 2)):
+        x = T(rs.randn(batch, 3, size, size) * 0.5).to(DEV)
+        gy = T(rs.randn(batch, 40)).to(DEV)
+        grads = []
+        old = nets16.SIGN_PLANES
+        try:
+            for flag in (True, False):
+                nets16.SIGN_PLANES = flag
+                xg = x.clone().requires_grad_(True)
+                net(xg).backward(gy)
+                grads.append(xg.grad.detach().clone())
+        finally:
+            nets16.SIGN_PLANES = old
+        torch.cuda.synchronize()
+        assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
