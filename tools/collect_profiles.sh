@@ -5,7 +5,7 @@
 set -u
 CFG=${1:-c3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/${L2I_ROUND:-r05}_$CFG
+OUT=$R/gpurun_out/${L2I_ROUND:-r06}_$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
