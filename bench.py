@@ -254,7 +254,7 @@ def roofline_block(prof, steps, tag, workload_key, t_events, ev_steps=None):
     peak_all = max(f['peak_tflops'] for f in fams)
     traffic, traffic_note = None, 'no PMC summary under profiles/ for these kernel sources and this workload'
     src = source_hash()
-    for rnd in ('r05', 'r04', 'r03'):
+    for rnd in ('r06', 'r05', 'r04', 'r03'):
         tp = os.path.join(ROOT, 'profiles', '%s_%s_hbm_traffic.json' % (rnd, tag))
         if not os.path.isfile(tp):
             continue
