@@ -667,13 +667,14 @@ def test_fp16_guarded_adam_matches_torch_adam_and_skips_nonfinite_steps():
         assert float((p - q).abs().max()) < 1e-6
 
 
-def test_fp16_overflow_guard_skips_steps_and_backs_the_scale_off(monkeypatch):
+@pytest.mark.parametrize('hipgraph', [False, True], ids=['eager', 'hipgraph'])
+def test_fp16_overflow_guard_skips_steps_and_backs_the_scale_off(monkeypatch, hipgraph):
     """The whole fp16 training step with the static exponents forced 13 octaves too high (L2I_F16_SCALES; the calibrated ones leave eleven octaves of
     headroom): the scaled gradient maps overflow fp16, the walk gradient comes back non-finite, and — instead of inf / NaN going straight into Adam as in
     round 5 — the step is skipped (walk and moments untouched), the dynamic factor halves step by step until the maps fit, and from then on the walk
     trains on gradients that agree with a run at the calibrated exponents.  No host read anywhere in the step (the same code path replays from the
     hipGraph: test_fp16_hipgraph_captured_steps_follow_eager_steps)."""
-    from latent2im_amd import constants, nets16, selfcheck, synth
+    from latent2im_amd import capture, constants, nets16, selfcheck, synth
     old = conv.PRECISION
     attrs = ['dirty', 'daylight', 'night', 'sunrisesunset', 'dawndusk']
     size, batch = 64, 4
@@ -692,8 +693,14 @@ def test_fp16_overflow_guard_skips_steps_and_backs_the_scale_off(monkeypatch):
         assert hot.loss_scaler.log2 == {k: v + 13 for k, v in base.items()}
         w0 = hot.walk.w.detach().clone()
         skipped, first_clean = 0, None
+        # hipgraph: forward + backward replayed from ONE captured graph — the dynamic factor is a device tensor the captured multiplies read, so every
+        # replay sees the value the guarded optimiser tail (outside the graph) left behind
+        cs = capture.CapturedStep(hot, batch, 5, clamp=True) if hipgraph else None
         for i in range(16):
-            r = selfcheck.run_step(hot, zs, alpha, clamp=True)
+            r = cs(zs, alpha) if hipgraph else selfcheck.run_step(hot, zs, alpha, clamp=True)
+            torch.cuda.synchronize()
+            if hipgraph:
+                r = dict(r, grad=r['grad'].detach().clone())
             finite = bool(torch.isfinite(r['grad']).all())
             assert bool(torch.isfinite(hot.walk.w).all())                           # whatever the gradient held, the walk never sees it
             if not finite:
