@@ -604,7 +604,11 @@ def main():
             roof5 = roofline_block(prof5, min(a.event_steps, a.config5_steps), 'c5', w5.key(), t_ev5, ev5) if rk == 0 else None
         cfg5 = dict(value=round(global_b * a.config5_steps / el5, 3), unit='images/s', ms_per_step=round(el5 / a.config5_steps * 1e3, 2),
                     steps=a.config5_steps, warmup_steps_run=warm5, dtype=C5_PRECISION, baseline_config='configs[4] per-GPU shape',
-                    workload=w5.describe(False, a.noise_strength, True), loss=float(r5['loss']), roofline=roof5, **step_stats(ms5))
+                    workload=w5.describe(False, a.noise_strength, True), loss=float(r5['loss']), roofline=roof5,
+                    # fp16: the dynamic loss scale after every step this workload ran (warm-up, timed, event pass): `skipped` = optimiser steps the device-side
+                    # overflow guard dropped (read after the timed regions: the guard itself never synchronises)
+                    loss_scale=(dict(w5.g.loss_scaler.stats(), static_log2=dict(w5.g.loss_scaler.log2)) if getattr(w5.g, 'loss_scaler', None) is not None else None),
+                    **step_stats(ms5))
         if reg is not None:
             reg[C5_PRECISION] = dict(quick_rate(w5.stepper(reg_only=True), 5, global_b, dev, a.max_ahead), workload=w5.describe(True, a.noise_strength, True))
             if not a.no_kernel_events:
@@ -635,6 +639,7 @@ def main():
         json.dump(rows, open(a.dump_launches, 'w'), indent=0)
     if prof:
         roof = roofline_block(prof, n_ev, 'c5' if c5 else 'c3', wkey3, t_events, ev_steps)
+    ls_main = dict(wl.g.loss_scaler.stats(), static_log2=dict(wl.g.loss_scaler.log2)) if getattr(wl.g, 'loss_scaler', None) is not None else None
     out = dict(metric='edited images/sec', value=round(value, 3), unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
                ms_per_step=round(ms_per_step, 2), higher_is_better=True, scaling='weak', vs_baseline=None, dtype=precision,
                data='synthetic',
@@ -648,7 +653,7 @@ def main():
                             note='shader clock (MHz) / socket power (W) of this rank\'s GPU; during_timed only when the sysfs files are readable '
                                  '(no subprocess between steps); the host is up to max_steps_ahead steps ahead of the GPU when it samples'),
                allocator=alloc,
-               roofline=roof, config5=cfg5, reg_only=reg, batch_sweep=sweep,
+               roofline=roof, config5=cfg5, reg_only=reg, batch_sweep=sweep, loss_scale=ls_main,
                ranks_seen=ranks, per_rank_ms_per_step=per_rank_ms, allreduce_us=None if allreduce_us is None else round(allreduce_us, 1),
                allreduce_note=allreduce_note)
     if world == 1 and a.cpu_baseline_s > 0:
