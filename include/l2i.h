@@ -199,10 +199,12 @@ int l2i_cast_f32_to_h8(void* y, const float* x, int B, int C, int Cpad, int64_t 
 int l2i_cast_h8_to_f32(float* y, const void* x, int B, int C, int Cpad, int64_t HW, void* stream);
 int l2i_upfirdn2d_h8(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
-                     float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, void* stream);
+                     float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, int mask_bits,
+                     void* stream);
                      /* ... then * (mask > 0 ? mask_pos : mask_neg) (h8, like y: a gradient through a (leaky) ReLU) and + addend (h8, like y).
                         k1y / k1x: HOST pointers to four floats each, or NULL: the caller states that k = outer(k1y, k1x) (4x4, up = down = 1: the
-                        register-streaming separable kernel) */
+                        register-streaming separable kernel).  [ABI 6] mask_bits = 1: `mask` is the SIGN PLANE of that map (one byte per pixel slot,
+                        l2i_conv_params::mask_out) — separable 4x4 blur without resampling only */
 int l2i_torgb_fwd_h8(float* rgb, const void* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream);
 int l2i_sg2_act_bwd_h8(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
                        const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, float* red_gin_y, int B, int C, int64_t HW, void* stream);
@@ -213,6 +215,7 @@ int l2i_maxpool2d_bwd_h8(void* gx, const void* gy, const void* idx, const void* 
 int l2i_sqdiff_h8(float* sum_out, void* grad, const void* a, const void* b, int64_t slots, float coef, const float* coef_dev, void* stream);
 int l2i_add_zero_insert_h8(void* y, const void* c, const void* mask, int64_t planes, int H, int W, int OH, int OW, void* stream);   /* mask (h8 like y, or NULL): c * (mask[2oy,2ox] > 0) */
 int l2i_mask_mul_h8(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream);                     /* y = g * (ref > 0 ? pos : neg) */
+int l2i_mask_mul_bits_h8(void* y, const void* g, const void* bits, float pos, float neg, int64_t slots, void* stream);               /* [ABI 6] the same with ref's sign plane (one byte per slot) */
 int l2i_modulate_planes_h8(void* planes, const float* w32, const float* s, int B, int Cs, int CinP, int KK, int CoutP, void* stream);
 /* [r5] l2i_modulate_planes_h8 for every modulated conv of a generator pass in one launch.  `table` (device): nseg rows of eight int64 — w32 offset
  * (floats from `w32`), scale offset (floats from `s`: the layer's [B, Cs] block), output offset (16-byte slots from `planes`: the layer's
@@ -231,7 +234,8 @@ int l2i_cast_f32_to_h8_f16(void* y, const float* x, int B, int C, int Cpad, int6
 int l2i_cast_h8_to_f32_f16(float* y, const void* x, int B, int C, int Cpad, int64_t HW, void* stream);
 int l2i_upfirdn2d_h8_f16(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
                          int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
-                         float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, void* stream);
+                         float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, int mask_bits,
+                         void* stream);
 int l2i_torgb_fwd_h8_f16(float* rgb, const void* x, const float* wmod, const float* bias, int B, int C, int64_t HW, void* stream);
 int l2i_sg2_act_bwd_h8_f16(void* dz, const void* gin, const float* gin_scale, const float* grgb, const float* wmod_rgb, const void* y, const float* bias,
                            const float* noise, float noise_w, float slope, float gain, float* red_dz_z, float* red_x_grgb, float* red_gin_y, int B, int C, int64_t HW, void* stream);
@@ -242,6 +246,7 @@ int l2i_maxpool2d_bwd_h8_f16(void* gx, const void* gy, const void* idx, const vo
 int l2i_sqdiff_h8_f16(float* sum_out, void* grad, const void* a, const void* b, int64_t slots, float coef, const float* coef_dev, void* stream);
 int l2i_add_zero_insert_h8_f16(void* y, const void* c, const void* mask, int64_t planes, int H, int W, int OH, int OW, void* stream);
 int l2i_mask_mul_h8_f16(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream);
+int l2i_mask_mul_bits_h8_f16(void* y, const void* g, const void* bits, float pos, float neg, int64_t slots, void* stream);
 int l2i_modulate_planes_h8_f16(void* planes, const float* w32, const float* s, int B, int Cs, int CinP, int KK, int CoutP, void* stream);
 int l2i_modulate_planes_multi_h8_f16(void* planes, const float* w32, const float* s, const void* table, int nseg, int B, int nblocks, void* stream);
 
@@ -403,7 +408,7 @@ int l2i_adam_guarded_f32(float* p, const float* g, float* m, float* v, float* st
 
 const char* l2i_last_error(void);
 /* Bumped whenever a struct of this header grows or an entry point changes meaning (1: round 1-2; 2: round 3, l2i_conv_params gained w_bstride /
- * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32, mask_out / mask_bits fields).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
+ * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32, mask_out / mask_bits fields, l2i_mask_mul_bits_h8, the mask_bits argument of l2i_upfirdn2d_h8).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
 #define L2I_ABI_VERSION 6
 int l2i_abi_version(void);
 int l2i_sizeof_conv_params(void);       /* sizeof(struct l2i_conv_params) of THIS build */

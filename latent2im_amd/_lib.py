@@ -94,7 +94,7 @@ _SIGNATURES = {
     'l2i_pool2x2_f32': (c_i, [c_p, c_p, c_l, c_i, c_i, c_f, c_p]),
     'l2i_cast_f32_to_h8': (c_i, [c_p, c_p, c_i, c_i, c_i, c_l, c_p]),
     'l2i_cast_h8_to_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_l, c_p]),
-    'l2i_upfirdn2d_h8': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_f, c_p, c_i, c_f, c_f, c_p, c_f, c_f, c_p, c_p, c_p, c_p]),
+    'l2i_upfirdn2d_h8': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_f, c_p, c_i, c_f, c_f, c_p, c_f, c_f, c_p, c_p, c_p, c_i, c_p]),
     'l2i_torgb_fwd_h8': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
     'l2i_sg2_act_bwd_h8': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
     'l2i_dot_reduce_h8': (c_i, [c_p, c_p, c_p, c_i, c_i, c_l, c_p]),
@@ -103,6 +103,7 @@ _SIGNATURES = {
     'l2i_sqdiff_h8': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p]),
     'l2i_add_zero_insert_h8': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p]),
     'l2i_mask_mul_h8': (c_i, [c_p, c_p, c_p, c_f, c_f, c_l, c_p]),
+    'l2i_mask_mul_bits_h8': (c_i, [c_p, c_p, c_p, c_f, c_f, c_l, c_p]),
     'l2i_modulate_planes_h8': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'l2i_modulate_planes_multi_h8': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     'l2i_segmented_matvec_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),

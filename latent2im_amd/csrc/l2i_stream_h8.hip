@@ -169,7 +169,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_h8_kernel(u32x4* __restrict__ y
 __device__ __forceinline__ float lane_shr1(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x138, 0xf, 0xf, false));   // wave_shr:1 (lane 0 gets 0)
 }
-template <int RB>
+// MBITS [r6]: `mask` is a sign plane (one byte per pixel slot, bit e = element e > 0: l2i.h, l2i_conv_params::mask_out) instead of an h8 map — the
+// discriminator's conv1 outputs are read by this kernel for their signs only (1/16 of the bytes)
+template <int RB, bool MBITS = false>
 __global__ __launch_bounds__(256) void upfirdn2d_h8_sep4_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ x, float4 ty, float4 tx, long long planes, int G8, int in_h, int in_w,
                                                                 int out_h, int out_w, int pad_x0, int pad_y0, const float* __restrict__ noise, float noise_w,
                                                                 const float* __restrict__ bias, int act, float slope, float gain, const u32x4* __restrict__ mask, float mpos,
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_h8_sep4_kernel(u32x4* __restric
             const bool ok = lane_out && oy < out_h;
             const long long o = ok ? (pl * out_h + oy) * out_w + ox : 0;
             if (noise) nzq[slot] = noise[ok ? (b * out_h + oy) * out_w + ox : 0];
-            if (mask) mq[slot] = mask[o];
+            if (mask) { if (MBITS) mq[slot].x = reinterpret_cast<const uint8_t*>(mask)[o]; else mq[slot] = mask[o]; }
             if (addend) aq[slot] = addend[o];
         };
         u32x4 q[PF];
@@ -253,10 +255,16 @@ __global__ __launch_bounds__(256) void upfirdn2d_h8_sep4_kernel(u32x4* __restric
                     }
                 }
                 if (mask) {
-                    float m[8];
-                    unpack8(mq[(i + 1) & 3], m);
+                    if (MBITS) {
+                        const unsigned mb = mq[(i + 1) & 3].x;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] *= m[e] > 0.f ? mpos : mneg;
+                        for (int e = 0; e < 8; ++e) acc[e] *= ((mb >> e) & 1u) ? mpos : mneg;
+                    } else {
+                        float m[8];
+                        unpack8(mq[(i + 1) & 3], m);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] *= m[e] > 0.f ? mpos : mneg;
+                    }
                 }
                 if (addend) {
                     float a2[8];
@@ -417,8 +425,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_h8_sep4_up2_kernel(u32x4* __res
 
 extern "C" int H8_NAME(l2i_upfirdn2d_h8)(void* y, const void* x, const float* k, int64_t planes, int channels, int in_h, int in_w, int kh, int kw, int up, int down,
                                 int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* noise, float noise_w, const float* bias, int act, float act_slope,
-                                float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, void* stream) {
+                                float act_gain, const void* mask, float mask_pos, float mask_neg, const void* addend, const float* k1y, const float* k1x, int mask_bits,
+                                void* stream) {
     if (!y || !x || !k) return l2i_set_error(L2I_E_ARG, "upfirdn2d_h8: null tensor");
+    if (mask_bits && !(mask && k1y && k1x && kh == 4 && kw == 4 && up == 1 && down == 1))
+        return l2i_set_error(L2I_E_UNSUPPORTED, "upfirdn2d_h8: a sign-plane mask rides on the separable 4x4 blur without resampling only");
     if (planes <= 0 || channels <= 0 || (channels % 8) != 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0 || kh > 4 || kw > 4 || (up != 1 && up != 2) || (down != 1 && down != 2))
         return l2i_set_error(L2I_E_ARG, "upfirdn2d_h8: kernels up to 4x4, up / down in {1, 2}, channels % 8 == 0");
     const int out_h = (in_h * up + pad_y0 + pad_y1 - kh) / down + 1, out_w = (in_w * up + pad_x0 + pad_x1 - kw) / down + 1;
@@ -429,6 +440,11 @@ extern "C" int H8_NAME(l2i_upfirdn2d_h8)(void* y, const void* x, const float* k,
         constexpr int RB = 16;
         const float4 ty = make_float4(k1y[3], k1y[2], k1y[1], k1y[0]), tx = make_float4(k1x[3], k1x[2], k1x[1], k1x[0]);
         const long long waves = (long long)planes * ((out_h + RB - 1) / RB) * ((out_w + 60) / 61);
+        if (mask_bits)
+            hipLaunchKernelGGL((upfirdn2d_h8_sep4_kernel<RB, true>), dim3(l2i_grid_for(waves, 4, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)x, ty, tx,
+                               (long long)planes, channels / 8, in_h, in_w, out_h, out_w, pad_x0, pad_y0, noise, noise_w, bias, act, act_slope, act_gain, (const u32x4*)mask,
+                               mask_pos, mask_neg, (const u32x4*)addend);
+        else
         hipLaunchKernelGGL((upfirdn2d_h8_sep4_kernel<RB>), dim3(l2i_grid_for(waves, 4, 256 * 64)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)x, ty, tx,
                            (long long)planes, channels / 8, in_h, in_w, out_h, out_w, pad_x0, pad_y0, noise, noise_w, bias, act, act_slope, act_gain, (const u32x4*)mask,
                            mask_pos, mask_neg, (const u32x4*)addend);
@@ -911,6 +927,24 @@ __global__ __launch_bounds__(256) void mask_mul_h8_kernel(u32x4* __restrict__ y,
         for (int e = 0; e < 8; ++e) a[e] *= m[e] > 0.f ? pos : neg;
         y[i] = pack8(a);
     }
+}
+// [r6] the same with `ref` given as its sign plane (one byte per slot)
+__global__ __launch_bounds__(256) void mask_mul_bits_h8_kernel(u32x4* __restrict__ y, const u32x4* __restrict__ g, const uint8_t* __restrict__ bits, float pos, float neg, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float a[8];
+        unpack8(g[i], a);
+        const unsigned mb = bits[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] *= ((mb >> e) & 1u) ? pos : neg;
+        y[i] = pack8(a);
+    }
+}
+extern "C" int H8_NAME(l2i_mask_mul_bits_h8)(void* y, const void* g, const void* bits, float pos, float neg, int64_t slots, void* stream) {
+    if (!y || !g || !bits || slots <= 0) return l2i_set_error(L2I_E_ARG, "mask_mul_bits_h8: bad arguments");
+    hipLaunchKernelGGL(mask_mul_bits_h8_kernel, dim3(l2i_grid_for(slots, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (u32x4*)y, (const u32x4*)g, (const uint8_t*)bits, pos, neg,
+                       (long long)slots);
+    L2I_CHECK_LAUNCH();
+    return L2I_OK;
 }
 extern "C" int H8_NAME(l2i_mask_mul_h8)(void* y, const void* g, const void* ref, float pos, float neg, int64_t slots, void* stream) {
     if (!y || !g || !ref || slots <= 0) return l2i_set_error(L2I_E_ARG, "mask_mul_h8: bad arguments");

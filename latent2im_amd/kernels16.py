@@ -66,7 +66,7 @@ def cast_from_h8(t, channels=None):
 
 
 def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0, 0, 0), noise=None, noise_w=0.0, bias=None, act=ACT_NONE, slope=0.2, gain=1.0, mask=None, mask_vals=(1.0, 0.0),
-              addend=None, sep=None):
+              addend=None, sep=None, mask_bits=False):
     """x h8; pad = (x0, x1, y0, y1) as in op/upfirdn2d.cpp:12-23; optional fused epilogue act(fir(x) + noise*noise_w + bias[c]) * gain, then
     * (mask > 0 ? mask_vals[0] : mask_vals[1]) and + addend (both h8, shaped like the output).  ``sep`` = separable(kernel) (4x4, no resampling): the
     register-streaming separable kernel."""
@@ -80,9 +80,9 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0, 0, 0), noise=None, noise_w=0.0
     k1y = (ctypes.c_float * 4)(*sep[0]) if use_sep else None
     k1x = (ctypes.c_float * 4)(*sep[1]) if use_sep else None
     _lib.check(_fn(lib, 'l2i_upfirdn2d_h8', x.dtype)(_lib.ptr(y), _h8(x), _lib.fptr(kernel.contiguous()), B * G8, G8 * 8, H, W, kh, kw, up, down, pad[0], pad[1], pad[2], pad[3],
-                                    _lib.fptr(noise), float(noise_w), _lib.fptr(bias), int(act), float(slope), float(gain), None if mask is None else _h8(mask),
-                                    float(mask_vals[0]), float(mask_vals[1]), None if addend is None else _h8(addend), k1y, k1x, _lib.stream_ptr()), 'l2i_upfirdn2d_h8')
-    assert (mask is None or mask.shape == y.shape) and (addend is None or addend.shape == y.shape)
+                                    _lib.fptr(noise), float(noise_w), _lib.fptr(bias), int(act), float(slope), float(gain), None if mask is None else (_lib.ptr(mask) if mask_bits else _h8(mask)),
+                                    float(mask_vals[0]), float(mask_vals[1]), None if addend is None else _h8(addend), k1y, k1x, int(bool(mask_bits)), _lib.stream_ptr()), 'l2i_upfirdn2d_h8')
+    assert (mask is None or tuple(mask.shape) == (tuple(y.shape[:4]) if mask_bits else tuple(y.shape))) and (addend is None or addend.shape == y.shape)
     return y
 
 
@@ -153,9 +153,13 @@ def add_zero_insert(y, c, mask=None):
 
 
 def mask_mul(g, ref, pos=1.0, neg=0.0):
-    """g * (ref > 0 ? pos : neg) on h8 maps."""
+    """g * (ref > 0 ? pos : neg) on h8 maps; ``ref`` may be the map or ([r6]) its sign plane (uint8 [B, C/8, H, W]: l2i_conv_params::mask_out)."""
     lib = _lib.load()
     y = torch.empty_like(g)
+    if ref.dtype == torch.uint8:
+        assert tuple(ref.shape) == tuple(g.shape[:4]) and ref.is_contiguous()
+        _lib.check(_fn(lib, 'l2i_mask_mul_bits_h8', g.dtype)(_lib.ptr(y), _h8(g), _lib.ptr(ref), float(pos), float(neg), g.numel() // 8, _lib.stream_ptr()), 'l2i_mask_mul_bits_h8')
+        return y
     _lib.check(_fn(lib, 'l2i_mask_mul_h8', g.dtype)(_lib.ptr(y), _h8(g), _h8(ref), float(pos), float(neg), g.numel() // 8, _lib.stream_ptr()), 'l2i_mask_mul_h8')
     return y
 

@@ -402,17 +402,20 @@ class _DBody16Fn(torch.autograd.Function):
             y0 = net.conv0.forward(K16.cast_to_h8(x, 32, dtype=net.dtype), bias=net.bias0, **lr)
         saved = [y0]
         cur = y0
+        bits = keep and SIGN_PLANES                    # [r6] the backward needs the SIGNS of y1 / y2 only: the convs write their sign planes, the maps are not kept
         for blk in net.blocks:
             h = cur.shape[2]
-            y1 = blk['c1'].forward(cur, bias=blk['b1'], **lr)
+            m1 = torch.empty(cur.shape[0], blk['c1'].cout // 8, h, cur.shape[3], device=cur.device, dtype=torch.uint8) if bits else None
+            m2 = torch.empty(cur.shape[0], blk['c2'].cout // 8, h // 2, cur.shape[3] // 2, device=cur.device, dtype=torch.uint8) if bits else None
+            y1 = blk['c1'].forward(cur, bias=blk['b1'], mask_out=m1, **lr)
             t = K16.upfirdn2d(y1, blk['k'], pad=(2, 2, 2, 2), sep=blk['ksep'])  # Blur before the stride-2 3x3 (networks.py:530-536): (h+1)^2
-            y2 = blk['c2'].forward(t, bias=blk['b2'], **lr)
+            y2 = blk['c2'].forward(t, bias=blk['b2'], mask_out=m2, **lr)
             del t
             ts = K16.upfirdn2d(cur, blk['k'], down=2, pad=(1, 1, 1, 1), sep=blk['ksep'])          # skip (networks.py:586-590): the blur only where the stride-2 1x1 samples it
             out = blk['sk1'].forward(ts, residual=y2, out_gain=1.0 / SQRT2)      # (conv2 + skip) / sqrt2
             del ts
             if keep:
-                saved.append((y1, y2, (h, cur.shape[3])))
+                saved.append((m1, m2, (h, cur.shape[3])) if bits else (y1, y2, (h, cur.shape[3])))
             cur = out
             _probe('D.fwd.out@%d' % h, out)
         ctx.net, ctx.saved, ctx.in_hw = net, saved if keep else None, (x.shape[2], x.shape[3])
@@ -434,7 +437,7 @@ class _DBody16Fn(torch.autograd.Function):
             gm = K16.mask_mul(g, y2, bg, 0.2 * bg)                                # 1/sqrt2 * lrelu' * sqrt2 on the conv2 branch (g also feeds the skip branch)
             g_t = blk['c2'].dgrad(gm, (h + 1, h + 1))
             del gm
-            g_y1 = K16.upfirdn2d(g_t, blk['kf'], pad=(1, 1, 1, 1), mask=y1, mask_vals=LRELU_MASK, sep=blk['kfsep'])
+            g_y1 = K16.upfirdn2d(g_t, blk['kf'], pad=(1, 1, 1, 1), mask=y1, mask_vals=LRELU_MASK, sep=blk['kfsep'], mask_bits=y1.dtype == torch.uint8)
             del g_t
             g_a = blk['c1'].dgrad(g_y1, in_hw)
             del g_y1

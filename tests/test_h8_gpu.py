@@ -841,3 +841,36 @@ def test_resnet16_backward_on_sign_planes_is_bit_identical():
             nets16.SIGN_PLANES = old
         torch.cuda.synchronize()
         assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
+
+
+def test_discriminator16_backward_on_sign_planes_is_bit_identical():
+    """[r6] nets16.Discriminator with the leaky-ReLU masks of its backward as sign planes (conv1 / conv2 of every block write them; the masked blur and
+    mask_mul read them) against the round-5 form on the maps: bit-identical image gradient; and the two stream kernels against their map forms."""
+    from latent2im_amd import kernels16 as K16, nets16, synth
+    rs = np.random.RandomState(3)
+    g = lambda t: t.to(DEV)
+    x = conv.to_h8(g(T(rs.randn(2, 64, 21, 37))), 8)
+    ref = conv.to_h8(g(T(rs.randn(2, 64, 21, 37))), 8)
+    pos = (ref.float() > 0).to(torch.int32)
+    bits = sum(pos[..., e] << e for e in range(8)).to(torch.uint8).contiguous()
+    assert torch.equal(K16.mask_mul(x, ref, 1.5, 0.3).view(torch.int16), K16.mask_mul(x, bits, 1.5, 0.3).view(torch.int16))
+    k = T(np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0).to(DEV)
+    sep = K16.separable(k)
+    a = K16.upfirdn2d(x, k, pad=(1, 2, 2, 1), mask=ref, mask_vals=(2 ** 0.5, 0.2 * 2 ** 0.5), sep=sep)
+    b = K16.upfirdn2d(x, k, pad=(1, 2, 2, 1), mask=bits, mask_vals=(2 ** 0.5, 0.2 * 2 ** 0.5), sep=sep, mask_bits=True)
+    assert a.shape == ref.shape and torch.equal(a.view(torch.int16), b.view(torch.int16))
+    for size, batch in ((64, 4), (128, 4)):
+        net = nets16.Discriminator(synth.discriminator_state(size, seed=200), size, device=DEV)
+        img = T(rs.randn(batch, 3, size, size) * 0.5).to(DEV)
+        grads = []
+        old = nets16.SIGN_PLANES
+        try:
+            for flag in (True, False):
+                nets16.SIGN_PLANES = flag
+                xg = img.clone().requires_grad_(True)
+                net(xg).sum().backward()
+                grads.append(xg.grad.detach().clone())
+        finally:
+            nets16.SIGN_PLANES = old
+        torch.cuda.synchronize()
+        assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
