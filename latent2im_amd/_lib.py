@@ -67,6 +67,7 @@ _SIGNATURES = {
     'l2i_conv2d_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv_transpose2d_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv_img_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
+    'l2i_conv1x1_pair_h8': (c_i, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvParams), c_i, c_p]),
     'l2i_fused_bias_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
     'l2i_fused_bias_act_f16': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
     'l2i_upfirdn2d_f16': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -118,7 +119,7 @@ _SIGNATURES = {
 for _n in [k for k in _SIGNATURES if k.endswith('_h8') or k in ('l2i_cast_f32_to_h8', 'l2i_cast_h8_to_f32')]:
     _SIGNATURES[_n + '_f16'] = _SIGNATURES[_n]
 
-ABI_VERSION = 6          # L2I_ABI_VERSION of include/l2i.h this binding mirrors
+ABI_VERSION = 7          # L2I_ABI_VERSION of include/l2i.h this binding mirrors
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -736,8 +736,9 @@ H8Conv.dgrad_compact = _h8_dgrad_compact
 
 def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=0, out_f32=False, out_scale=None, noise=None, noise_w=0.0, bias=None,
            residual=None, res_mask=None, out_mask=None, mask=(1.0, 0.0), act=ACT_NONE, slope=0.2, gain=1.0, out_gain=1.0, accumulate=False, res_sub=None, res_coef=1.0,
-           res_coef_dev=None, sq=None, relu_in=False, rgb=None, mask_out=None, mask_bits=False):
-    """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels."""
+           res_coef_dev=None, sq=None, relu_in=False, rgb=None, mask_out=None, mask_bits=False, _defer=None):
+    """Enqueue l2i_conv2d_h8 / l2i_conv_transpose2d_h8 on the current stream.  x: h8 bf16 with ``cin`` (multiple of 32) channels.
+    ``_defer``: a list — the filled parameter struct is appended to it instead of being launched (``launch_pair_h8`` launches two of them as one kernel)."""
     lib = _lib.load()
     B, cg, H, W, _ = x.shape
     assert x.dtype in (torch.bfloat16, torch.float16) and cg * 8 == cin and cin % 16 == 0, (x.dtype, x.shape, cin)
@@ -788,6 +789,10 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
         assert not transposed and not out_f32 and cout in (32, 64) and tuple(rgb[0].shape) == (B, 3, cout) and tuple(rgb[2].shape) == (B, 3, OHf, OWf)
         p.rgb_w, p.rgb_bias, p.rgb_out = _lib.fptr(rgb[0]), _lib.fptr(rgb[1]), _lib.fptr(rgb[2])
     name = ('l2i_conv_transpose2d_h8' if transposed else 'l2i_conv2d_h8') + ('_f16' if f16 else '')
+    if _defer is not None:
+        assert not transposed
+        _defer.append((p, f16, (planes, x, y, residual, res_mask, out_mask, mask_out, bias), ''.join(c for c, t in zip('brmo', (bias, residual, res_mask, out_mask)) if t is not None) + str(act)))
+        return y
     entry = getattr(lib, name)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -801,3 +806,36 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
         return y
     _lib.check(entry(p, _lib.stream_ptr()), name)
     return y
+
+
+PAIR_VARIANT = int(_os.environ.get('L2I_H8_PAIR_TILE', '-1'))      # -1: by map size (launch_pair_h8); 0 / 1: l2i_conv1x1_pair_h8's variant argument
+
+
+PAIR_SHAPES = ((64, 64), (128, 128), (256, 256), (64, 128), (128, 256))          # (input channels of the first conv, output channels of the second) l2i_conv1x1_pair_h8 is built for
+
+
+def pair_h8_shapes_ok(cin1, cout1, cout2, npix):
+    """Does l2i_conv1x1_pair_h8 take two chained 1x1 stride-1 convs cin1 -> cout1 -> cout2 on maps of ``npix`` pixels (include/l2i.h lists the conditions)?"""
+    return (cin1, cout2) in PAIR_SHAPES and cout1 % 32 == 0 and npix % 128 == 0
+
+
+def launch_pair_h8(deferred, variant=None):
+    """``deferred``: the two structs ``run_h8(..., _defer=deferred)`` left (first conv, then the conv that reads its output): ONE launch of
+    l2i_conv1x1_pair_h8 on the current stream.  Raises L2IError when the library refuses the pair (the caller checks ``pair_h8_eligible`` shapes first)."""
+    lib = _lib.load()
+    (p1, f16, keep1, fl1), (p2, f16b, keep2, fl2) = deferred
+    assert f16 == f16b
+    name = 'l2i_conv1x1_pair_h8' + ('_f16' if f16 else '')
+    entry = getattr(lib, name)
+    npix = int(p1.H) * int(p1.W)
+    if variant is None:
+        variant = PAIR_VARIANT if PAIR_VARIANT >= 0 else (1 if int(p1.B) * npix < 256 * 1024 else 0)      # 128-pixel tiles below 1024 blocks of 256 pixels
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(entry(p1, p2, int(variant), _lib.stream_ptr()), name)
+        e1.record()
+        B, c1, c2, c3 = int(p1.B), int(p1.Cin), int(p1.Cout), int(p2.Cout)
+        PROFILE.append((e0, e1, 2.0 * B * npix * (c1 * c2 + c2 * c3), (B, c1, c2, 1, 1, 1, int(p1.H), int(p1.W), int(p1.H), int(p1.W), 1, False, False, fl1 + '+' + fl2, c3), name, 'conv_h8'))            # (priced in the conv_h8 family: its 1x1 launches are what it replaces; bench.call_bytes knows the entry name)
+        return
+    _lib.check(entry(p1, p2, int(variant), _lib.stream_ptr()), name)

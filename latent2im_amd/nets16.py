@@ -51,6 +51,7 @@ RGB_FUSED = os.environ.get('L2I_H8_RGB_FUSED', '1') != '0'
 # [r6] ResNet-50's backward reads one-bit sign planes written by the forward convs instead of the activation maps themselves (l2i.h: mask_out / mask_bits).
 # L2I_H8_SIGN_PLANES=0: the maps, as in round 5 (A/B).
 SIGN_PLANES = os.environ.get('L2I_H8_SIGN_PLANES', '1') != '0'
+PAIR = os.environ.get('L2I_H8_PAIR', '1') != '0'          # [r6] ResNet-50's trunk: chained 1x1 convs as one launch (csrc/l2i_pair_h8.hip); 0: separate launches (A/B)
 # [r5] the per-sample weight planes of all modulated convs of a pass in ONE launch (kernels16.ModulatePlan) instead of one 15 us launch per layer and
 # pass (51 per step).  L2I_H8_MOD_MULTI=0: per layer (A/B).
 MOD_MULTI = os.environ.get('L2I_H8_MOD_MULTI', '1') != '0'
@@ -261,19 +262,33 @@ class _ResNet16Fn(torch.autograd.Function):
         bits = keep and SIGN_PLANES
         plane = lambda t: torch.empty(t.shape[:4], device=t.device, dtype=torch.uint8)
         n_blk = len(net.blocks)
+        # [r6] PAIR: conv3 + identity + ReLU of a block and conv1 + ReLU of the NEXT block as one launch (l2i_conv1x1_pair_h8: the wide map goes from the first
+        # conv's epilogue to the second conv's MFMAs in registers, written once, never read back) where the library has the shape; bit-identical
+        ahead = None                                       # (y1, its sign plane) of this block when the previous block's pair launch already produced it
         for bi, blk in enumerate(net.blocks):
+            hw_in = (cur.shape[2], cur.shape[3])
+            s2 = blk['c2'].conv.stride
+            hw_out = (hw_in[0] // s2, hw_in[1] // s2)
             if bits:
-                hw_in = (cur.shape[2], cur.shape[3])
-                s2 = blk['c2'].conv.stride
-                m1 = torch.empty(cur.shape[0], blk['c1'].conv.cout // 8, hw_in[0], hw_in[1], device=cur.device, dtype=torch.uint8)
-                m2 = torch.empty(cur.shape[0], blk['c2'].conv.cout // 8, hw_in[0] // s2, hw_in[1] // s2, device=cur.device, dtype=torch.uint8)
-                mo = torch.empty(cur.shape[0], blk['c3'].conv.cout // 8, hw_in[0] // s2, hw_in[1] // s2, device=cur.device, dtype=torch.uint8)
+                m1 = ahead[1] if ahead is not None else torch.empty(cur.shape[0], blk['c1'].conv.cout // 8, hw_in[0], hw_in[1], device=cur.device, dtype=torch.uint8)
+                m2 = torch.empty(cur.shape[0], blk['c2'].conv.cout // 8, hw_out[0], hw_out[1], device=cur.device, dtype=torch.uint8)
+                mo = torch.empty(cur.shape[0], blk['c3'].conv.cout // 8, hw_out[0], hw_out[1], device=cur.device, dtype=torch.uint8)
             else:
                 m1 = m2 = mo = None
-            y1 = blk['c1'].conv.forward(cur, bias=blk['c1'].bias, act=C.ACT_RELU, mask_out=m1)
+            y1 = ahead[0] if ahead is not None else blk['c1'].conv.forward(cur, bias=blk['c1'].bias, act=C.ACT_RELU, mask_out=m1)
             y2 = blk['c2'].conv.forward(y1, bias=blk['c2'].bias, act=C.ACT_RELU, mask_out=m2)
             idt = blk['down'].conv.forward(cur, bias=blk['down'].bias) if blk['down'] is not None else cur
-            out = blk['c3'].conv.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU, mask_out=mo)
+            nxt = net.blocks[bi + 1] if bi + 1 < n_blk else None
+            ahead = None
+            if PAIR and nxt is not None and C.pair_h8_shapes_ok(blk['c3'].conv.cinp, blk['c3'].conv.cout, nxt['c1'].conv.cout, hw_out[0] * hw_out[1]):
+                m1n = torch.empty(cur.shape[0], nxt['c1'].conv.cout // 8, hw_out[0], hw_out[1], device=cur.device, dtype=torch.uint8) if bits else None
+                d = []
+                out = blk['c3'].conv.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU, mask_out=mo, _defer=d)
+                y1n = nxt['c1'].conv.forward(out, bias=nxt['c1'].bias, act=C.ACT_RELU, mask_out=m1n, _defer=d)
+                C.launch_pair_h8(d)
+                ahead = (y1n, m1n)
+            else:
+                out = blk['c3'].conv.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU, mask_out=mo)
             if bits:
                 # (kept as maps: the input of a stride-2 block — its mask rides on the zero-insertion pass — and the last output, for the first mask)
                 keep_cur = blk['down'] is not None and blk['down'].conv.stride == 2
@@ -307,6 +322,7 @@ class _ResNet16Fn(torch.autograd.Function):
         G = K16.mask_mul(g, last)                                                        # gradient w.r.t. the pre-ReLU sum of the last block
         n = len(net.blocks)
         bits = len(saved['blocks'][0]) == 5                # sign planes (forward: SIGN_PLANES)
+        ahead = None                                       # g_y2 of this block when the pair launch of the block above already produced it
         for bi in range(n - 1, -1, -1):
             blk = net.blocks[bi]
             if bits:
@@ -320,11 +336,21 @@ class _ResNet16Fn(torch.autograd.Function):
                 m = cur if bi > 0 else None                # the block input is the previous block's ReLU output (the pooled stem map is not)
                 mb = {}
             mm = dict(out_mask=m, res_mask=m, **mb) if m is not None else {}
-            g_y2 = blk['c3'].conv.dgrad(G, hw(y2), out_mask=y2, **mb)
+            g_y2 = ahead if ahead is not None else blk['c3'].conv.dgrad(G, hw(y2), out_mask=y2, **mb)
+            ahead = None
             g_y1 = blk['c2'].conv.dgrad(g_y2, hw(y1), out_mask=y1, **mb)
             del g_y2
             if blk['down'] is None:
-                Gp = blk['c1'].conv.dgrad(g_y1, cur_hw, residual=G, **mm)
+                prev = net.blocks[bi - 1]
+                # [r6] PAIR: conv1's input gradient + trunk gradient, masked, and conv3's input gradient of the block below in one launch
+                if PAIR and bits and m is not None and C.pair_h8_shapes_ok(blk['c1'].conv.coutp_in, blk['c1'].conv.cin, prev['c3'].conv.cin, cur_hw[0] * cur_hw[1]):
+                    y2p = saved['blocks'][bi - 1][2]
+                    d = []
+                    Gp = blk['c1'].conv.dgrad(g_y1, cur_hw, residual=G, _defer=d, **mm)
+                    ahead = prev['c3'].conv.dgrad(Gp, hw(y2p), out_mask=y2p, _defer=d, **mb)
+                    C.launch_pair_h8(d)
+                else:
+                    Gp = blk['c1'].conv.dgrad(g_y1, cur_hw, residual=G, **mm)
             elif blk['down'].conv.stride == 1:
                 t = blk['c1'].conv.dgrad(g_y1, cur_hw)
                 Gp = blk['down'].conv.dgrad(G, cur_hw, residual=t, **mm)

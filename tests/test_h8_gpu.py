@@ -874,3 +874,87 @@ def test_discriminator16_backward_on_sign_planes_is_bit_identical():
             nets16.SIGN_PLANES = old
         torch.cuda.synchronize()
         assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
+
+
+@pytest.mark.parametrize('c1,c2,c3,h,w,batch', [(64, 256, 64, 16, 32, 2), (128, 512, 128, 16, 16, 3), (64, 256, 128, 8, 32, 2), (64, 256, 64, 32, 40, 1), (256, 1024, 256, 16, 16, 2),
+                                                  (128, 512, 256, 8, 16, 3)])
+def test_conv1x1_pair_h8_is_bit_identical_to_two_launches(c1, c2, c3, h, w, batch):
+    """[r6] l2i_conv1x1_pair_h8 (csrc/l2i_pair_h8.hip): two chained 1x1 convs in one launch, the wide map handed from the first conv's epilogue to the second
+    conv's MFMAs in registers.  Forward form (bias + identity + ReLU + sign plane -> bias + ReLU + sign plane) and backward form (sign-plane mask on the
+    accumulator and on the trunk gradient -> sign-plane mask), both tile variants: every output and every sign plane equals the two l2i_conv2d_h8 launches'
+    bit for bit (the second conv sees the rounded 16-bit map in both, K steps accumulate in the same order)."""
+    rs = np.random.RandomState(c1 + h)
+    g = lambda t: t.to(DEV)
+    A = conv.H8Conv(T(rs.randn(c2, c1, 1, 1) / np.sqrt(c1)), 1, 0, device=DEV)
+    Bc = conv.H8Conv(T(rs.randn(c3, c2, 1, 1) / np.sqrt(c2)), 1, 0, device=DEV)
+    x = conv.to_h8(g(T(rs.randn(batch, c1, h, w))), 32)
+    res = conv.to_h8(g(T(rs.randn(batch, c2, h, w))), 8)
+    ba, bb = g(T(rs.randn(c2))), g(T(rs.randn(c3) * 0.3))
+    plane = lambda c, fill: torch.full((batch, c // 8, h, w), fill, device=DEV, dtype=torch.uint8)
+    assert conv.pair_h8_shapes_ok(c1, c2, c3, h * w)
+    # ---- forward form ----
+    m_mid, m_out = plane(c2, 0xAA), plane(c3, 0x55)
+    mid0 = A.forward(x, bias=ba, residual=res, act=conv.ACT_RELU, mask_out=m_mid)
+    out0 = Bc.forward(mid0, bias=bb, act=conv.ACT_RELU, mask_out=m_out)
+    for variant in (0, 1):
+        if variant == 0 and (h * w) % 256:
+            continue
+        pm_mid, pm_out = plane(c2, 0x11), plane(c3, 0x22)
+        d = []
+        mid1 = A.forward(x, bias=ba, residual=res, act=conv.ACT_RELU, mask_out=pm_mid, _defer=d)
+        out1 = Bc.forward(mid1, bias=bb, act=conv.ACT_RELU, mask_out=pm_out, _defer=d)
+        conv.launch_pair_h8(d, variant=variant)
+        torch.cuda.synchronize()
+        assert torch.equal(mid0.view(torch.int16), mid1.view(torch.int16)) and torch.equal(out0.view(torch.int16), out1.view(torch.int16)), variant
+        assert torch.equal(m_mid, pm_mid) and torch.equal(m_out, pm_out), variant
+        assert float(out1.float().abs().max()) > 0 and 0.1 < float((out1.float() > 0).float().mean()) < 0.9
+    # ---- backward form: G_prev = (conv of g + G) * [m > 0]; then (conv of G_prev) * [y2 > 0], no biases, no activation ----
+    bits1 = torch.from_numpy(rs.randint(0, 256, size=(batch, c2 // 8, h, w)).astype(np.uint8)).to(DEV)
+    bits2 = torch.from_numpy(rs.randint(0, 256, size=(batch, c3 // 8, h, w)).astype(np.uint8)).to(DEV)
+    mid0 = A.forward(x, residual=res, out_mask=bits1, res_mask=bits1, mask_bits=True)
+    out0 = Bc.forward(mid0, out_mask=bits2, mask_bits=True)
+    for variant in (0, 1):
+        if variant == 0 and (h * w) % 256:
+            continue
+        d = []
+        mid1 = A.forward(x, residual=res, out_mask=bits1, res_mask=bits1, mask_bits=True, _defer=d)
+        out1 = Bc.forward(mid1, out_mask=bits2, mask_bits=True, _defer=d)
+        conv.launch_pair_h8(d, variant=variant)
+        torch.cuda.synchronize()
+        assert torch.equal(mid0.view(torch.int16), mid1.view(torch.int16)) and torch.equal(out0.view(torch.int16), out1.view(torch.int16)), variant
+    # refusals: a 3x3 first conv, a residual-less first conv
+    with pytest.raises((AssertionError, _lib.L2IError)):
+        d = []
+        A.forward(x, bias=ba, act=conv.ACT_RELU, _defer=d)
+        Bc.forward(mid1, bias=bb, act=conv.ACT_RELU, _defer=d)
+        conv.launch_pair_h8(d)
+
+
+def test_resnet16_pair_launches_are_bit_identical():
+    """[r6] nets16.ResNet50 with the trunk's chained 1x1 convs as l2i_conv1x1_pair_h8 launches (nets16.PAIR) against the separate launches: predictions of the
+    no-grad pass, predictions and image gradient of the differentiable pass — bit-identical; and the pair launches are really taken at this size."""
+    from latent2im_amd import nets16, synth
+    net = nets16.ResNet50(synth.resnet50_state(seed=301), device=DEV)
+    rs = np.random.RandomState(12)
+    x = T(rs.randn(2, 3, 256, 256) * 0.5).to(DEV)
+    gy = T(rs.randn(2, 40)).to(DEV)
+    res, taken = [], []
+    old = nets16.PAIR
+    try:
+        for flag in (True, False):
+            nets16.PAIR = flag
+            conv.PROFILE = []
+            with torch.no_grad():
+                p0 = net(x).clone()
+            xg = x.clone().requires_grad_(True)
+            p1 = net(xg)
+            p1.backward(gy)
+            torch.cuda.synchronize()
+            taken.append(sum(1 for q in conv.PROFILE if q[4].startswith('l2i_conv1x1_pair_h8')))
+            conv.PROFILE = None
+            res.append((p0, p1.detach().clone(), xg.grad.detach().clone()))
+    finally:
+        nets16.PAIR, conv.PROFILE = old, None
+    assert taken[0] >= 12 and taken[1] == 0, taken          # 64^2 / 32^2 trunks at this input: layer1 + layer2 pairs of two forwards and one backward
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0

@@ -45,6 +45,8 @@ def family_of(kernel):
         return 'cin3_f32'
     if kernel.startswith('conv_direct_small_kernel'):
         return 'direct_small_valu'
+    if kernel.startswith('pair_h8_kernel'):               # [r6] two chained 1x1 convs of the 16-bit path in one launch: same family
+        return 'conv_h8'
     if kernel.startswith('conv_img_h8_kernel'):           # [r5] the image-side convs of the 16-bit path: bench.py prices them in the conv_h8 family
         return 'conv_h8'
     if kernel.startswith('conv_h8_kernel'):               # <WM, WN, K, S, TR, OUT32, RELU_IN, KS>
