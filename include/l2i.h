@@ -187,6 +187,11 @@ int l2i_conv_transpose2d_h8(const l2i_conv_params* p, void* stream);
  * planes (mask_bits), H * W a multiple of 128, (Cin1, Cout2) one of (64, 64), (128, 128), (256, 256), (64, 128), (128, 256) — the caller then launches the two convs separately.
  * variant: 0 = 256-pixel tiles, 1 = 128-pixel tiles (more blocks on small maps). */
 int l2i_conv1x1_pair_h8(const l2i_conv_params* first, const l2i_conv_params* second, int variant, void* stream);
+/* The same launch with the 3x3 stride-1 pad-1 conv in FRONT of the pair: head3x3 (C -> C, C <= 128 here: bias / ReLU / sign-plane mask / sign-plane output; its
+ * map is written only if head3x3->y is set) -> first -> second: one launch per ResNet-50 bottleneck (conv2, conv3 + identity, the next block's conv1; backwards:
+ * conv2's input gradient, conv1's + trunk gradient, conv3's of the block below).  The 3x3 runs exactly as l2i_conv2d_h8 would (16-channel chunks), so the
+ * three results equal the three launches' bit for bit.  Needs W % 32 == 0, H % 4 == 0 and (C, Cout2) one of (64, 64), (128, 128), (64, 128). */
+int l2i_conv_chain3_h8(const l2i_conv_params* head3x3, const l2i_conv_params* first, const l2i_conv_params* second, int variant, void* stream);
 
 /* [r5] The image-side convolutions of the 16-bit path (csrc/l2i_img_h8.hip): x = fp32 NCHW image [B, Cin <= 4, H, W], y = 16-bit h8
  * [B, Cout/8, OHf, OWf, 8], 16-bit MFMA with fp32 accumulation on operands rounded to the element type inside the kernel — VGG-19 conv1_1
@@ -240,6 +245,7 @@ int l2i_modulate_planes_multi_h8(void* planes, const float* w32, const float* s,
 int l2i_conv2d_h8_f16(const l2i_conv_params* p, void* stream);
 int l2i_conv_transpose2d_h8_f16(const l2i_conv_params* p, void* stream);
 int l2i_conv1x1_pair_h8_f16(const l2i_conv_params* first, const l2i_conv_params* second, int variant, void* stream);
+int l2i_conv_chain3_h8_f16(const l2i_conv_params* head3x3, const l2i_conv_params* first, const l2i_conv_params* second, int variant, void* stream);
 int l2i_conv_img_h8_f16(const l2i_conv_params* p, void* stream);
 int l2i_cast_f32_to_h8_f16(void* y, const float* x, int B, int C, int Cpad, int64_t HW, void* stream);
 int l2i_cast_h8_to_f32_f16(float* y, const void* x, int B, int C, int Cpad, int64_t HW, void* stream);
@@ -419,7 +425,7 @@ int l2i_adam_guarded_f32(float* p, const float* g, float* m, float* v, float* st
 
 const char* l2i_last_error(void);
 /* Bumped whenever a struct of this header grows or an entry point changes meaning (1: round 1-2; 2: round 3, l2i_conv_params gained w_bstride /
- * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32, mask_out / mask_bits fields, l2i_mask_mul_bits_h8, the mask_bits argument of l2i_upfirdn2d_h8; 7: round 6: l2i_conv1x1_pair_h8).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
+ * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32, mask_out / mask_bits fields, l2i_mask_mul_bits_h8, the mask_bits argument of l2i_upfirdn2d_h8; 7: round 6: l2i_conv1x1_pair_h8, l2i_conv_chain3_h8).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
 #define L2I_ABI_VERSION 7
 int l2i_abi_version(void);
 int l2i_sizeof_conv_params(void);       /* sizeof(struct l2i_conv_params) of THIS build */

@@ -68,6 +68,7 @@ _SIGNATURES = {
     'l2i_conv_transpose2d_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv_img_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv1x1_pair_h8': (c_i, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvParams), c_i, c_p]),
+    'l2i_conv_chain3_h8': (c_i, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvParams), ctypes.POINTER(ConvParams), c_i, c_p]),
     'l2i_fused_bias_act_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
     'l2i_fused_bias_act_f16': (c_i, [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_i, c_i, c_f, c_f, c_p]),
     'l2i_upfirdn2d_f16': (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

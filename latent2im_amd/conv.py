@@ -811,31 +811,45 @@ def run_h8(planes, x, y, cin, cout, k, stride, pad, transposed=False, w_bstride=
 PAIR_VARIANT = int(_os.environ.get('L2I_H8_PAIR_TILE', '-1'))      # -1: by map size (launch_pair_h8); 0 / 1: l2i_conv1x1_pair_h8's variant argument
 
 
+PAIR_MAX_COUT2 = int(_os.environ.get('L2I_H8_PAIR_MAXC', '256'))     # (A/B: 128 leaves the 256-channel shapes — one block per CU — to separate launches)
 PAIR_SHAPES = ((64, 64), (128, 128), (256, 256), (64, 128), (128, 256))          # (input channels of the first conv, output channels of the second) l2i_conv1x1_pair_h8 is built for
 
 
 def pair_h8_shapes_ok(cin1, cout1, cout2, npix):
     """Does l2i_conv1x1_pair_h8 take two chained 1x1 stride-1 convs cin1 -> cout1 -> cout2 on maps of ``npix`` pixels (include/l2i.h lists the conditions)?"""
-    return (cin1, cout2) in PAIR_SHAPES and cout1 % 32 == 0 and npix % 128 == 0
+    return (cin1, cout2) in PAIR_SHAPES and cout2 <= PAIR_MAX_COUT2 and cout1 % 32 == 0 and npix % 128 == 0
+
+
+CHAIN3_SHAPES = ((64, 64), (128, 128), (64, 128))        # (channels of the 3x3 conv, output channels of the last conv) l2i_conv_chain3_h8 is built for
+
+
+def chain3_h8_shapes_ok(c, cout1, cout2, h, w):
+    """Does l2i_conv_chain3_h8 take 3x3 (c -> c) -> 1x1 (c -> cout1) -> 1x1 (cout1 -> cout2) on h x w maps?"""
+    return (c, cout2) in CHAIN3_SHAPES and cout2 <= PAIR_MAX_COUT2 and cout1 % 32 == 0 and w % 32 == 0 and h % 4 == 0
 
 
 def launch_pair_h8(deferred, variant=None):
-    """``deferred``: the two structs ``run_h8(..., _defer=deferred)`` left (first conv, then the conv that reads its output): ONE launch of
-    l2i_conv1x1_pair_h8 on the current stream.  Raises L2IError when the library refuses the pair (the caller checks ``pair_h8_eligible`` shapes first)."""
+    """``deferred``: the structs ``run_h8(..., _defer=deferred)`` left — two (a 1x1 conv, then the 1x1 conv that reads its output: l2i_conv1x1_pair_h8) or three
+    (a 3x3 stride-1 conv in front of them: l2i_conv_chain3_h8): ONE launch on the current stream.  Raises L2IError when the library refuses the chain (the caller
+    checks ``pair_h8_shapes_ok`` / ``chain3_h8_shapes_ok`` first)."""
     lib = _lib.load()
-    (p1, f16, keep1, fl1), (p2, f16b, keep2, fl2) = deferred
-    assert f16 == f16b
-    name = 'l2i_conv1x1_pair_h8' + ('_f16' if f16 else '')
+    head = deferred[0] if len(deferred) == 3 else None
+    (p1, f16, keep1, fl1), (p2, f16b, keep2, fl2) = deferred[-2:]
+    assert f16 == f16b and (head is None or head[1] == f16)
+    name = ('l2i_conv_chain3_h8' if head is not None else 'l2i_conv1x1_pair_h8') + ('_f16' if f16 else '')
     entry = getattr(lib, name)
     npix = int(p1.H) * int(p1.W)
     if variant is None:
         variant = PAIR_VARIANT if PAIR_VARIANT >= 0 else (1 if int(p1.B) * npix < 256 * 1024 else 0)      # 128-pixel tiles below 1024 blocks of 256 pixels
+    args = ((head[0],) if head is not None else ()) + (p1, p2, int(variant), _lib.stream_ptr())
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.check(entry(p1, p2, int(variant), _lib.stream_ptr()), name)
+        _lib.check(entry(*args), name)
         e1.record()
         B, c1, c2, c3 = int(p1.B), int(p1.Cin), int(p1.Cout), int(p2.Cout)
-        PROFILE.append((e0, e1, 2.0 * B * npix * (c1 * c2 + c2 * c3), (B, c1, c2, 1, 1, 1, int(p1.H), int(p1.W), int(p1.H), int(p1.W), 1, False, False, fl1 + '+' + fl2, c3), name, 'conv_h8'))            # (priced in the conv_h8 family: its 1x1 launches are what it replaces; bench.call_bytes knows the entry name)
+        flop = 2.0 * B * npix * (c1 * c2 + c2 * c3 + (9 * c1 * c1 if head is not None else 0))
+        # (priced in the conv_h8 family: its launches are what this one replaces; bench.call_bytes knows the entry names)
+        PROFILE.append((e0, e1, flop, (B, c1, c2, 1, 1, 1, int(p1.H), int(p1.W), int(p1.H), int(p1.W), 1, False, False, fl1 + '+' + fl2, c3), name, 'conv_h8'))
         return
-    _lib.check(entry(p1, p2, int(variant), _lib.stream_ptr()), name)
+    _lib.check(entry(*args), name)

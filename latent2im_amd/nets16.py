@@ -51,6 +51,7 @@ RGB_FUSED = os.environ.get('L2I_H8_RGB_FUSED', '1') != '0'
 # [r6] ResNet-50's backward reads one-bit sign planes written by the forward convs instead of the activation maps themselves (l2i.h: mask_out / mask_bits).
 # L2I_H8_SIGN_PLANES=0: the maps, as in round 5 (A/B).
 SIGN_PLANES = os.environ.get('L2I_H8_SIGN_PLANES', '1') != '0'
+CHAIN3 = os.environ.get('L2I_H8_CHAIN3', '1') != '0'       # [r6] ... and the 3x3 conv in front of such a pair in the same launch (l2i_conv_chain3_h8)
 PAIR = os.environ.get('L2I_H8_PAIR', '1') != '0'          # [r6] ResNet-50's trunk: chained 1x1 convs as one launch (csrc/l2i_pair_h8.hip); 0: separate launches (A/B)
 # [r5] the per-sample weight planes of all modulated convs of a pass in ONE launch (kernels16.ModulatePlan) instead of one 15 us launch per layer and
 # pass (51 per step).  L2I_H8_MOD_MULTI=0: per layer (A/B).
@@ -243,6 +244,12 @@ class ResNet50:
         return torch.addmm(self.fc_b, feat, self.fc_w.t())
 
 
+def _NO_MAP(like):
+    """Stand-in for the output of a conv whose map is never written (the 3x3 head of l2i_conv_chain3_h8): carries shape and dtype for the parameter struct,
+    owns no new memory (the deferred launch clears its pointer)."""
+    return like
+
+
 class _ResNet16Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, net):
@@ -276,19 +283,28 @@ class _ResNet16Fn(torch.autograd.Function):
             else:
                 m1 = m2 = mo = None
             y1 = ahead[0] if ahead is not None else blk['c1'].conv.forward(cur, bias=blk['c1'].bias, act=C.ACT_RELU, mask_out=m1)
-            y2 = blk['c2'].conv.forward(y1, bias=blk['c2'].bias, act=C.ACT_RELU, mask_out=m2)
             idt = blk['down'].conv.forward(cur, bias=blk['down'].bias) if blk['down'] is not None else cur
             nxt = net.blocks[bi + 1] if bi + 1 < n_blk else None
             ahead = None
-            if PAIR and nxt is not None and C.pair_h8_shapes_ok(blk['c3'].conv.cinp, blk['c3'].conv.cout, nxt['c1'].conv.cout, hw_out[0] * hw_out[1]):
+            c2, c3 = blk['c2'].conv, blk['c3'].conv
+            pair = PAIR and nxt is not None and C.pair_h8_shapes_ok(c3.cinp, c3.cout, nxt['c1'].conv.cout, hw_out[0] * hw_out[1])
+            # [r6] CHAIN3: conv2 joins the launch too where it is a stride-1 3x3 on a shape the library has (l2i_conv_chain3_h8): one launch per bottleneck, y2 never
+            # written (its sign plane is, for the backward)
+            chain = pair and CHAIN3 and c2.stride == 1 and (bits or not keep) and C.chain3_h8_shapes_ok(c2.cinp, c3.cout, nxt['c1'].conv.cout, hw_out[0], hw_out[1])
+            d = []
+            y2 = c2.forward(y1, bias=blk['c2'].bias, act=C.ACT_RELU, mask_out=m2, **(dict(_defer=d, out=_NO_MAP(y1)) if chain else {}))
+            if pair:
                 m1n = torch.empty(cur.shape[0], nxt['c1'].conv.cout // 8, hw_out[0], hw_out[1], device=cur.device, dtype=torch.uint8) if bits else None
-                d = []
-                out = blk['c3'].conv.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU, mask_out=mo, _defer=d)
+                if not chain:
+                    d = []
+                out = c3.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU, mask_out=mo, _defer=d)
                 y1n = nxt['c1'].conv.forward(out, bias=nxt['c1'].bias, act=C.ACT_RELU, mask_out=m1n, _defer=d)
+                if chain:
+                    d[0][0].y = None                       # (the 3x3 conv's map is not written: `y2` above only carries its shape)
                 C.launch_pair_h8(d)
                 ahead = (y1n, m1n)
             else:
-                out = blk['c3'].conv.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU, mask_out=mo)
+                out = c3.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU, mask_out=mo)
             if bits:
                 # (kept as maps: the input of a stride-2 block — its mask rides on the zero-insertion pass — and the last output, for the first mask)
                 keep_cur = blk['down'] is not None and blk['down'].conv.stride == 2
@@ -338,16 +354,24 @@ class _ResNet16Fn(torch.autograd.Function):
             mm = dict(out_mask=m, res_mask=m, **mb) if m is not None else {}
             g_y2 = ahead if ahead is not None else blk['c3'].conv.dgrad(G, hw(y2), out_mask=y2, **mb)
             ahead = None
-            g_y1 = blk['c2'].conv.dgrad(g_y2, hw(y1), out_mask=y1, **mb)
-            del g_y2
+            prev = net.blocks[bi - 1] if bi > 0 else None
+            # [r6] PAIR: conv1's input gradient + trunk gradient, masked, and conv3's input gradient of the block below in one launch; CHAIN3: conv2's input gradient in front
+            pair = (PAIR and bits and m is not None and blk['down'] is None
+                    and C.pair_h8_shapes_ok(blk['c1'].conv.coutp_in, blk['c1'].conv.cin, prev['c3'].conv.cin, cur_hw[0] * cur_hw[1]))
+            chain = pair and CHAIN3 and blk['c2'].conv.stride == 1 and C.chain3_h8_shapes_ok(blk['c2'].conv.coutp_in, blk['c1'].conv.cin, prev['c3'].conv.cin, cur_hw[0], cur_hw[1])
+            d = []
+            g_y1 = blk['c2'].conv.dgrad(g_y2, hw(y1), out_mask=y1, **mb, **(dict(_defer=d, out=_NO_MAP(g_y2)) if chain else {}))
+            if not chain:
+                del g_y2
             if blk['down'] is None:
-                prev = net.blocks[bi - 1]
-                # [r6] PAIR: conv1's input gradient + trunk gradient, masked, and conv3's input gradient of the block below in one launch
-                if PAIR and bits and m is not None and C.pair_h8_shapes_ok(blk['c1'].conv.coutp_in, blk['c1'].conv.cin, prev['c3'].conv.cin, cur_hw[0] * cur_hw[1]):
+                if pair:
                     y2p = saved['blocks'][bi - 1][2]
-                    d = []
+                    if not chain:
+                        d = []
                     Gp = blk['c1'].conv.dgrad(g_y1, cur_hw, residual=G, _defer=d, **mm)
                     ahead = prev['c3'].conv.dgrad(Gp, hw(y2p), out_mask=y2p, _defer=d, **mb)
+                    if chain:
+                        d[0][0].y = None
                     C.launch_pair_h8(d)
                 else:
                     Gp = blk['c1'].conv.dgrad(g_y1, cur_hw, residual=G, **mm)

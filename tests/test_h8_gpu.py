@@ -931,18 +931,18 @@ def test_conv1x1_pair_h8_is_bit_identical_to_two_launches(c1, c2, c3, h, w, batc
 
 
 def test_resnet16_pair_launches_are_bit_identical():
-    """[r6] nets16.ResNet50 with the trunk's chained 1x1 convs as l2i_conv1x1_pair_h8 launches (nets16.PAIR) against the separate launches: predictions of the
-    no-grad pass, predictions and image gradient of the differentiable pass — bit-identical; and the pair launches are really taken at this size."""
+    """[r6] nets16.ResNet50 with the trunk's chained convs as l2i_conv_chain3_h8 / l2i_conv1x1_pair_h8 launches (nets16.CHAIN3 / PAIR) against the separate launches:
+    predictions of the no-grad pass, predictions and image gradient of the differentiable pass — bit-identical; and the fused launches are really taken."""
     from latent2im_amd import nets16, synth
     net = nets16.ResNet50(synth.resnet50_state(seed=301), device=DEV)
     rs = np.random.RandomState(12)
     x = T(rs.randn(2, 3, 256, 256) * 0.5).to(DEV)
     gy = T(rs.randn(2, 40)).to(DEV)
     res, taken = [], []
-    old = nets16.PAIR
+    old = nets16.PAIR, nets16.CHAIN3
     try:
-        for flag in (True, False):
-            nets16.PAIR = flag
+        for pair, chain in ((True, True), (True, False), (False, False)):
+            nets16.PAIR, nets16.CHAIN3 = pair, chain
             conv.PROFILE = []
             with torch.no_grad():
                 p0 = net(x).clone()
@@ -950,11 +950,67 @@ def test_resnet16_pair_launches_are_bit_identical():
             p1 = net(xg)
             p1.backward(gy)
             torch.cuda.synchronize()
-            taken.append(sum(1 for q in conv.PROFILE if q[4].startswith('l2i_conv1x1_pair_h8')))
+            taken.append((sum(1 for q in conv.PROFILE if q[4].startswith('l2i_conv_chain3_h8')), sum(1 for q in conv.PROFILE if q[4].startswith('l2i_conv1x1_pair_h8'))))
             conv.PROFILE = None
             res.append((p0, p1.detach().clone(), xg.grad.detach().clone()))
     finally:
-        nets16.PAIR, conv.PROFILE = old, None
-    assert taken[0] >= 12 and taken[1] == 0, taken          # 64^2 / 32^2 trunks at this input: layer1 + layer2 pairs of two forwards and one backward
-    for a, b in zip(res[0], res[1]):
-        assert torch.equal(a, b) and float(a.abs().max()) > 0
+        (nets16.PAIR, nets16.CHAIN3), conv.PROFILE = old, None
+    # 64^2 / 32^2 / 16^2 trunks at this input: layer1 + layer2 chains of two forwards and one backward, the wider shapes as pairs
+    assert taken[0][0] >= 12 and taken[0][1] >= 3 and taken[1][0] == 0 and taken[1][1] >= 15 and taken[2] == (0, 0), taken
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize('c,c2,c3,h,w,batch', [(64, 256, 64, 16, 32, 2), (128, 512, 128, 8, 32, 2), (64, 256, 128, 24, 64, 1), (64, 256, 64, 12, 32, 3)])
+def test_conv_chain3_h8_is_bit_identical_to_three_launches(c, c2, c3, h, w, batch):
+    """[r6] l2i_conv_chain3_h8: the 3x3 stride-1 conv in front of the pair in the same launch (one launch per ResNet-50 bottleneck: conv2 -> conv3 + identity -> next
+    conv1; backwards: conv2's input gradient -> conv1's + trunk gradient -> conv3's of the block below).  The 3x3 conv's map is never written; its sign plane, the wide
+    map and the last conv's output (and their planes) equal the three l2i_conv2d_h8 launches' bit for bit, on tiles that cross the image border (zero padding)
+    and on both tile variants."""
+    rs = np.random.RandomState(c + h)
+    g = lambda t: t.to(DEV)
+    H3 = conv.H8Conv(T(rs.randn(c, c, 3, 3) / np.sqrt(9 * c)), 1, 1, device=DEV, cin_pad=16)
+    A = conv.H8Conv(T(rs.randn(c2, c, 1, 1) / np.sqrt(c)), 1, 0, device=DEV)
+    Bc = conv.H8Conv(T(rs.randn(c3, c2, 1, 1) / np.sqrt(c2)), 1, 0, device=DEV)
+    x = conv.to_h8(g(T(rs.randn(batch, c, h, w))), 16)
+    res = conv.to_h8(g(T(rs.randn(batch, c2, h, w))), 8)
+    b0, ba, bb = g(T(rs.randn(c) * 0.3)), g(T(rs.randn(c2))), g(T(rs.randn(c3) * 0.3))
+    plane = lambda ch, fill: torch.full((batch, ch // 8, h, w), fill, device=DEV, dtype=torch.uint8)
+    assert conv.chain3_h8_shapes_ok(c, c2, c3, h, w)
+    # ---- forward form ----
+    m0, m_mid, m_out = plane(c, 0xAA), plane(c2, 0xAA), plane(c3, 0x55)
+    y0 = H3.forward(x, bias=b0, act=conv.ACT_RELU, mask_out=m0)
+    mid0 = A.forward(y0, bias=ba, residual=res, act=conv.ACT_RELU, mask_out=m_mid)
+    out0 = Bc.forward(mid0, bias=bb, act=conv.ACT_RELU, mask_out=m_out)
+    for variant in (0, 1):
+        if variant == 0 and h % 8:
+            continue
+        q0, qm, qo = plane(c, 0x11), plane(c2, 0x22), plane(c3, 0x33)
+        d = []
+        y1 = H3.forward(x, bias=b0, act=conv.ACT_RELU, mask_out=q0, _defer=d)
+        mid1 = A.forward(y1, bias=ba, residual=res, act=conv.ACT_RELU, mask_out=qm, _defer=d)
+        out1 = Bc.forward(mid1, bias=bb, act=conv.ACT_RELU, mask_out=qo, _defer=d)
+        d[0][0].y = None                                   # the 3x3 conv's map is not wanted
+        conv.launch_pair_h8(d, variant=variant)
+        torch.cuda.synchronize()
+        assert torch.equal(mid0.view(torch.int16), mid1.view(torch.int16)) and torch.equal(out0.view(torch.int16), out1.view(torch.int16)), variant
+        assert torch.equal(m0, q0) and torch.equal(m_mid, qm) and torch.equal(m_out, qo), variant
+    # ---- backward form ----
+    bits0 = torch.from_numpy(rs.randint(0, 256, size=(batch, c // 8, h, w)).astype(np.uint8)).to(DEV)
+    bits1 = torch.from_numpy(rs.randint(0, 256, size=(batch, c2 // 8, h, w)).astype(np.uint8)).to(DEV)
+    bits2 = torch.from_numpy(rs.randint(0, 256, size=(batch, c3 // 8, h, w)).astype(np.uint8)).to(DEV)
+    y0 = H3.forward(x, out_mask=bits0, mask_bits=True)
+    mid0 = A.forward(y0, residual=res, out_mask=bits1, res_mask=bits1, mask_bits=True)
+    out0 = Bc.forward(mid0, out_mask=bits2, mask_bits=True)
+    for variant in (0, 1):
+        if variant == 0 and h % 8:
+            continue
+        d = []
+        y1 = H3.forward(x, out_mask=bits0, mask_bits=True, _defer=d)
+        mid1 = A.forward(y1, residual=res, out_mask=bits1, res_mask=bits1, mask_bits=True, _defer=d)
+        out1 = Bc.forward(mid1, out_mask=bits2, mask_bits=True, _defer=d)
+        d[0][0].y = None
+        conv.launch_pair_h8(d, variant=variant)
+        torch.cuda.synchronize()
+        assert torch.equal(mid0.view(torch.int16), mid1.view(torch.int16)) and torch.equal(out0.view(torch.int16), out1.view(torch.int16)), variant

@@ -13,6 +13,9 @@ conv.PRECISION = sys.argv[1] if len(sys.argv) > 1 else 'f16'
 SHAPES = [('layer1 256^2', 64, 256, 64, 256), ('layer1->2 256^2', 64, 256, 128, 256), ('layer2 128^2', 128, 512, 128, 128), ('layer2->3 128^2', 128, 512, 256, 128),
           ('layer3 64^2', 256, 1024, 256, 64)]
 B, NSET, INNER, REPS = 8, 4, 8, 7
+import os
+if os.environ.get('PAIR_BENCH_ONLY'):
+    SHAPES = [q for q in SHAPES if q[0].startswith(os.environ['PAIR_BENCH_ONLY'])]
 
 
 def timeit(fn):
@@ -66,6 +69,43 @@ def main():
             Bc.forward(mids[i], out=outs[i], out_mask=po[i], mask_bits=True, _defer=d)
             conv.launch_pair_h8(d, variant=variant)
 
+        if os.environ.get('PAIR_BENCH_CHAIN3') and c3 <= 128 and c1 <= 128:
+            H3 = conv.H8Conv(T(rs.randn(c1, c1, 3, 3) / np.sqrt(9 * c1)), 1, 1, device=DEV, cin_pad=16)
+            x3, y3s, p3 = mk(c1), mk(c1), pl(c1)
+            b3 = torch.randn(c1, device=DEV)
+
+            def three_f(i):
+                H3.forward(x3[i], out=xs[i], bias=b3, act=conv.ACT_RELU, mask_out=p3[i])
+                two_f(i)
+
+            def chain_f(i, variant=0):
+                d = []
+                H3.forward(x3[i], out=xs[i], bias=b3, act=conv.ACT_RELU, mask_out=p3[i], _defer=d)
+                A.forward(xs[i], out=mids[i], bias=ba, residual=rss[i], act=conv.ACT_RELU, mask_out=pm[i], _defer=d)
+                Bc.forward(mids[i], out=outs[i], bias=bb, act=conv.ACT_RELU, mask_out=po[i], _defer=d)
+                d[0][0].y = None
+                conv.launch_pair_h8(d, variant=variant)
+
+            def three_b(i):
+                H3.forward(x3[i], out=xs[i], out_mask=p3[i], mask_bits=True)
+                two_b(i)
+
+            def chain_b(i, variant=0):
+                d = []
+                H3.forward(x3[i], out=xs[i], out_mask=p3[i], mask_bits=True, _defer=d)
+                A.forward(xs[i], out=mids[i], residual=rss[i], out_mask=pm[i], res_mask=pm[i], mask_bits=True, _defer=d)
+                Bc.forward(mids[i], out=outs[i], out_mask=po[i], mask_bits=True, _defer=d)
+                d[0][0].y = None
+                conv.launch_pair_h8(d, variant=variant)
+
+            row = '%-18s chain3 | fwd three launches %6.1f  3x3 + pair %6.1f' % (name, timeit(three_f), timeit(lambda i: (H3.forward(x3[i], out=xs[i], bias=b3, act=conv.ACT_RELU, mask_out=p3[i]), pair_f(i, 0 if c1 == 64 else 1))))
+            for v in (0, 1):
+                row += '  chain3[v%d] %6.1f' % (v, timeit(lambda i: chain_f(i, v)))
+            row += ' | bwd three %6.1f' % timeit(three_b)
+            for v in (0, 1):
+                row += '  chain3[v%d] %6.1f' % (v, timeit(lambda i: chain_b(i, v)))
+            print(row, flush=True)
+            continue
         t2f, t2b = timeit(two_f), timeit(two_b)
         row = '%-18s wide map %6.1f MB | fwd two %6.1f' % (name, unit, t2f)
         for v in (0, 1):
