@@ -211,6 +211,8 @@ def call_bytes(q):
     """Algorithmic HBM bytes of a conv call: input (+ its gradient mask) read once, output written once, every fused epilogue
     operand (residual, its mask, output mask, accumulate, res_sub) read once; weights / per-sample vectors are noise."""
     B, cin, cout, kh, kw, stride, H, W, OH, OW, step, in_mask = q[3][:12]
+    if q[4] == 'l2i_conv1x1_pair_f32':                      # [r6] the fp32 pair: input, identity, the wide map written, the narrow output
+        return 4.0 * B * H * W * (cin + 2 * cout + q[3][14])
     if q[4].startswith(('l2i_conv1x1_pair_h8', 'l2i_conv_chain3_h8')):                                 # [r6] two chained 1x1 convs: input, the first conv's operand map, the wide map written, the narrow output
         return 2.0 * B * H * W * (cin + 2 * cout + q[3][14])            # (chain3: cin = the 3x3 conv's input, read once plus its halo)
     flags = q[3][13] if len(q[3]) > 13 else ''

@@ -193,6 +193,12 @@ int l2i_conv1x1_pair_h8(const l2i_conv_params* first, const l2i_conv_params* sec
  * three results equal the three launches' bit for bit.  Needs W % 32 == 0, H % 4 == 0 and (C, Cout2) one of (64, 64), (128, 128), (64, 128). */
 int l2i_conv_chain3_h8(const l2i_conv_params* head3x3, const l2i_conv_params* first, const l2i_conv_params* second, int variant, void* stream);
 
+/* [ABI 7] The fp32 twin of l2i_conv1x1_pair_h8 (csrc/l2i_pair_f32.hip): `first` = a 1x1 stride-1 conv of l2i_conv2d_f32 with bias / residual / ReLU (its y, the wide
+ * map, is written), `second` = the 1x1 conv that reads it (bias / ReLU), one launch, the wide map not read back.  Both structs filled as for l2i_conv2d_f32
+ * (w = the [Cin][1][CoutP] pack).  The second conv adds its channel pairs in another order than l2i_conv2d_f32: equal to fp32 rounding, not bit for bit.
+ * Refused (L2I_E_UNSUPPORTED; the caller launches the two convs) unless H * W % 256 == 0 and (Cin1, Cout2) is (64, 64), (64, 128) or (128, 128). */
+int l2i_conv1x1_pair_f32(const l2i_conv_params* first, const l2i_conv_params* second, void* stream);
+
 /* [r5] The image-side convolutions of the 16-bit path (csrc/l2i_img_h8.hip): x = fp32 NCHW image [B, Cin <= 4, H, W], y = 16-bit h8
  * [B, Cout/8, OHf, OWf, 8], 16-bit MFMA with fp32 accumulation on operands rounded to the element type inside the kernel — VGG-19 conv1_1
  * (3x3 / stride 1; transform_base.py:426-454), the discriminator's from-RGB 1x1 (networks.py:568-575), ResNet-50's 7x7 / stride 2 stem
@@ -425,7 +431,7 @@ int l2i_adam_guarded_f32(float* p, const float* g, float* m, float* v, float* st
 
 const char* l2i_last_error(void);
 /* Bumped whenever a struct of this header grows or an entry point changes meaning (1: round 1-2; 2: round 3, l2i_conv_params gained w_bstride /
- * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32, mask_out / mask_bits fields, l2i_mask_mul_bits_h8, the mask_bits argument of l2i_upfirdn2d_h8; 7: round 6: l2i_conv1x1_pair_h8, l2i_conv_chain3_h8).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
+ * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32, mask_out / mask_bits fields, l2i_mask_mul_bits_h8, the mask_bits argument of l2i_upfirdn2d_h8; 7: round 6: l2i_conv1x1_pair_h8, l2i_conv_chain3_h8, l2i_conv1x1_pair_f32).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
 #define L2I_ABI_VERSION 7
 int l2i_abi_version(void);
 int l2i_sizeof_conv_params(void);       /* sizeof(struct l2i_conv_params) of THIS build */

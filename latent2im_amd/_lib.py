@@ -64,6 +64,7 @@ _SIGNATURES = {
     'l2i_conv_transpose2d_bf16x3_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_wino_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_wino4_f32': (c_i, [ctypes.POINTER(ConvParams), c_p]),
+    'l2i_conv1x1_pair_f32': (c_i, [ctypes.POINTER(ConvParams), ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv2d_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv_transpose2d_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),
     'l2i_conv_img_h8': (c_i, [ctypes.POINTER(ConvParams), c_p]),

@@ -374,8 +374,8 @@ def run_fused_transposed(F, x, y, in_scale=None, in_mask=None, mask=(1.0, 0.0), 
 
 def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0), out_scale=None, noise=None,
                noise_w=0.0, bias=None, residual=None, res_mask=None, out_mask=None, act=ACT_NONE, slope=0.2, gain=1.0,
-               out_gain=1.0, accumulate=False, tile_hint=0, res_sub=None, res_coef=1.0, res_coef_dev=None, sq=None, pool=None):
-    """Enqueue one kernel call on the current stream.  ``y`` is the full output tensor [B, Cout, OHf, OWf].  ``pool`` ([r5]) = (pooled [B, Cout, OHf/2, OWf/2]
+               out_gain=1.0, accumulate=False, tile_hint=0, res_sub=None, res_coef=1.0, res_coef_dev=None, sq=None, pool=None, _defer=None):
+    """Enqueue one kernel call on the current stream.  ``_defer`` (a list): a plain 1x1 stride-1 launch appends its struct instead (``launch_pair_f32``).  ``y`` is the full output tensor [B, Cout, OHf, OWf].  ``pool`` ([r5]) = (pooled [B, Cout, OHf/2, OWf/2]
     fp32, arg-max bytes of the same shape, [fused flag]): where the launch takes the position-split F(4x4) kernel it also writes MaxPool2d(2, 2) of y
     (l2i.h: pool_out / pool_idx) and sets the flag; otherwise the caller runs the pool kernel."""
     lib = _lib.load()
@@ -413,6 +413,10 @@ def run_launch(L, x, y, out_hw=None, in_scale=None, in_mask=None, mask=(1.0, 0.0
     if out_mask is not None:
         assert out_mask.shape == y.shape
     entry, name = lib.l2i_conv2d_f32, 'l2i_conv2d_f32'
+    if _defer is not None:
+        assert L.kh == 1 and L.kw == 1 and L.stride == 1 and L.step == 1
+        _defer.append((p, (x, y, L.w, bias, residual)))
+        return
     if (L.w4 is not None and tile_hint == 0 and out_scale is None and noise is None and bias is None and residual is None and out_mask is None
             and act == ACT_NONE):                          # the launch takes the direct VALU kernel (l2i_conv2d_family): hand it the dense pack
         p.w, p.CoutP = _lib.fptr(L.w4), 4
@@ -853,3 +857,27 @@ def launch_pair_h8(deferred, variant=None):
         PROFILE.append((e0, e1, flop, (B, c1, c2, 1, 1, 1, int(p1.H), int(p1.W), int(p1.H), int(p1.W), 1, False, False, fl1 + '+' + fl2, c3), name, 'conv_h8'))
         return
     _lib.check(entry(*args), name)
+
+
+PAIR_F32_SHAPES = ((64, 64), (64, 128), (128, 128))       # (input channels of the first conv, output channels of the second) l2i_conv1x1_pair_f32 is built for
+
+
+def pair_f32_shapes_ok(cin1, cout1, cout2, npix):
+    return (cin1, cout2) in PAIR_F32_SHAPES and cout1 % 32 == 0 and npix % 256 == 0
+
+
+def launch_pair_f32(deferred):
+    """``deferred``: the two structs ``run_launch(..., _defer=deferred)`` left (a 1x1 conv with bias / residual / ReLU, then the 1x1 conv that reads its output):
+    ONE launch of l2i_conv1x1_pair_f32 on the current stream."""
+    lib = _lib.load()
+    (p1, keep1), (p2, keep2) = deferred
+    name = 'l2i_conv1x1_pair_f32'
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.l2i_conv1x1_pair_f32(p1, p2, _lib.stream_ptr()), name)
+        e1.record()
+        B, c1, c2, c3, npix = int(p1.B), int(p1.Cin), int(p1.Cout), int(p2.Cout), int(p1.H) * int(p1.W)
+        PROFILE.append((e0, e1, 2.0 * B * npix * (c1 * c2 + c2 * c3), (B, c1, c2, 1, 1, 1, int(p1.H), int(p1.W), int(p1.H), int(p1.W), 1, False, False, 'br1+b1', c3), name, 'gemm1x1_f32'))
+        return
+    _lib.check(lib.l2i_conv1x1_pair_f32(p1, p2, _lib.stream_ptr()), name)

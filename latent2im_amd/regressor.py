@@ -58,6 +58,7 @@ class ResNet50:
         return torch.addmm(self.fc_b, feat, self.fc_w.t())
 
 
+PAIR = __import__('os').environ.get('L2I_R_PAIR', '1') != '0'            # [r6] chained 1x1 convs of the trunk as one launch (csrc/l2i_pair_f32.hip); 0: separate launches (A/B)
 PREMASK = __import__('os').environ.get('L2I_R_PREMASK', '1') != '0'      # 0: the round-5 mask plumbing of the backward (A/B)
 
 
@@ -92,14 +93,28 @@ class _ResNetFeatFn(torch.autograd.Function):
         p0, idx0 = K.maxpool2d_fwd(a0, 3, 2, 1)
         saved = dict(in_hw=(x.shape[2], x.shape[3]), a0=a0 if keep else None, idx0=idx0 if keep else None, blocks=[])
         cur = p0
-        for blk in net.blocks:
-            y1 = blk['c1'].conv.forward(cur, bias=blk['c1'].bias, act=C.ACT_RELU)
+        # [r6] PAIR: conv3 + identity + ReLU of a block and conv1 + ReLU of the NEXT block as one launch where the library has the shape (l2i_conv1x1_pair_f32:
+        # the wide map goes from the first conv's accumulators to the second conv's MFMAs in registers — written once, not read back)
+        ahead = None
+        n_blk = len(net.blocks)
+        for bi, blk in enumerate(net.blocks):
+            y1 = ahead if ahead is not None else blk['c1'].conv.forward(cur, bias=blk['c1'].bias, act=C.ACT_RELU)
             y2 = blk['c2'].conv.forward(y1, bias=blk['c2'].bias, act=C.ACT_RELU)
             if blk['down'] is not None:
                 idt = blk['down'].conv.forward(cur, bias=blk['down'].bias)
             else:
                 idt = cur
-            out = blk['c3'].conv.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU)
+            nxt = net.blocks[bi + 1] if bi + 1 < n_blk else None
+            ahead = None
+            c3 = blk['c3'].conv
+            if (PAIR and C.PRECISION == 'f32' and nxt is not None and c3.k == 1 and c3.stride == 1 and nxt['c1'].conv.stride == 1
+                    and C.pair_f32_shapes_ok(c3.cin, c3.cout, nxt['c1'].conv.cout, y2.shape[2] * y2.shape[3])):
+                d = []
+                out = c3.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU, _defer=d)
+                ahead = nxt['c1'].conv.forward(out, bias=nxt['c1'].bias, act=C.ACT_RELU, _defer=d)
+                C.launch_pair_f32(d)
+            else:
+                out = c3.forward(y2, bias=blk['c3'].bias, residual=idt, act=C.ACT_RELU)
             if keep:
                 saved['blocks'].append((y1, y2, out, (cur.shape[2], cur.shape[3])))
             cur = out

@@ -1205,3 +1205,31 @@ def test_resnet_backward_premasked_trunk_equals_round5_plumbing(size, batch):
         R.PREMASK = old
     err = float((grads[0] - grads[1]).abs().max() / grads[1].abs().max())
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize('c1,c2,c3,h,w,batch', [(64, 256, 64, 16, 32, 2), (64, 256, 128, 16, 16, 3), (128, 512, 128, 32, 32, 1)])
+def test_conv1x1_pair_f32_matches_two_launches(c1, c2, c3, h, w, batch):
+    """[r6] l2i_conv1x1_pair_f32 (csrc/l2i_pair_f32.hip): ResNet-50's conv3 + identity + ReLU and the next block's conv1 + ReLU in one fp32 launch, the wide map
+    handed over in the MFMA's registers.  Against the two l2i_conv2d_f32 launches: the wide map bit for bit (same K order), the second conv's output to fp32
+    rounding (its channel pairs are summed in another order: 1e-5 of the map's magnitude), and both against float64 torch."""
+    from latent2im_amd import conv
+    rs = np.random.RandomState(c1 + h)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    wa, wb = T(rs.randn(c2, c1, 1, 1) / np.sqrt(c1)), T(rs.randn(c3, c2, 1, 1) / np.sqrt(c2))
+    A, Bc = conv.FrozenConv2d(wa, 1, 0, device=DEV), conv.FrozenConv2d(wb, 1, 0, device=DEV)
+    x, res = T(rs.randn(batch, c1, h, w)).to(DEV), T(rs.randn(batch, c2, h, w)).to(DEV)
+    ba, bb = T(rs.randn(c2)).to(DEV), T(rs.randn(c3) * 0.3).to(DEV)
+    assert conv.pair_f32_shapes_ok(c1, c2, c3, h * w)
+    mid0 = A.forward(x, bias=ba, residual=res, act=conv.ACT_RELU)
+    out0 = Bc.forward(mid0, bias=bb, act=conv.ACT_RELU)
+    d = []
+    mid1 = A.forward(x, bias=ba, residual=res, act=conv.ACT_RELU, _defer=d)
+    out1 = Bc.forward(mid1, bias=bb, act=conv.ACT_RELU, _defer=d)
+    conv.launch_pair_f32(d)
+    torch.cuda.synchronize()
+    ref_mid = torch.relu(torch.nn.functional.conv2d(x.double(), wa.double().to(DEV)) + ba.double().view(1, -1, 1, 1) + res.double())
+    ref_out = torch.relu(torch.nn.functional.conv2d(ref_mid, wb.double().to(DEV)) + bb.double().view(1, -1, 1, 1))
+    scale_m, scale_o = float(ref_mid.abs().max()), float(ref_out.abs().max())
+    assert float((mid1.double() - ref_mid).abs().max()) < 2e-6 * scale_m and float((out1.double() - ref_out).abs().max()) < 4e-6 * scale_o
+    assert float((mid1 - mid0).abs().max()) < 1e-6 * scale_m and float((out1 - out0).abs().max()) < 1e-5 * scale_o
+    assert 0.1 < float((out1 > 0).float().mean()) < 0.9
