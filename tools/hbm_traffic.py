@@ -37,7 +37,7 @@ def family_of(kernel):
         return 'winograd_f32'
     if kernel.startswith('conv_mfma_kernel') or kernel.startswith('conv3x3s2_dma_kernel') or kernel.startswith('splitk_epilogue'):
         return 'implicit_gemm_f32'
-    if kernel.startswith('gemm1x1_kernel'):
+    if kernel.startswith('gemm1x1_kernel') or 'pair_f32_kernel' in kernel:      # [r6] the fp32 pair launch replaces two of the GEMM kernel's: same family
         return 'gemm1x1_f32'
     if kernel.startswith('convt_mfma_kernel'):
         return 'transposed_f32'
@@ -45,7 +45,7 @@ def family_of(kernel):
         return 'cin3_f32'
     if kernel.startswith('conv_direct_small_kernel'):
         return 'direct_small_valu'
-    if kernel.startswith('pair_h8_kernel'):               # [r6] two chained 1x1 convs of the 16-bit path in one launch: same family
+    if 'pair_h8_kernel' in kernel:               # [r6] two chained 1x1 convs of the 16-bit path in one launch: same family
         return 'conv_h8'
     if kernel.startswith('conv_img_h8_kernel'):           # [r5] the image-side convs of the 16-bit path: bench.py prices them in the conv_h8 family
         return 'conv_h8'
