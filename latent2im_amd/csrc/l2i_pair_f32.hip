@@ -29,7 +29,7 @@
 typedef float pf32x16 __attribute__((ext_vector_type(16)));
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 
-namespace {
+namespace l2i_pair_f32 {
 
 struct PairF32Launch {
     int total, tiles_per_sample, npix, nch;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, OCC) void pair_f32_kernel(const l2i_conv_param
 }
 
 template <int K1, int MC, int WN, int OCC>
-int launch_pair_f32(const l2i_conv_params& p1, const l2i_conv_params& p2, hipStream_t st) {
+static int launch_pair_f32(const l2i_conv_params& p1, const l2i_conv_params& p2, hipStream_t st) {
     PairF32Launch L;
     L.npix = p1.H * p1.W;
     L.tiles_per_sample = L.npix / (128 * WN);
@@ -208,7 +208,7 @@ int launch_pair_f32(const l2i_conv_params& p1, const l2i_conv_params& p2, hipStr
     return L2I_OK;
 }
 
-const char* pair_f32_unsupported(const l2i_conv_params& p) {
+static const char* pair_f32_unsupported(const l2i_conv_params& p) {
     if (!p.w || !p.y) return "null tensor";
     if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad_y != 0 || p.pad_x != 0 || p.oy_step != 1 || p.ox_step != 1 || p.oy_off || p.ox_off) return "both convs must be 1x1, stride 1, pad 0, dense output";
     if (p.OH != p.H || p.OW != p.W || p.OHf != p.H || p.OWf != p.W) return "output maps have the input's size";
@@ -220,7 +220,8 @@ const char* pair_f32_unsupported(const l2i_conv_params& p) {
     if (p.CoutP < p.Cout || (p.CoutP % 32) != 0 || (p.Cout % 32) != 0 || (p.Cin % 32) != 0) return "channel counts must be multiples of 32";
     return nullptr;
 }
-}  // namespace
+}  // namespace l2i_pair_f32
+using namespace l2i_pair_f32;
 
 extern "C" int l2i_conv1x1_pair_f32(const l2i_conv_params* first, const l2i_conv_params* second, void* stream) {
     if (!first || !second) return l2i_set_error(L2I_E_ARG, "conv1x1_pair_f32: null params");

@@ -62,8 +62,8 @@ def load(d, name):
     out = {}
     for r in csv.DictReader(open('%s/run_counter_collection.csv' % d)):
         if r['Counter_Name'] == name:
-            kname = r['Kernel_Name'].split('(')[0].replace('void ', '')
-            for ns in ('l2i_h8_bf16::', 'l2i_h8s_bf16::', 'l2i_h8_f16::', 'l2i_h8s_f16::'):      # [r5] the h8 kernels live in per-element-type namespaces
+            kname = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
+            for ns in ('l2i_h8_bf16::', 'l2i_h8s_bf16::', 'l2i_h8_f16::', 'l2i_h8s_f16::', 'l2i_pair_f32::'):      # [r5] the h8 kernels live in per-element-type namespaces
                 kname = kname.replace(ns, '')
             out[int(r['Dispatch_Id'])] = (kname, int(r['Grid_Size']), float(r['Counter_Value']) * 1024.0)
     return out

@@ -13,8 +13,8 @@ import sys
 
 
 def short(n):
-    n = n.replace('void ', '').split('(')[0]
-    for ns in ('l2i_h8_bf16::', 'l2i_h8s_bf16::', 'l2i_h8_f16::', 'l2i_h8s_f16::'):      # [r5] per-element-type namespaces of the h8 kernels
+    n = n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
+    for ns in ('l2i_h8_bf16::', 'l2i_h8s_bf16::', 'l2i_h8_f16::', 'l2i_h8s_f16::', 'l2i_pair_f32::'):      # [r5] per-element-type namespaces of the h8 kernels
         n = n.replace(ns, '')
     return n
 

@@ -4,7 +4,7 @@ import collections, csv, sys
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
-        rows[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append((int(r['Dispatch_Id']), float(r['Counter_Value']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+        rows[r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')][r['Counter_Name']].append((int(r['Dispatch_Id']), float(r['Counter_Value']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
 for k, cs in rows.items():
     if not any(s in k for s in ('conv', 'gemm', 'wino')):
         continue

@@ -7,7 +7,7 @@ import sys
 rows = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for r in csv.DictReader(open(sys.argv[1])):
-    k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+    k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
     for ns in ('l2i_h8_bf16::', 'l2i_h8s_bf16::', 'l2i_h8_f16::', 'l2i_h8s_f16::'):
         k = k.replace(ns, '')
     rows[k][r['Counter_Name']] += float(r['Counter_Value'])
