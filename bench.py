@@ -475,7 +475,7 @@ def main():
                          "matrix cores (fp32-class results)")
     ap.add_argument('--hip_graph', type=int, default=None, help='1: replay forward+backward from one hipGraph (c5 default), 0: eager launches')
     ap.add_argument('--no_config5', action='store_true', help='skip the `config5` block (c5 workload, 16-bit path, hipGraph) of a c3 run')
-    ap.add_argument('--config5_steps', type=int, default=10)
+    ap.add_argument('--config5_steps', type=int, default=20, help='timed steps of the config5 block (20: one host hiccup of 20 ms moves the figure by 3 %, not 6)')
     ap.add_argument('--no_reg_only', action='store_true', help='skip the `reg_only` figures')
     ap.add_argument('--no_allreduce_rehearsal', action='store_true', help='N = 1: do not build the one-rank RCCL group for `allreduce_us` (profiler runs)')
     ap.add_argument('--direct_3x3', action='store_true', help='run 3x3 stride-1 layers on the direct implicit-GEMM kernel instead of Winograd')
