@@ -429,9 +429,16 @@ int l2i_adam_guarded_f32(float* p, const float* g, float* m, float* v, float* st
                          int32_t check_self, int32_t* state, float* scale, float growth, float backoff, int32_t interval, float max_scale,
                          int32_t last, void* stream);
 
+/* [ABI 7] The regressor head and its BCE term in one launch (csrc/l2i_loss.hip) — transform_base.py:416-424: pred = fc(feat)[:, cols]; loss =
+ * -mean(y log(max(pred, eps)) + (1 - y) log(max(1 - pred, eps))) (fp32 logs, float64 sum, like the torch expression on an fp32 pred and a float64 y).
+ * feat [B, F], fc_w [A, F], fc_b [A] fp32; cols [K] int64 (K <= 64); target [B, K] float64 (target_f64 = 1) or fp32.  Writes loss[0] (float64), preds [B, K] and
+ * g_feat [B, F] = d loss / d feat for an upstream gradient of 1 (clamp passes the gradient where its argument >= eps, as torch.clamp does). */
+int l2i_reg_bce_f32(double* loss, float* preds, float* g_feat, const float* feat, const float* fc_w, const float* fc_b, const int64_t* cols,
+                    const void* target, int target_f64, int B, int F, int K, float eps, void* stream);
+
 const char* l2i_last_error(void);
 /* Bumped whenever a struct of this header grows or an entry point changes meaning (1: round 1-2; 2: round 3, l2i_conv_params gained w_bstride /
- * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32, mask_out / mask_bits fields, l2i_mask_mul_bits_h8, the mask_bits argument of l2i_upfirdn2d_h8; 7: round 6: l2i_conv1x1_pair_h8, l2i_conv_chain3_h8, l2i_conv1x1_pair_f32).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
+ * out_f32; 3: round 4: l2i_conv2d_wino4_f32, l2i_sizeof_conv_params; 4: round 5: the l2i_*_h8_f16 entry points, wino4 tile_hint / CoutP % 32; 5: round 5: in_h8 / rgb_* fields, l2i_conv_img_h8; 6: round 6: l2i_nonfinite_flag_f32 / l2i_adam_guarded_f32, mask_out / mask_bits fields, l2i_mask_mul_bits_h8, the mask_bits argument of l2i_upfirdn2d_h8; 7: round 6: l2i_conv1x1_pair_h8, l2i_conv_chain3_h8, l2i_conv1x1_pair_f32, l2i_reg_bce_f32).  The ctypes binding (latent2im_amd/_lib.py) refuses a library whose version or struct size differs from its own mirror. */
 #define L2I_ABI_VERSION 7
 int l2i_abi_version(void);
 int l2i_sizeof_conv_params(void);       /* sizeof(struct l2i_conv_params) of THIS build */

@@ -110,6 +110,7 @@ _SIGNATURES = {
     'l2i_modulate_planes_h8': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'l2i_modulate_planes_multi_h8': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     'l2i_segmented_matvec_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    'l2i_reg_bce_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     'l2i_nonfinite_flag_f32': (c_i, [c_p, c_l, c_p, c_p]),
     'l2i_adam_guarded_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_i, c_p, c_p, c_f, c_f, c_i, c_f, c_i, c_p]),
     'l2i_last_error': (ctypes.c_char_p, []),

@@ -35,3 +35,6 @@ WALK_IS_MLP = False
 
 # fp16 elements (--precision f16): clean steps before the dynamic loss-scale factor doubles again (torch.cuda.amp.GradScaler's growth_interval)
 LOSS_SCALE_GROWTH_INTERVAL = 2000
+
+# [r6] regressor head + BCE (+ their backward) as one launch each way (csrc/l2i_loss.hip); 0: the torch ops (A/B)
+FUSED_REG_LOSS = _os.environ.get('L2I_FUSED_REG_LOSS', '1') != '0'

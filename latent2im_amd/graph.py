@@ -218,6 +218,33 @@ def attribute_change_bucket(pred, org):
 # ----------------------------------------------------------------------------------------------------------------
 # TransformGraph
 # ----------------------------------------------------------------------------------------------------------------
+class _RegBceFn(torch.autograd.Function):
+    """loss = get_bce_loss(fc(feat)[:, cols], target.double()).mean() (transform_base.py:416-424), forward and d loss / d feat, one launch (l2i_reg_bce_f32)."""
+
+    @staticmethod
+    def forward(ctx, feat, fc_w, fc_b, cols, target):
+        from . import _lib
+        feat = feat.detach().contiguous()
+        assert feat.dtype == torch.float32 and feat.is_cuda and fc_w.shape[1] == feat.shape[1] and target.dtype in (torch.float32, torch.float64)
+        B, F = feat.shape
+        K = int(cols.numel())
+        target = target.detach().contiguous()
+        assert tuple(target.shape) == (B, K), (target.shape, B, K)
+        loss = torch.empty(1, dtype=torch.float64, device=feat.device)
+        preds = torch.empty(B, K, dtype=torch.float32, device=feat.device)
+        g = torch.empty_like(feat)
+        _lib.check(_lib.load().l2i_reg_bce_f32(_lib.ptr(loss), _lib.fptr(preds), _lib.fptr(g), _lib.fptr(feat), _lib.fptr(fc_w), _lib.fptr(fc_b), _lib.ptr(cols),
+                                              _lib.ptr(target), int(target.dtype == torch.float64), B, F, K, 1e-12, _lib.stream_ptr()), 'l2i_reg_bce_f32')
+        ctx.save_for_backward(g)
+        ctx.preds = preds
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (g,) = ctx.saved_tensors
+        return torch.mul(g, g_loss), None, None, None, None          # (fp32 tensor x 0-dim float64 tensor -> fp32: one launch)
+
+
 class TransformGraph:
     def __init__(self, lr, walk_type, nsliders, loss_type, eps, N_f, trainEmbed, attrList, attrTable, layers, stylegan_opts,
                  nets=None):
@@ -332,8 +359,13 @@ class TransformGraph:
 
     def get_reg_loss(self, feed_dict):
         logit = feed_dict['logit']
+        reg = self.regressor
+        if constants.FUSED_REG_LOSS and hasattr(reg, 'features') and len(self.attrIdx) <= 64:
+            # [r6] fc + column select + the float64 BCE and everything autograd would run backwards through them as ONE launch each way (csrc/l2i_loss.hip):
+            # ~40 launches of a few microseconds between the regressor's last conv and its first gradient conv otherwise
+            return _RegBceFn.apply(reg.features(logit), reg.fc_w, reg.fc_b, self._attr_columns(), feed_dict['alpha'])
         alpha_gt = feed_dict['alpha'].to(torch.double)
-        preds = self.regressor(logit).index_select(1, self._attr_columns())
+        preds = reg(logit).index_select(1, self._attr_columns())
         return self.get_bce_loss(preds, alpha_gt).mean()
 
     def prefetch_content_taps(self, org_img):

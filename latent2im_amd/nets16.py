@@ -239,9 +239,11 @@ class ResNet50:
         self.fc_w = torch.as_tensor(np.asarray(P['fc.weight']), dtype=torch.float32).contiguous().to(device)
         self.fc_b = torch.as_tensor(np.asarray(P['fc.bias']), dtype=torch.float32).contiguous().to(device)
 
+    def features(self, img):
+        return _ResNet16Fn.apply(img, self)
+
     def __call__(self, img):
-        feat = _ResNet16Fn.apply(img, self)
-        return torch.addmm(self.fc_b, feat, self.fc_w.t())
+        return torch.addmm(self.fc_b, self.features(img), self.fc_w.t())
 
 
 def _NO_MAP(like):

@@ -52,10 +52,13 @@ class ResNet50:
         self.fc_w = torch.as_tensor(np.asarray(P['fc.weight']), dtype=torch.float32).contiguous().to(device)
         self.fc_b = torch.as_tensor(np.asarray(P['fc.bias']), dtype=torch.float32).contiguous().to(device)
 
+    def features(self, img):
+        """[B,3,H,W] -> [B, 2048] pooled features (what ``fc`` reads); differentiable w.r.t. img."""
+        return _ResNetFeatFn.apply(img, self)
+
     def __call__(self, img):
         """[B,3,H,W] -> [B, num_classes]; differentiable w.r.t. img."""
-        feat = _ResNetFeatFn.apply(img, self)                  # [B, 2048] pooled features
-        return torch.addmm(self.fc_b, feat, self.fc_w.t())
+        return torch.addmm(self.fc_b, self.features(img), self.fc_w.t())
 
 
 PAIR = __import__('os').environ.get('L2I_R_PAIR', '1') != '0'            # [r6] chained 1x1 convs of the trunk as one launch (csrc/l2i_pair_f32.hip); 0: separate launches (A/B)

@@ -1233,3 +1233,34 @@ def test_conv1x1_pair_f32_matches_two_launches(c1, c2, c3, h, w, batch):
     assert float((mid1.double() - ref_mid).abs().max()) < 2e-6 * scale_m and float((out1.double() - ref_out).abs().max()) < 4e-6 * scale_o
     assert float((mid1 - mid0).abs().max()) < 1e-6 * scale_m and float((out1 - out0).abs().max()) < 1e-5 * scale_o
     assert 0.1 < float((out1 > 0).float().mean()) < 0.9
+
+
+def test_fused_regressor_bce_matches_torch_ops():
+    """[r6] l2i_reg_bce_f32 (csrc/l2i_loss.hip): fc + attribute-column select + the float64 BCE of transform_base.py:416-424 and their autograd backward in one
+    launch each way, against the torch expression it replaces (graph.get_bce_loss on fc(feat)[:, cols]) — loss (float64) and d loss / d feat, for float64 and fp32
+    targets, with predictions on both sides of the clamp (pred < eps and 1 - pred < eps: the clamp stops the gradient there), K = 1, 5, 40."""
+    from latent2im_amd import graph as G
+    rs = np.random.RandomState(7)
+    F, A = 2048, 40
+    fc_w = torch.from_numpy((rs.randn(A, F) / np.sqrt(F)).astype(np.float32)).to(DEV)
+    fc_b = torch.from_numpy((rs.randn(A) * 0.3 + 0.5).astype(np.float32)).to(DEV)
+    bce = G.TransformGraph.get_bce_loss
+    for B, cols, dt in ((8, [3, 7, 11, 20, 39], torch.float64), (8, [31], torch.float32), (3, list(range(40)), torch.float64)):
+        K = len(cols)
+        feat0 = torch.from_numpy(rs.randn(B, F).astype(np.float32) * 0.8).to(DEV)
+        target = torch.from_numpy(rs.uniform(0, 1, size=(B, K))).to(DEV).to(dt)
+        ci = torch.tensor(cols, dtype=torch.long, device=DEV)
+        fa = feat0.clone().requires_grad_(True)
+        la = bce(None, torch.addmm(fc_b, fa, fc_w.t()).index_select(1, ci), target.to(torch.double)).mean()
+        (la * 10).backward()
+        fb = feat0.clone().requires_grad_(True)
+        lb = G._RegBceFn.apply(fb, fc_w, fc_b, ci, target)
+        (lb * 10).backward()
+        torch.cuda.synchronize()
+        assert lb.dtype == torch.float64 and lb.dim() == 0
+        assert abs(float(la) - float(lb)) < 1e-6 * max(1.0, abs(float(la))), (float(la), float(lb))
+        scale = float(fa.grad.abs().max())
+        # (1 / pred amplifies the last-bit difference of two summation orders of the 2048-long fc dot where pred is small: 1.5e-4 measured with predictions at 1e-3)
+        assert scale > 0 and float((fa.grad - fb.grad).abs().max()) < 5e-4 * scale, (float((fa.grad - fb.grad).abs().max()), scale)
+        p = torch.addmm(fc_b, feat0, fc_w.t()).index_select(1, ci)
+        assert bool((p < 1e-12).any()) and bool((p > 1).any())          # both clamp branches are exercised
