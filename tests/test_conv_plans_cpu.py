@@ -144,3 +144,18 @@ def test_kernel_source_hash_follows_the_sources_not_the_binary():
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'l2i.h')
     src = open(hdr).read()
     assert '#define L2I_ABI_VERSION %d' % _lib.ABI_VERSION in src
+
+
+def test_fused_trunk_shape_predicates():
+    """[r6] Which of ResNet-50's chained convs the library fuses (conv.pair_h8_shapes_ok / chain3_h8_shapes_ok / pair_f32_shapes_ok mirror the refusals of
+    l2i_conv1x1_pair_h8 / l2i_conv_chain3_h8 / l2i_conv1x1_pair_f32): the trunk shapes of a 1024^2 and of a 256^2 regressor input, and what must stay separate."""
+    from latent2im_amd import conv
+    # (first conv's input channels, wide channels, second conv's output channels, map side)
+    assert conv.pair_h8_shapes_ok(64, 256, 64, 256 * 256) and conv.pair_h8_shapes_ok(64, 256, 128, 256 * 256) and conv.pair_h8_shapes_ok(128, 512, 128, 128 * 128)
+    assert conv.pair_h8_shapes_ok(128, 512, 256, 128 * 128) and conv.pair_h8_shapes_ok(256, 1024, 256, 64 * 64)
+    assert not conv.pair_h8_shapes_ok(512, 2048, 512, 32 * 32) and not conv.pair_h8_shapes_ok(256, 1024, 512, 64 * 64)      # layer4: too few pixels for the tiling
+    assert not conv.pair_h8_shapes_ok(64, 256, 64, 9 * 9)                                                              # H * W must be a multiple of 128
+    assert conv.chain3_h8_shapes_ok(64, 256, 64, 256, 256) and conv.chain3_h8_shapes_ok(128, 512, 128, 32, 32) and conv.chain3_h8_shapes_ok(64, 256, 128, 64, 64)
+    assert not conv.chain3_h8_shapes_ok(256, 1024, 256, 64, 64) and not conv.chain3_h8_shapes_ok(64, 256, 64, 16, 16)      # the 3x3 head: C <= 128, W % 32 == 0
+    assert conv.pair_f32_shapes_ok(64, 256, 64, 256 * 256) and conv.pair_f32_shapes_ok(128, 512, 128, 128 * 128) and not conv.pair_f32_shapes_ok(256, 1024, 256, 64 * 64)
+    assert not conv.pair_f32_shapes_ok(64, 256, 64, 8 * 16)
