@@ -28,6 +28,9 @@ CASES = {
                bounded=False, f64=False),
     'g256': dict(size=256, batch=4, attrs=['Smiling'], z_seed=6, alpha=lambda: np.ones((4, 1)) * 0.37, clamp=False, bounded=False, f64=True),
     'g1024': dict(size=1024, batch=1, attrs=['Smiling'], z_seed=12, alpha=lambda: np.ones((1, 1)) * 0.41, clamp=False, bounded=True, f64=True),
+    # [r6] two more float64 samples of the bench resolution for the walk-gradient bar (the round-5 review: "the float64 bound at 1024^2 is one sample")
+    'g1024b': dict(size=1024, batch=1, attrs=['Smiling'], z_seed=19, alpha=lambda: np.ones((1, 1)) * 0.77, clamp=False, bounded=True, f64=True),
+    'g1024c': dict(size=1024, batch=1, attrs=['Smiling'], z_seed=23, alpha=lambda: np.ones((1, 1)) * 0.15, clamp=False, bounded=True, f64=True),
     'c5': dict(size=1024, batch=1, attrs=SCENE5, scene=True, z_seed=15, alpha=lambda: np.ones((1, 5)) * np.random.RandomState(16).uniform(-1, 1, 5), clamp=True,
                bounded=True, f64=True),
     # [r5] the 16-bit path's step tests (tools/bf16_study.py:step: five scene attributes, clamp flow) at their three sizes: float64 evaluations
